@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Imports World-In-World's vendored diffusers fork read-only from
+/root/reference (shims: oracle/_ref_import.py), loads seeded weights drawn by
+`wiw_amd.weights.random_state_dict` into the reference modules (no checkpoint exists offline),
+runs the reference code and stores inputs + reference outputs as small .npz files.
+The reference itself never travels to the GPU box; only these vectors do.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Fixtures written (all fp32 unless noted):
+  scheduler_tables.npz     EulerDiscreteScheduler sigmas/timesteps/init_noise_sigma for 10/25/30 steps
+  action_ids.npz           utils/svd_utils.get_action_ids (micro_cond) on nav sequences
+  noise_rotation.npz       pipeline.sample_latent_noise on a fixed draw
+  unet_tiny_b1.npz         tiny UNet forward, B=1 with CFG (fp32 reference + the reference's own bf16 run)
+  unet_tiny_b2.npz         tiny UNet forward, B=2: literal reference batch (cross-wired)
+                           and the two B=1 runs that define the build's contract
+  blocks_tiny.npz          inputs/outputs of one SpatioTemporalResBlock (with shortcut) and one
+                           TransformerSpatioTemporalModel captured by forward hooks
+  pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
+                           tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from _ref_import import import_reference  # noqa: E402
+import wiw_amd  # noqa: E402,F401
+from wiw_amd.config import UNetConfig  # noqa: E402
+from wiw_amd.weights import random_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+VERSIONS = dict(torch=torch.__version__, numpy=np.__version__)
+
+
+def save(name, **arrs):
+    import transformers
+
+    meta = dict(VERSIONS, transformers=transformers.__version__)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, _versions=np.array(repr(meta)), **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def ref_unet(ns, cfg: UNetConfig, seed: int):
+    m = ns.UNet(block_out_channels=cfg.block_out_channels, num_attention_heads=cfg.num_attention_heads,
+                num_frames=cfg.num_frames, action_strategy="micro_cond", task_type="navigation",
+                action_input_channel=cfg.action_input_channel)
+    sd = {k: torch.from_numpy(v) for k, v in random_state_dict(cfg, seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def make_scheduler(ns):
+    return ns.EulerDiscreteScheduler(
+        beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", prediction_type="v_prediction",
+        timestep_type="continuous", use_karras_sigmas=True, sigma_min=0.002, sigma_max=700.0,
+        timestep_spacing="leading", steps_offset=1, interpolation_type="linear")
+
+
+def gen_scheduler(ns):
+    arrs = {}
+    for n in (3, 10, 25, 30):
+        s = make_scheduler(ns)
+        s.set_timesteps(n)
+        arrs[f"sigmas_{n}"] = s.sigmas.numpy().astype(np.float32)
+        arrs[f"timesteps_{n}"] = s.timesteps.numpy().astype(np.float32)
+        arrs[f"init_noise_sigma_{n}"] = np.array(float(s.init_noise_sigma), dtype=np.float64)
+    # one Euler step known answer
+    s = make_scheduler(ns)
+    s.set_timesteps(10)
+    rs = np.random.RandomState(7)
+    x = torch.from_numpy(rs.standard_normal((1, 2, 4, 4, 8)).astype(np.float32)) * 700
+    v = torch.from_numpy(rs.standard_normal((1, 2, 4, 4, 8)).astype(np.float32))
+    xs = [x.numpy()]
+    for i, t in enumerate(s.timesteps[:3]):
+        inp = s.scale_model_input(x, t)
+        if i == 0:
+            arrs["step_scaled_input0"] = inp.numpy()
+        x = s.step(v, t, x).prev_sample
+        xs.append(x.numpy())
+    arrs["step_v"] = v.numpy()
+    arrs["step_x"] = np.stack(xs)
+    save("scheduler_tables.npz", **arrs)
+
+
+def gen_action_ids(ns):
+    acts = np.array([[4, 1, 2, 1, 3, 1, 1, 2, 2, 1, 3, 3, 1, 1],
+                     [1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0],
+                     [4, 3, 3, 3, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1]], dtype=np.int64)
+    ids = ns.get_action_ids(3, torch.from_numpy(acts), "micro_cond", torch.float32)
+    save("action_ids.npz", actions=acts, action_ids=ids.numpy())
+
+
+def gen_noise_rotation(ns):
+    pl = ns.pipeline_module
+    rs = np.random.RandomState(11)
+    noise = rs.standard_normal((2, 6, 4, 4, 32)).astype(np.float32)
+    acts = np.array([[4, 2, 2, 1, 3, 3], [4, 3, 1, 2, 1, 1]], dtype=np.int64)
+    orig = pl.randn_tensor
+    pl.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.from_numpy(noise.copy())
+    try:
+        out = pl.sample_latent_noise(torch.from_numpy(acts), noise.shape, "cpu", torch.float32, None)
+    finally:
+        pl.randn_tensor = orig
+    save("noise_rotation.npz", noise=noise, actions=acts, rotated=out.numpy())
+
+
+def unet_inputs(cfg, B, h, w, seed):
+    rs = np.random.RandomState(seed)
+    T = cfg.num_frames
+    sample = rs.standard_normal((2 * B, T, 8, h, w)).astype(np.float32)
+    ehs = rs.standard_normal((2 * B, 1, cfg.cross_attention_dim)).astype(np.float32)
+    ehs[:B] = 0  # CFG: uncond half zeros (pipeline:221-227)
+    sample[:B, :, 4:] = 0  # uncond image latents zeros (pipeline:244-250)
+    tids = np.tile(np.array([[6, 127, 0.02]], dtype=np.float32), (2 * B, 1))
+    acts = np.stack([np.array(([4, 2, 1, 3, 1, 2, 3, 1] * 4)[:T]), np.array(([4, 1, 3, 3, 2, 1, 1, 2] * 4)[:T])])[:B]
+    return sample, ehs, tids, acts.astype(np.int64)
+
+
+def gen_unet(ns):
+    cfg = UNetConfig.tiny(4)
+    m = ref_unet(ns, cfg, seed=0)
+    h, w = 8, 16
+    t = 1.0640485  # sigma_8 of the 10-step table
+    # ---- B = 1 (with CFG doubling)
+    sample, ehs, tids, acts = unet_inputs(cfg, 1, h, w, seed=1)
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    captured = {}
+
+    def hook(name):
+        def f(mod, args, kwargs, out):
+            captured[name + "_in"] = args[0].detach().clone()
+            if len(args) > 1 and torch.is_tensor(args[1]):
+                captured[name + "_temb"] = args[1].detach().clone()
+            if "encoder_hidden_states" in kwargs:
+                captured[name + "_ehs"] = kwargs["encoder_hidden_states"].detach().clone()
+            captured[name + "_out"] = (out[0] if isinstance(out, tuple) else out).detach().clone()
+        return f
+
+    hs = [m.down_blocks[1].resnets[0].register_forward_hook(hook("res"), with_kwargs=True),
+          m.down_blocks[1].attentions[0].register_forward_hook(hook("tr"), with_kwargs=True)]
+    with torch.no_grad():
+        out = m(torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids),
+                return_dict=False, added_action_ids=aid)[0]
+    for x in hs:
+        x.remove()
+    mb = ref_unet(ns, cfg, seed=0).to(torch.bfloat16)
+    with torch.no_grad():
+        out_bf16 = mb(torch.from_numpy(sample).bfloat16(), torch.tensor(t), torch.from_numpy(ehs).bfloat16(),
+                      torch.from_numpy(tids).bfloat16(), return_dict=False, added_action_ids=aid.bfloat16())[0]
+    save("unet_tiny_b1.npz", weight_seed=np.array(0), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
+         added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(), out_ref_bf16=out_bf16.float().numpy())
+    save("blocks_tiny.npz", weight_seed=np.array(0),
+         res_prefix=np.array("down_blocks.1.resnets.0"), res_eps=np.array(1e-6),
+         res_in=captured["res_in"].numpy(), res_temb=captured["res_temb"].numpy(), res_out=captured["res_out"].numpy(),
+         tr_prefix=np.array("down_blocks.1.attentions.0"), tr_heads=np.array(2),
+         tr_in=captured["tr_in"].numpy(), tr_ehs=captured["tr_ehs"].numpy(), tr_out=captured["tr_out"].numpy())
+    # ---- B = 2: literal reference batch vs two B=1 runs
+    sample, ehs, tids, acts = unet_inputs(cfg, 2, h, w, seed=2)
+    aid = ns.get_action_ids(2, torch.from_numpy(acts), "micro_cond", torch.float32)
+    with torch.no_grad():
+        out_b = m(torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids),
+                  return_dict=False, added_action_ids=aid)[0]
+        singles = []
+        for b in range(2):
+            idx = [b, 2 + b]
+            singles.append(m(torch.from_numpy(sample[idx]), torch.tensor(t), torch.from_numpy(ehs[idx]),
+                             torch.from_numpy(tids[idx]), return_dict=False, added_action_ids=aid[b:b + 1])[0])
+    contract = torch.stack([singles[0][0], singles[1][0], singles[0][1], singles[1][1]])
+    save("unet_tiny_b2.npz", weight_seed=np.array(0), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
+         added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out_reference_batched=out_b.numpy(),
+         out_contract=contract.numpy())
+
+
+def gen_pipeline(ns):
+    from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    pl = ns.pipeline_module
+    cfg = UNetConfig.tiny(4)
+    unet = ref_unet(ns, cfg, seed=3)
+    torch.manual_seed(0)
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=(32, 64, 64, 64), down_block_types=("DownEncoderBlock2D",) * 4,
+                                       layers_per_block=1, latent_channels=4,
+                                       force_upcast=True, scaling_factor=0.18215).eval()
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=1024)).eval()
+    pipe = StableVideoDiffusionPipeline(vae=vae, image_encoder=clip, unet=unet, scheduler=make_scheduler(ns),
+                                        feature_extractor=CLIPImageProcessor())
+    pipe.set_progress_bar_config(disable=True)
+    H, W = 64, 128  # latent 8 x 16
+    B, T, steps = 2, 4, 3
+    rs = np.random.RandomState(5)
+    from PIL import Image
+
+    imgs = [Image.fromarray(rs.randint(0, 256, size=(H, W, 3), dtype=np.uint8)) for _ in range(B)]
+    acts = np.array([[4, 2, 1, 3], [4, 1, 3, 3]], dtype=np.int64)
+    img_noise = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    lat_noise = rs.standard_normal((1, T, 4, H // 8, W // 8)).astype(np.float32)
+    results, image_latents, image_embeds = [], [], []
+    for b in range(B):  # the served system always calls the worker with batch 1 (worker_manager.py:712)
+        queue = [img_noise, lat_noise]
+        orig = pl.randn_tensor
+        pl.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.from_numpy(queue.pop(0).copy()).to(dtype)
+        cap = {}
+        o_vae, o_img = pipe._encode_vae_image, pipe._encode_image
+
+        def enc_vae(*a, **k):
+            r = o_vae(*a, **k)
+            cap["il"] = r.detach().clone()
+            return r
+
+        def enc_img(*a, **k):
+            r = o_img(*a, **k)
+            cap["ie"] = r.detach().clone()
+            return r
+
+        pipe._encode_vae_image, pipe._encode_image = enc_vae, enc_img
+        try:
+            aid = ns.get_action_ids(1, torch.from_numpy(acts[b:b + 1]), "micro_cond", torch.float32)
+            with torch.no_grad():
+                lat = pipe([imgs[b]], height=H, width=W, num_frames=T, fps=7, motion_bucket_id=127,
+                           noise_aug_strength=0.02, num_inference_steps=steps, added_action_ids=aid,
+                           output_type="latent").frames
+        finally:
+            pl.randn_tensor = orig
+            pipe._encode_vae_image, pipe._encode_image = o_vae, o_img
+        assert not queue
+        results.append(lat[0].numpy())
+        image_latents.append(cap["il"][1].numpy())  # cond half (uncond half is zeros)
+        assert float(cap["il"][0].abs().max()) == 0.0 and float(cap["ie"][0].abs().max()) == 0.0
+        image_embeds.append(cap["ie"][1].numpy())
+    save("pipeline_tiny.npz", weight_seed=np.array(3), num_steps=np.array(steps), actions=acts,
+         latent_noise=np.repeat(lat_noise, B, axis=0), image_latents=np.stack(image_latents),
+         image_embeddings=np.stack(image_embeds), latents_out=np.stack(results))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = import_reference()
+    torch.set_num_threads(8)
+    gen_scheduler(ns)
+    gen_action_ids(ns)
+    gen_noise_rotation(ns)
+    gen_unet(ns)
+    gen_pipeline(ns)
+
+
+if __name__ == "__main__":
+    main()

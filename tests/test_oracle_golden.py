@@ -1,0 +1,101 @@
+"""Pin the CPU oracle (oracle/svd_oracle.py) against vectors produced by the reference itself
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import torch
+
+import svd_oracle as O
+import wiw_amd  # noqa: F401
+from wiw_amd.config import UNetConfig
+from wiw_amd.weights import random_state_dict
+
+
+def _sd(cfg, seed):
+    return {k: torch.from_numpy(v) for k, v in random_state_dict(cfg, int(seed)).items()}
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_scheduler_tables(golden):
+    g = golden("scheduler_tables.npz")
+    for n in (3, 10, 25, 30):
+        sig = O.karras_sigmas(n)
+        np.testing.assert_array_equal(sig, g[f"sigmas_{n}"])  # bit-exact float32 table
+        np.testing.assert_allclose(O.sigma_to_timestep(sig), g[f"timesteps_{n}"], rtol=0, atol=2e-7)
+        assert abs(O.init_noise_sigma(sig) - float(g[f"init_noise_sigma_{n}"])) < 1e-4
+    # SURVEY.md Appendix D known answers
+    np.testing.assert_allclose(O.karras_sigmas(10)[[1, 4, 9]], [352.9922, 26.75720, 0.002], rtol=1e-6)
+
+
+def test_euler_step(golden):
+    g = golden("scheduler_tables.npz")
+    sig = O.karras_sigmas(10)
+    x = torch.from_numpy(g["step_x"][0])
+    v = torch.from_numpy(g["step_v"])
+    np.testing.assert_allclose((x / (float(sig[0]) ** 2 + 1) ** 0.5).numpy(), g["step_scaled_input0"], rtol=1e-6)
+    for i in range(3):
+        x = O.euler_step(v, x, float(sig[i]), float(sig[i + 1]))
+        assert _rel(x.numpy(), g["step_x"][i + 1]) < 1e-6
+
+
+def test_action_ids(golden):
+    g = golden("action_ids.npz")
+    np.testing.assert_array_equal(O.action_ids_idx_encode(g["actions"]), g["action_ids"])
+    dec = O.decode_action_seq_frames(g["action_ids"])
+    assert (dec[:, 0] == 4).all() and (dec[:, 1:] == g["actions"][:, 1:]).all()
+
+
+def test_noise_rotation(golden):
+    g = golden("noise_rotation.npz")
+    out = O.rotate_latent_noise(torch.from_numpy(g["noise"]), g["actions"])
+    np.testing.assert_array_equal(out.numpy(), g["rotated"])
+
+
+def test_blocks(golden):
+    g = golden("blocks_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = _sd(cfg, g["weight_seed"])
+    out = O.spatio_temporal_res_block(sd, str(g["res_prefix"]), torch.from_numpy(g["res_in"]),
+                                      torch.from_numpy(g["res_temb"]), cfg.num_frames, float(g["res_eps"]))
+    assert _rel(out.numpy(), g["res_out"]) < 2e-5
+    out = O.transformer_spatio_temporal(sd, str(g["tr_prefix"]), torch.from_numpy(g["tr_in"]),
+                                        torch.from_numpy(g["tr_ehs"]), cfg.num_frames, int(g["tr_heads"]))
+    assert _rel(out.numpy(), g["tr_out"]) < 2e-5
+
+
+def test_unet_b1(golden):
+    g = golden("unet_tiny_b1.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = _sd(cfg, g["weight_seed"])
+    np.testing.assert_array_equal(O.action_ids_idx_encode(g["actions"]), g["action_ids"])
+    out = O.unet_forward(sd, cfg.as_dict(), torch.from_numpy(g["sample"]), torch.tensor(float(g["timestep"])),
+                         torch.from_numpy(g["ehs"]), torch.from_numpy(g["added_time_ids"]), torch.from_numpy(g["action_ids"]))
+    assert _rel(out.numpy(), g["out"]) < 5e-5
+    # the reference's own bf16 run sets the scale of "bf16-class" error for the HIP parity tests
+    assert 1e-4 < _rel(g["out_ref_bf16"], g["out"]) < 0.2
+
+
+def test_unet_b2_contract_and_quirk(golden):
+    g = golden("unet_tiny_b2.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = _sd(cfg, g["weight_seed"])
+    args = (torch.from_numpy(g["sample"]), torch.tensor(float(g["timestep"])), torch.from_numpy(g["ehs"]),
+            torch.from_numpy(g["added_time_ids"]), torch.from_numpy(g["action_ids"]))
+    contract = O.unet_forward(sd, cfg.as_dict(), *args)
+    assert _rel(contract.numpy(), g["out_contract"]) < 5e-5
+    quirk = O.unet_forward(sd, cfg.as_dict(), *args, reference_quirk=True)
+    assert _rel(quirk.numpy(), g["out_reference_batched"]) < 5e-5
+    # the literal batched reference cross-wires candidates (rows u1 / c0 differ)
+    assert _rel(g["out_reference_batched"][[1, 2]], g["out_contract"][[1, 2]]) > 1e-3
+    assert _rel(g["out_reference_batched"][[0, 3]], g["out_contract"][[0, 3]]) < 5e-5
+
+
+def test_pipeline_loop(golden):
+    g = golden("pipeline_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = _sd(cfg, g["weight_seed"])
+    lat = O.denoise(sd, cfg.as_dict(), torch.from_numpy(g["image_latents"]), torch.from_numpy(g["image_embeddings"]),
+                    torch.from_numpy(g["latent_noise"]), g["actions"], num_steps=int(g["num_steps"]))
+    assert _rel(lat.numpy(), g["latents_out"]) < 1e-4
