@@ -1,0 +1,176 @@
+/*
+ * wiw_svd.h — C ABI of the MI355X-native SVD denoising hot path (libwiwsvd.so).
+ *
+ * The reference (World-In-World) has no FFI: its hot path is Python calling torch.nn modules
+ * (SURVEY.md §8b).  This header is therefore the boundary DESIGNED by the build: one entry point per
+ * device operator that the reference executes implicitly through ATen/cuDNN/cuBLAS/SDPA.  Each
+ * declaration cites the reference call site(s) it replaces; `dp/` =
+ * FTsvd/diffusers-private/diffusers/.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); no internal threads,
+ *     no allocation, no synchronisation inside any entry point (graph-capture safe);
+ *   - activations are bf16 (uint16 storage) token-major: X[m][c], m = ((b*T + t)*H + y)*W + x
+ *     (NHWC per frame); weights bf16 [out][k]; conv weights bf16 [Cout][tap][Cin];
+ *     vectors (bias, gamma, beta, statistics, embeddings, latents) fp32;
+ *   - return value: WIW_OK or a negative WIW_E* code (nothing is launched on error);
+ *     wiw_last_error() returns a static message for the calling thread's last failure.
+ */
+#ifndef WIW_SVD_H
+#define WIW_SVD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WIW_OK 0
+#define WIW_EINVAL -1  /* unsupported shape / null pointer / misaligned argument */
+#define WIW_ELAUNCH -2 /* HIP launch error */
+#define WIW_ENODEV -3  /* no gfx950 device visible */
+
+#define WIW_ABI_VERSION 1
+
+int wiw_abi_version(void);
+const char* wiw_last_error(void);
+/* Returns WIW_OK when device `dev` is a gfx950 (MI355X) and fills optional name buffer. */
+int wiw_device_check(int dev, char* name, int name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution on bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ *
+ *   acc[m][n]  = sum_k Agather[m][k] * W[n][k]
+ *   y          = alpha * (acc + bias[n] + rowvec[m / rows_per_vec][n]) (optionally SiLU)
+ *   out[m][n]  = y + beta1 * res1[m][n] + beta2 * res2[m][n]
+ *   GEGLU      : W rows are stored in tiles of 160 = [80 value | 80 gate] (see weights.py
+ *                `pack_geglu`); out[m][j] = (v + bias_v) * gelu_erf(g + bias_g), N counts packed rows.
+ *
+ * mode WIW_A_DENSE     : Agather[m][k] = concat(A[m][0:C1], A2[m][0:C2])           (K = C1 + C2)
+ *        replaces nn.Linear / 1x1 conv call sites: dp/models/attention_processor.py:2358-2391
+ *        (to_q/k/v/out), dp/models/attention.py:1185-1243 + activations.py:117-123 (GEGLU FF),
+ *        dp/models/transformers/transformer_temporal.py:327,374 (proj_in/out),
+ *        dp/models/resnet.py:311-318 (conv_shortcut over the skip concat, unet_3d_blocks.py:1612),
+ *        dp/models/embeddings.py:804-816 (TimestepEmbedding), resnet.py:343-350 (time_emb_proj).
+ * mode WIW_A_CONV3X3   : 3x3, stride 1, zero pad 1 over (H, Wd)                   (K = 9 * C1)
+ *        dp/models/resnet.py:269,285 (ResnetBlock2D.conv1/conv2), unet:130-135, 255-260.
+ * mode WIW_A_CONV3X3_S2: 3x3, stride 2, pad 1; input is (2H, 2Wd)                 (K = 9 * C1)
+ *        dp/models/downsampling.py:132-150 (Downsample2D).
+ * mode WIW_A_CONV3X3_UP: nearest x2 upsample fused into a 3x3 conv; input (H/2, Wd/2)
+ *        dp/models/upsampling.py:142-186 (Upsample2D).
+ * mode WIW_A_CONV_T3   : (3,1,1) temporal conv, zero pad 1 over T; S = H*Wd       (K = 3 * C1)
+ *        dp/models/resnet.py:570-592 (TemporalResnetBlock.conv1/conv2).
+ * Constraints: C1 % 64 == 0, C2 % 64 == 0, K = taps * (C1 + C2); A2 only with WIW_A_DENSE.
+ * ---------------------------------------------------------------------------------------------- */
+enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_UP = 3, WIW_A_CONV_T3 = 4 };
+enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4 };
+
+typedef struct WiwGemmArgs {
+    const void* A;       /* bf16 [rows_in][C1] */
+    const void* A2;      /* bf16 [rows_in][C2] or NULL */
+    const void* W;       /* bf16 [N][K] */
+    void* out;           /* bf16 (or fp32 with WIW_EPI_OUT_F32) [M][ldo] */
+    const float* bias;   /* [N] or NULL */
+    const float* rowvec; /* [M / rows_per_vec][rowvec_ld] or NULL */
+    const void* res1;    /* bf16 [M][ldr1] or NULL */
+    const void* res2;    /* bf16 [M][ldr2] or NULL */
+    const void* zeros;   /* >= 16 bytes of device zeros (source of padding taps) */
+    int32_t M, N, K;
+    int32_t C1, C2;
+    int32_t mode;
+    int32_t H, Wd, T;    /* OUTPUT geometry of the conv modes */
+    int32_t ldo, ldr1, ldr2;
+    int32_t n_out;       /* GEGLU only: number of valid output columns (N/2 minus packing pad) */
+    int32_t rowvec_ld, rows_per_vec;
+    float alpha, beta1, beta2;
+    int32_t epilogue;    /* WIW_EPI_* bits */
+} WiwGemmArgs;
+
+int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spatial self-attention, head_dim 64, flash-style (online softmax, fp32 statistics):
+ *   O[n][s][h*64 + d] = softmax_s'(Q.K / 8) V,  per frame n and head h.
+ * Replaces F.scaled_dot_product_attention at dp/models/attention_processor.py:2383-2385 as called
+ * from BasicTransformerBlock.attn1 (dp/models/attention.py:507-512).
+ *   QK : bf16 [frames*S][ldqk], Q at column h*64, K at column k_col_off + h*64
+ *   Vt : bf16 [heads*64][ldvt] (V TRANSPOSED: Vt[h*64 + d][n*S + s]), produced by wiw_gemm_bf16 with
+ *        swapped operands; S % 8 == 0 required (16-byte aligned key runs).
+ *   O  : bf16 [frames*S][ldo];  zeros: >= 16 bytes of device zeros (V^T chunks past the frame end)
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt,
+                          void* O, int ldo, int frames, int S, int heads, float scale, const void* zeros);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal self-attention over the T (<= 16) frames of every spatial site, head_dim 64:
+ * rows of site (b, s) are m = (b*T + t)*S + s — the (B*S, T, C) permutes of
+ * dp/models/attention.py:720-722, 758-760 are never materialised.
+ * Replaces TemporalBasicTransformerBlock.attn1 (dp/models/attention.py:735-737).
+ *   QKV : bf16 [batch*T*S][ldqkv] with Q | K | V at columns 0, C, 2C (C = heads*64);  O: [..][ldo]
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, int ldo, int batch, int T, int S,
+                           int heads, float scale);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) in NHWC, split into statistics + fused normalise/affine/SiLU.
+ * Replaces torch.nn.GroupNorm (+ SiLU) at dp/models/resnet.py:327-328, 351-363, 611-622,
+ * dp/models/transformers/transformer_temporal.py:324, unet:565-566.  `rows_per_unit` = H*W for the
+ * per-frame 2D norms and T*H*W for the 5D norms of TemporalResnetBlock (statistics over T too).
+ * The input may be the channel concat of two tensors (skip connections, unet_3d_blocks.py:1612).
+ *   stats : fp32 [units][32][2] (sum, sum of squares) — MUST be zeroed by the caller (wiw_fill_f32);
+ *   ab    : fp32 [units][2][C]  per-channel scale a = rstd*gamma and shift b = beta - mean*a.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                        int rows_per_unit, float* stats);
+int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta, int units,
+                           int C, int rows_per_unit, float eps, float* ab);
+int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                        int rows_per_unit, const float* ab, int silu, void* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel dim with an optional fused pre-add of a per-row-group vector:
+ *   x' = x + addvec[m / rows_per_vec][:]   (written to `sum_out` when non-NULL)
+ *   y  = LayerNorm(x') * gamma + beta      (eps, fp32 two-pass statistics, wave shuffles)
+ * Replaces nn.LayerNorm at dp/models/attention.py:371,401,432,659-694, the `hidden_states + emb`
+ * of transformer_temporal.py:352-353 and the residual add of the single-key cross-attentions
+ * (attention.py:545-551, 740-743; exact elision).   C % 8 == 0, C <= 2048.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma, const float* beta,
+                       float eps, const float* addvec, int addvec_ld, int rows_per_vec, void* sum_out, void* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conditioning embedding rows (unet:464-487, micro_cond, no-grad path) with the SiLU of
+ * resnet.py:343-344 applied once:  out[(i*T + t)][c] = silu(time[i][c] + act[(i % B)*T + t][c] + noise[i][c])
+ * (contract of SURVEY.md §9.2: candidate i % B's actions — NOT the reference's cross-wiring).
+ *   time, noise: fp32 [Bc][E];  act: fp32 [B*T][E];  out: bf16 [Bc*T][E]
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_emb_combine(void* stream, const float* time, const float* act, const float* noise, int Bc, int B, int T,
+                    int E, void* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * UNet input assembly (pipeline:589-593 + scheduler:313-314 + unet:502):
+ *   X[(i*T + t)*h*w + p][0:4]  = latents[i % B][t][:, p] / sqrt(sigma^2 + 1)
+ *   X[...][4:8]                = (i < B) ? 0 : image_latents[i - B][:, p]        (CFG halves)
+ *   X[...][8:Cpad]             = 0   (channel padding so conv_in runs on the MFMA conv kernel)
+ *   latents fp32 (B,T,4,h,w); image_latents fp32 (B,4,h,w); X bf16 [2B*T*h*w][Cpad]
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_prep_unet_input(void* stream, const float* latents, const float* image_latents, int B, int T, int hw,
+                        float sigma, int Cpad, void* X);
+
+/* ------------------------------------------------------------------------------------------------
+ * CFG combine + Euler step, fp32 (pipeline:606-611, scheduler:635-673, v_prediction):
+ *   v  = v_u + g_t (v_c - v_u),  g_t = gmin + (gmax - gmin) * t / (T - 1)
+ *   x0 = -sigma/sqrt(sigma^2+1) v + x/(sigma^2+1);   x += (x - x0)/sigma * (sigma_next - sigma)
+ *   V fp32 [2B*T*h*w][ldv] (UNet output, channels 0..3); latents fp32 (B,T,4,h,w) updated in place.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_cfg_euler_step(void* stream, const float* V, int ldv, float* latents, int B, int T, int hw, float sigma,
+                       float sigma_next, float gmin, float gmax);
+
+/* Utility: fill fp32 buffer (used to zero GroupNorm statistics inside captured graphs). */
+int wiw_fill_f32(void* stream, float* p, int64_t n, float value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIW_SVD_H */

@@ -130,7 +130,7 @@ def unet_inputs(cfg, B, h, w, seed):
 def gen_unet(ns):
     cfg = UNetConfig.tiny(4)
     m = ref_unet(ns, cfg, seed=0)
-    h, w = 8, 16
+    h, w = 16, 32  # L3 = 2x4 = 8 sites: the spatial attention kernel needs S % 8 == 0
     t = 1.0640485  # sigma_8 of the 10-step table
     # ---- B = 1 (with CFG doubling)
     sample, ehs, tids, acts = unet_inputs(cfg, 1, h, w, seed=1)
@@ -147,8 +147,8 @@ def gen_unet(ns):
             captured[name + "_out"] = (out[0] if isinstance(out, tuple) else out).detach().clone()
         return f
 
-    hs = [m.down_blocks[1].resnets[0].register_forward_hook(hook("res"), with_kwargs=True),
-          m.down_blocks[1].attentions[0].register_forward_hook(hook("tr"), with_kwargs=True)]
+    hs = [m.up_blocks[1].resnets[2].register_forward_hook(hook("res"), with_kwargs=True),
+          m.down_blocks[2].attentions[0].register_forward_hook(hook("tr"), with_kwargs=True)]
     with torch.no_grad():
         out = m(torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids),
                 return_dict=False, added_action_ids=aid)[0]
@@ -161,9 +161,9 @@ def gen_unet(ns):
     save("unet_tiny_b1.npz", weight_seed=np.array(0), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
          added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(), out_ref_bf16=out_bf16.float().numpy())
     save("blocks_tiny.npz", weight_seed=np.array(0),
-         res_prefix=np.array("down_blocks.1.resnets.0"), res_eps=np.array(1e-6),
+         res_prefix=np.array("up_blocks.1.resnets.2"), res_eps=np.array(1e-6),
          res_in=captured["res_in"].numpy(), res_temb=captured["res_temb"].numpy(), res_out=captured["res_out"].numpy(),
-         tr_prefix=np.array("down_blocks.1.attentions.0"), tr_heads=np.array(2),
+         tr_prefix=np.array("down_blocks.2.attentions.0"), tr_heads=np.array(2),
          tr_in=captured["tr_in"].numpy(), tr_ehs=captured["tr_ehs"].numpy(), tr_out=captured["tr_out"].numpy())
     # ---- B = 2: literal reference batch vs two B=1 runs
     sample, ehs, tids, acts = unet_inputs(cfg, 2, h, w, seed=2)
@@ -199,7 +199,7 @@ def gen_pipeline(ns):
     pipe = StableVideoDiffusionPipeline(vae=vae, image_encoder=clip, unet=unet, scheduler=make_scheduler(ns),
                                         feature_extractor=CLIPImageProcessor())
     pipe.set_progress_bar_config(disable=True)
-    H, W = 64, 128  # latent 8 x 16
+    H, W = 128, 256  # latent 16 x 32
     B, T, steps = 2, 4, 3
     rs = np.random.RandomState(5)
     from PIL import Image

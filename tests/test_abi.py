@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads, and exports exactly the symbols
+declared in include/wiw_svd.h; the ctypes struct mirrors the C struct.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import wiw_amd  # noqa: F401
+    from wiw_amd.build import build
+
+    return build(verbose=False)
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "wiw_svd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wiw_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(lib_path):
+    from wiw_amd.hip import EXPORTS
+
+    assert declared_symbols() == sorted(EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported"
+    lib.wiw_abi_version.restype = ctypes.c_int
+    assert lib.wiw_abi_version() == 1
+
+
+def test_gemm_args_struct_layout():
+    from wiw_amd.hip import WiwGemmArgs
+
+    # 9 pointers + 19 x 4-byte fields, natural alignment (matches the C struct in wiw_svd.h)
+    assert ctypes.sizeof(WiwGemmArgs) == 9 * 8 + 19 * 4 + 4
+    assert WiwGemmArgs.M.offset == 72 and WiwGemmArgs.epilogue.offset == 72 + 18 * 4
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from wiw_amd.hip import load_library
+
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        load_library(str(tmp_path / "libwiwsvd.so"))
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """Entry points validate before launching: bad arguments return WIW_EINVAL (-1) with a message."""
+    from wiw_amd.hip import WiwGemmArgs, load_library
+
+    lib = load_library(lib_path)
+    a = WiwGemmArgs()
+    assert lib.wiw_gemm_bf16(None, ctypes.byref(a)) == -1
+    assert b"null" in lib.wiw_last_error()
+    assert lib.wiw_attn_temporal_bf16(None, 1, 192, 1, 64, 1, 17, 8, 1, 0.125) == -1
+    assert b"T <= 16" in lib.wiw_last_error()
+    assert lib.wiw_attn_spatial_bf16(None, 1, 128, 64, 1, 8, 1, 64, 1, 4, 1, 0.125, 1) == -1
+    assert b"multiple of 8" in lib.wiw_last_error()

@@ -1,0 +1,326 @@
+"""Parity of every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.  GPU only.
+
+Tolerances (stated here, used below):
+  * kernels compute with bf16 operands and fp32 accumulation and store bf16; against the oracle run in
+    fp32 on the SAME bf16-rounded inputs the only differences are fp32 summation order and the final
+    bf16 rounding (2^-9 relative).  Gate: max|err| <= 1.2e-2 * max|ref| and rms(err) <= 4e-3 * rms(ref).
+  * fp32-output kernels (Euler step, GroupNorm scale/shift): 1e-5 relative.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import svd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    return Hip(torch.device(DEV))
+
+
+def bf(x):  # round to bf16 and back (what the kernels see)
+    return x.to(torch.bfloat16).float()
+
+
+def dev_bf(x):
+    return x.to(DEV, torch.bfloat16).contiguous()
+
+
+def dev_f(x):
+    return x.to(DEV, torch.float32).contiguous()
+
+
+def check(out, ref, max_tol=1.2e-2, rms_tol=4e-3, what=""):
+    out = out.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    err = (out - ref).abs()
+    mx = float(err.max() / (ref.abs().max() + 1e-30))
+    rms = float(err.pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30))
+    print(f"[parity] {what}: max_rel={mx:.3e} rms_rel={rms:.3e}")
+    assert mx <= max_tol and rms <= rms_tol, f"{what}: max_rel={mx:.3e} rms_rel={rms:.3e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM, dense mode
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 160, 64), (300, 320, 320), (28, 1280, 320), (4032, 1280, 1280),
+                                   (1000, 200, 128), (128, 200, 128), (130, 8, 64), (64, 4, 192)])
+def test_gemm_dense_plain(hip, M, N, K):
+    from wiw_amd import hip as H
+
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K)
+    check(out, a @ w.t(), what=f"gemm {M}x{N}x{K}")
+    # asymmetric A = I check (catches a transposed C write)
+    if M == K:
+        eye = torch.eye(M)
+        hip.gemm(dev_bf(eye), dev_bf(w), out, M=M, N=N, K=K, C1=K)
+        check(out, w.t(), what="gemm identity")
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.gemm(dev_bf(a), dev_bf(w), out32, M=M, N=N, K=K, C1=K, epilogue=H.EPI_OUT_F32)
+    check(out32, a @ w.t(), max_tol=2e-5, rms_tol=2e-6, what="gemm f32 out")
+
+
+def test_gemm_epilogues(hip):
+    from wiw_amd import hip as H
+
+    M, N, K, rpv = 700, 320, 256, 50
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / 16)
+    bias, rowvec = rnd(N, seed=3), rnd(M // rpv, N + 24, seed=4)
+    r1, r2 = bf(rnd(M, N, seed=5)), bf(rnd(M, N, seed=6))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    rv_dev = dev_f(rowvec)
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K, bias=dev_f(bias), rowvec=rv_dev[:, 8:], rowvec_ld=N + 24,
+             rows_per_vec=rpv, res1=dev_bf(r1), ldr1=N, beta1=0.7, res2=dev_bf(r2), ldr2=N, beta2=0.3, alpha=0.6)
+    ref = 0.6 * (a @ w.t() + bias + rowvec[:, 8:8 + N].repeat_interleave(rpv, 0)) + 0.7 * r1 + 0.3 * r2
+    check(out, ref, what="gemm epilogue mix")
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K, bias=dev_f(bias), epilogue=H.EPI_SILU)
+    check(out, F.silu(a @ w.t() + bias), what="gemm silu")
+    # in-place residual (out aliases res1), as used by the attention out-projection
+    res = dev_bf(r1).clone()
+    hip.gemm(dev_bf(a), dev_bf(w), res, M=M, N=N, K=K, C1=K, bias=dev_f(bias), res1=res, ldr1=N, beta1=1.0)
+    check(res, a @ w.t() + bias + r1, what="gemm in-place residual")
+
+
+@pytest.mark.parametrize("Cn", [64, 320])
+def test_gemm_geglu(hip, Cn):
+    from wiw_amd import hip as H
+    from wiw_amd.unet import pack_geglu
+
+    M = 520
+    a = bf(rnd(M, Cn, seed=1))
+    w, b = rnd(8 * Cn, Cn, seed=2) / math.sqrt(Cn), rnd(8 * Cn, seed=3)
+    wp, bp, n_half = pack_geglu(w, b)
+    out = torch.empty(M, 4 * Cn, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), dev_bf(wp), out, M=M, N=wp.shape[0], K=Cn, C1=Cn, bias=dev_f(bp), epilogue=H.EPI_GEGLU, n_out=4 * Cn)
+    h = a @ bf(w).t() + b
+    val, gate = h.chunk(2, dim=-1)
+    check(out, val * F.gelu(gate), what=f"gemm geglu C={Cn}")
+
+
+def test_gemm_concat_and_swapped(hip):
+    M, C1, C2, N = 390, 128, 64, 192
+    a1, a2, w = bf(rnd(M, C1, seed=1)), bf(rnd(M, C2, seed=2)), bf(rnd(N, C1 + C2, seed=3) / 14)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a1), dev_bf(w), out, M=M, N=N, K=C1 + C2, C1=C1, A2=dev_bf(a2), C2=C2)
+    check(out, torch.cat([a1, a2], 1) @ w.t(), what="gemm concat-K")
+    # swapped operands -> V^T layout used by spatial attention
+    Cn, Mt = 128, 1000
+    x, wv = bf(rnd(Mt, Cn, seed=4)), bf(rnd(Cn, Cn, seed=5) / 11)
+    vt = torch.empty(Cn, Mt, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(wv), dev_bf(x), vt, M=Cn, N=Mt, K=Cn, C1=Cn)
+    check(vt, (x @ wv.t()).t(), what="gemm swapped (V^T)")
+
+
+# ----------------------------------------------------------------------------------------------
+# implicit-GEMM convolutions
+# ----------------------------------------------------------------------------------------------
+def nhwc(x):  # (N,C,H,W) -> token-major [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def from_nhwc(t, n, h, w):
+    return t.float().cpu().reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 64, 96, 8, 16), (2, 128, 320, 9, 16), (5, 64, 64, 4, 8), (1, 64, 4, 8, 8)])
+def test_conv3x3(hip, n, cin, cout, h, w):
+    from wiw_amd import hip as H
+
+    x = bf(rnd(n, cin, h, w, seed=1))
+    wt = bf(rnd(cout, cin, 3, 3, seed=2) / math.sqrt(9 * cin))
+    b = rnd(cout, seed=3)
+    wk = dev_bf(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=cout, K=9 * cin, C1=cin, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+    check(from_nhwc(out, n, h, w), F.conv2d(x, wt, b, padding=1), what=f"conv3x3 {n}x{cin}->{cout}@{h}x{w}")
+
+
+def test_conv_stride2_and_upsample(hip):
+    from wiw_amd import hip as H
+
+    n, c, h, w = 3, 64, 8, 16
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(c, c, 3, 3, seed=2) / math.sqrt(9 * c))
+    b = rnd(c, seed=3)
+    wk = dev_bf(wt.permute(0, 2, 3, 1).reshape(c, -1))
+    Mo = n * (h // 2) * (w // 2)
+    out = torch.empty(Mo, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=Mo, N=c, K=9 * c, C1=c, mode=H.A_CONV3X3_S2, H=h // 2, Wd=w // 2, bias=dev_f(b))
+    check(from_nhwc(out, n, h // 2, w // 2), F.conv2d(x, wt, b, stride=2, padding=1), what="conv3x3 stride 2")
+    Mo = n * 4 * h * w
+    out = torch.empty(Mo, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=Mo, N=c, K=9 * c, C1=c, mode=H.A_CONV3X3_UP, H=2 * h, Wd=2 * w, bias=dev_f(b))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    check(from_nhwc(out, n, 2 * h, 2 * w), ref, what="nearest-up + conv3x3")
+
+
+@pytest.mark.parametrize("B,T,c,h,w", [(2, 4, 64, 4, 8), (1, 14, 128, 3, 8)])
+def test_conv_temporal(hip, B, T, c, h, w):
+    from wiw_amd import hip as H
+
+    x = bf(rnd(B * T, c, h, w, seed=1))
+    wt = bf(rnd(c, c, 3, 1, 1, seed=2) / math.sqrt(3 * c))
+    b = rnd(c, seed=3)
+    wk = dev_bf(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, -1))
+    M = B * T * h * w
+    out = torch.empty(M, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=c, K=3 * c, C1=c, mode=H.A_CONV_T3, H=h, Wd=w, T=T, bias=dev_f(b))
+    x5 = x.reshape(B, T, c, h, w).permute(0, 2, 1, 3, 4)
+    ref = F.conv3d(x5, wt, b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(B * T, c, h, w)
+    check(from_nhwc(out, B * T, h, w), ref, what=f"temporal conv T={T}")
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def sdpa(q, k, v, heads):
+    Bn, S, C = q.shape
+    d = C // heads
+    q, k, v = (t.reshape(Bn, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    w = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1)
+    return (w @ v).transpose(1, 2).reshape(Bn, S, C)
+
+
+@pytest.mark.parametrize("frames,S,heads", [(2, 128, 1), (3, 144, 2), (1, 8, 2), (2, 200, 5), (1, 1024, 1)])
+def test_attn_spatial(hip, frames, S, heads):
+    C = heads * 64
+    q, k, v = (bf(rnd(frames, S, C, seed=s, scale=sc)) for s, sc in ((1, 1.5), (2, 1.5), (3, 1.0)))
+    qk = dev_bf(torch.cat([q, k], -1).reshape(frames * S, 2 * C))
+    vt = dev_bf(v.reshape(frames * S, C).t())
+    o = torch.empty(frames * S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads, 0.125)
+    check(o.reshape(frames, S, C), sdpa(q, k, v, heads), max_tol=2e-2, rms_tol=8e-3, what=f"attn_spatial S={S} h={heads}")
+
+
+def test_attn_spatial_online_softmax_rescale(hip):
+    """One key with a huge score in a LATE tile forces the running-max rescale branch (every tile)."""
+    frames, S, heads, C = 1, 256, 1, 64
+    q, k, v = bf(rnd(frames, S, C, seed=1)), bf(rnd(frames, S, C, seed=2)), bf(rnd(frames, S, C, seed=3))
+    k[0, 200] = q[0, 17] * 6.0
+    k[0, 70] = q[0, 17] * 3.0
+    qk = dev_bf(torch.cat([q, k], -1).reshape(S, 2 * C))
+    vt = dev_bf(v.reshape(S, C).t())
+    o = torch.empty(S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial(qk, 2 * C, C, vt, S, o, C, frames, S, heads, 0.125)
+    check(o.reshape(frames, S, C), sdpa(q, k, v, heads), max_tol=2e-2, rms_tol=8e-3, what="attn_spatial rescale")
+
+
+@pytest.mark.parametrize("B,T,S,heads", [(2, 4, 32, 1), (1, 14, 72, 5), (3, 16, 8, 2), (2, 1, 8, 1)])
+def test_attn_temporal(hip, B, T, S, heads):
+    C = heads * 64
+    q, k, v = (bf(rnd(B, T, S, C, seed=s, scale=1.5)) for s in (1, 2, 3))
+    qkv = dev_bf(torch.cat([q, k, v], -1).reshape(B * T * S, 3 * C))
+    o = torch.empty(B * T * S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_temporal(qkv, 3 * C, o, C, B, T, S, heads, 0.125)
+
+    def perm(t):  # (B,T,S,C) -> (B*S, T, C)
+        return t.permute(0, 2, 1, 3).reshape(B * S, T, C)
+
+    ref = sdpa(perm(q), perm(k), perm(v), heads).reshape(B, S, T, C).permute(0, 2, 1, 3)
+    check(o.reshape(B, T, S, C), ref, max_tol=2e-2, rms_tol=8e-3, what=f"attn_temporal T={T} S={S} h={heads}")
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c1,c2,h,w,unit_frames", [(4, 64, 0, 4, 8, 1), (4, 320, 0, 6, 8, 1), (4, 128, 64, 4, 8, 1),
+                                                     (4, 1280, 640, 2, 4, 1), (4, 64, 0, 4, 8, 2), (6, 2560, 0, 2, 2, 3)])
+def test_groupnorm(hip, n, c1, c2, h, w, unit_frames):
+    C = c1 + c2
+    x = bf(rnd(n, C, h, w, seed=1) * 2 + 0.5)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    t = nhwc(x)
+    x1 = dev_bf(t[:, :c1])
+    x2 = dev_bf(t[:, c1:]) if c2 else None
+    rows = n * h * w
+    for silu in (True, False):
+        out = hip.groupnorm(x1, c1, x2, c2, rows, unit_frames * h * w, dev_f(gamma), dev_f(beta), 1e-5, silu)
+        if unit_frames == 1:
+            ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+        else:  # 5-D GroupNorm of TemporalResnetBlock: statistics over the frames of a batch item too
+            x5 = x.reshape(n // unit_frames, unit_frames, C, h, w).permute(0, 2, 1, 3, 4)
+            ref = F.group_norm(x5, 32, gamma, beta, 1e-5).permute(0, 2, 1, 3, 4).reshape(n, C, h, w)
+        ref = F.silu(ref) if silu else ref
+        check(from_nhwc(out, n, h, w), ref, what=f"groupnorm C={c1}+{c2} unit={unit_frames} silu={silu}")
+
+
+@pytest.mark.parametrize("rows,C", [(100, 64), (777, 320), (64, 1280), (50, 2048)])
+def test_layernorm(hip, rows, C):
+    x = bf(rnd(rows, C, seed=1) * 1.7 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    out = hip.layernorm(dev_bf(x), rows, C, dev_f(gamma), dev_f(beta))
+    check(out, F.layer_norm(x, (C,), gamma, beta, 1e-5), what=f"layernorm C={C}")
+    rpv = 10
+    av = rnd((rows + rpv - 1) // rpv, C, seed=4)
+    s = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    out = hip.layernorm(dev_bf(x), rows, C, dev_f(gamma), dev_f(beta), addvec=dev_f(av), addvec_ld=C, rows_per_vec=rpv, sum_out=s)
+    xs = bf(x + av.repeat_interleave(rpv, 0)[:rows])
+    check(s, xs, max_tol=1e-6, rms_tol=1e-6, what="layernorm sum_out")
+    check(out, F.layer_norm(xs, (C,), gamma, beta, 1e-5), what=f"layernorm+add C={C}")
+
+
+# ----------------------------------------------------------------------------------------------
+# loop-side kernels
+# ----------------------------------------------------------------------------------------------
+def test_prep_and_euler(hip, golden):
+    B, T, h, w = 2, 4, 4, 8
+    lat = rnd(B, T, 4, h, w, seed=1) * 30
+    img = rnd(B, 4, h, w, seed=2)
+    sigma = 26.7572
+    X = torch.empty(2 * B * T * h * w, 64, dtype=torch.bfloat16, device=DEV)
+    hip.prep_unet_input(dev_f(lat), dev_f(img), B, T, h * w, sigma, 64, X)
+    inp = torch.cat([lat, lat]) / (sigma ** 2 + 1) ** 0.5
+    il = torch.cat([torch.zeros_like(img), img])[:, None].repeat(1, T, 1, 1, 1)
+    ref = torch.cat([inp, il], 2).permute(0, 1, 3, 4, 2).reshape(-1, 8)
+    Xc = X.float().cpu()
+    check(Xc[:, :8], bf(ref), max_tol=8e-3, rms_tol=4e-3, what="prep_unet_input")
+    assert float(Xc[:, 8:].abs().max()) == 0.0
+    # CFG + Euler against the scheduler fixture produced by the reference (3 steps, same v for u and c halves)
+    g = golden("scheduler_tables.npz")
+    sig = O.karras_sigmas(10)
+    x = torch.from_numpy(g["step_x"][0])  # (1,2,4,4,8)
+    v = torch.from_numpy(g["step_v"])
+    Bx, Tx, _, hx, wx = x.shape
+    vtok = v.permute(0, 1, 3, 4, 2).reshape(-1, 4)
+    V = dev_f(torch.cat([vtok, vtok]))
+    xl = dev_f(x)
+    for i in range(3):
+        hip.cfg_euler_step(V, 4, xl, Bx, Tx, hx * wx, float(sig[i]), float(sig[i + 1]), 1.0, 3.0)
+        check(xl, torch.from_numpy(g["step_x"][i + 1]), max_tol=2e-6, rms_tol=1e-6, what=f"euler step {i}")
+    # guidance: v = vu + g_t (vc - vu)
+    vu, vc = rnd(B * T * h * w, 4, seed=5), rnd(B * T * h * w, 4, seed=6)
+    xl = dev_f(lat)
+    hip.cfg_euler_step(dev_f(torch.cat([vu, vc])), 4, xl, B, T, h * w, 2.5, 1.25, 1.0, 3.0)
+    gs = torch.linspace(1.0, 3.0, T).reshape(1, T, 1, 1, 1)
+    to5 = lambda t: t.reshape(B, T, h, w, 4).permute(0, 1, 4, 2, 3)  # noqa: E731
+    vv = to5(vu) + gs * (to5(vc) - to5(vu))
+    check(xl, O.euler_step(vv, lat, 2.5, 1.25), max_tol=2e-6, rms_tol=1e-6, what="cfg + euler")
+
+
+def test_emb_combine(hip):
+    Bc, B, T, E = 4, 2, 3, 256
+    t, a, n = rnd(Bc, E, seed=1), rnd(B * T, E, seed=2), rnd(Bc, E, seed=3)
+    out = torch.empty(Bc * T, E, dtype=torch.bfloat16, device=DEV)
+    hip.emb_combine(dev_f(t), dev_f(a), dev_f(n), Bc, B, T, E, out)
+    ref = t.repeat_interleave(T, 0) + a.reshape(B, T, E).repeat(Bc // B, 1, 1).reshape(Bc * T, E) + n.repeat_interleave(T, 0)
+    check(out, F.silu(ref), what="emb_combine")

@@ -1,0 +1,308 @@
+// Attention kernels for gfx950, head_dim 64, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 softmax.
+//
+// Both kernels use the "transposed" formulation so that the softmax probabilities never leave the
+// registers and no operand needs a transpose in LDS:
+//     S^T = K . Q^T        A = K rows (keys x d),      B = Q rows (queries x d)
+//     O^T = V^T . P^T      A = V^T rows (d x keys),    B = P^T  (from the S^T accumulator itself)
+// The MFMA C/D layout (lane l, reg r: row = 4*(l>>4) + r, col = l & 15) gives every lane 4 consecutive
+// KEYS of one QUERY (l & 15); two such fragments are exactly the 8-element B operand of the next
+// MFMA when the K index of that MFMA is enumerated as  key(q, e) = 16*(e>>2) + 4*q + (e&3)
+// (q = l>>4).  The V^T A operand is read from LDS with the same enumeration (two 8-byte reads), so
+// the contraction is consistent.  Query statistics live in the lanes that own the query column —
+// the O^T accumulator has the same column ownership, so rescaling needs no cross-lane traffic.
+#include "common.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ---------------------------------------------------------------------------------------------
+// Spatial flash attention.  Block = 4 waves = 128 queries of one (frame, head); KV tiles of 64 keys
+// double-buffered in LDS by LDS-DMA (K tile 8 KiB [key][d], V^T tile 8 KiB [d][key]).
+// ---------------------------------------------------------------------------------------------
+constexpr int QB = 128, KB = 64;
+constexpr int KV_STAGE = 16384;   // K tile + V^T tile
+
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
+                                                               const uint16_t* __restrict__ Vt, int64_t ldvt,
+                                                               uint16_t* __restrict__ O, int ldo, int S, int heads,
+                                                               int q_tiles, float scale_log2e, const char* zeros) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KV_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware remap: an XCD walks a contiguous range of (frame, head, q_tile) so K/V stay in its L2
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int qt = bid % q_tiles;
+    const int fh = bid / q_tiles;
+    const int h = fh % heads, n = fh / heads;
+    const int64_t row0 = (int64_t)n * S;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- Q^T B-operands straight from global: lane (query fr, d chunk fq) -> 8 consecutive d
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        int qi = qt * QB + wave * 32 + f * 16 + fr;
+        qi = qi < S ? qi : S - 1;
+        const uint16_t* src = QK + (row0 + qi) * ldqk + h * 64 + fq * 8;
+        qf[f][0] = *(const bf16x8*)(src);
+        qf[f][1] = *(const bf16x8*)(src + 32);
+    }
+
+    // ---- LDS-DMA sources for this lane
+    const int rsub = lane >> 3, pos = lane & 7;
+    const int nkt = (S + KB - 1) / KB;
+    auto issue = [&](int stage, int kt) {
+        char* sK = smem + stage * KV_STAGE + wave * 2 * 1024;
+        char* sV = smem + stage * KV_STAGE + 8192 + wave * 2 * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 16 + i * 8 + rsub;            // row of the tile (key for K, d for V^T)
+            // K: chunk swizzle by (r & 7)
+            int key = kt * KB + r;
+            key = key < S ? key : S - 1;
+            const int ck = pos ^ (r & 7);
+            glds16((const char*)(QK + (row0 + key) * ldqk + k_col_off + h * 64 + ck * 8), sK + i * 1024);
+            // V^T: chunk swizzle by ((r >> 1) & 7); chunks past the end of the frame read zeros
+            const int cv = pos ^ ((r >> 1) & 7);
+            const int key0 = kt * KB + cv * 8;
+            const char* vsrc = key0 < S ? (const char*)(Vt + (int64_t)(h * 64 + r) * ldvt + row0 + key0) : zeros;
+            glds16(vsrc, sV + i * 1024);
+        }
+    };
+
+    f32x4 o[4][2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) o[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    float l_run[2] = {0.f, 0.f};
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+        const char* sK = smem + (kt & 1) * KV_STAGE;
+        const char* sV = sK + 8192;
+        // ---- S^T = K . Q^T  (4 key frags x 2 query frags x 2 d steps)
+        f32x4 s[4][2];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            const char* rowp = sK + (kf * 16 + fr) * 128;
+            const bf16x8 k0 = *(const bf16x8*)(rowp + (((0 + fq) ^ (fr & 7)) << 4));
+            const bf16x8 k1 = *(const bf16x8*)(rowp + (((4 + fq) ^ (fr & 7)) << 4));
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[f][0], z, 0, 0, 0);
+                s[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[f][1], z, 0, 0, 0);
+            }
+        }
+        // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag
+        const bool tail = (kt + 1) * KB > S;
+        uint32_t pb[2][2][4];   // [query frag][key step][4 dwords] = packed bf16x8 B operands
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kf][f][r] * scale_log2e;
+                    if (tail && (kt * KB + kf * 16 + fq * 4 + r) >= S) v = -INFINITY;
+                    s[kf][f][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[f], mx);
+            const float alpha = exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
+            m_run[f] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                float p0 = exp2f(s[kf][f][0] - m_new), p1 = exp2f(s[kf][f][1] - m_new);
+                float p2 = exp2f(s[kf][f][2] - m_new), p3 = exp2f(s[kf][f][3] - m_new);
+                ps += (p0 + p1) + (p2 + p3);
+                pb[f][kf >> 1][(kf & 1) * 2 + 0] = pack2bf(p0, p1);
+                pb[f][kf >> 1][(kf & 1) * 2 + 1] = pack2bf(p2, p3);
+            }
+            l_run[f] = l_run[f] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                o[d][f][0] *= alpha; o[d][f][1] *= alpha; o[d][f][2] *= alpha; o[d][f][3] *= alpha;
+            }
+        }
+        // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int drow = d * 16 + fr;
+            const char* rowp = sV + drow * 128 + (fq & 1) * 8;
+            const int sw = (drow >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ks * 4 + (fq >> 1);
+                const uint2 lo = *(const uint2*)(rowp + ((c ^ sw) << 4));
+                const uint2 hi = *(const uint2*)(rowp + (((c + 2) ^ sw) << 4));
+                union { uint32_t u[4]; bf16x8 v; } va;
+                va.u[0] = lo.x; va.u[1] = lo.y; va.u[2] = hi.x; va.u[3] = hi.y;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    union { uint32_t u[4]; bf16x8 v; } pv;
+                    pv.u[0] = pb[f][ks][0]; pv.u[1] = pb[f][ks][1]; pv.u[2] = pb[f][ks][2]; pv.u[3] = pb[f][ks][3];
+                    o[d][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, o[d][f], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- normalise and store: lane holds O[query fr][d = dfrag*16 + 4*fq + r]
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        float l = l_run[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qi = qt * QB + wave * 32 + f * 16 + fr;
+        if (qi < S) {
+            uint16_t* dst = O + (row0 + qi) * ldo + h * 64 + fq * 4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint2 pk;
+                pk.x = pack2bf(o[d][f][0] * inv, o[d][f][1] * inv);
+                pk.y = pack2bf(o[d][f][2] * inv, o[d][f][3] * inv);
+                *(uint2*)(dst + d * 16) = pk;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Temporal attention: one wave per (batch item, spatial site, head); the T <= 16 frames of a site
+// are rows m = (b*T + t)*S + s of the QKV buffer (stride S*ld) — the permutes are address math.
+// K and Q fragments come straight from global (16 B per lane); V is staged in a per-wave LDS tile
+// and read back transposed (2-byte reads).  Keys 16..31 of the K=32 MFMA are zero padding.
+// ---------------------------------------------------------------------------------------------
+constexpr int TV_LD = 72;   // bf16 elements per staged V row (144 B: 16-B aligned, skewed banks)
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __restrict__ QKV, int ldqkv,
+                                                             uint16_t* __restrict__ O, int ldo, int T, int S, int heads,
+                                                             int64_t total, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) uint16_t vst[4][16 * TV_LD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= total) return;     // wave-uniform; no block-level barrier below
+    const int C = heads * 64;
+    const int h = (int)(task % heads);
+    const int64_t site = task / heads;           // b*S + s
+    const int s = (int)(site % S);
+    const int64_t b = site / S;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t frame_stride = (int64_t)S * ldqkv;
+    const uint16_t* base = QKV + ((b * T) * S + s) * ldqkv + h * 64;
+
+    // Q (B operand: query fr, d chunk) and K (A operand: key fr, d chunk)
+    const int tq = fr < T ? fr : T - 1;
+    const uint16_t* qsrc = base + tq * frame_stride + fq * 8;
+    const bf16x8 q0 = *(const bf16x8*)(qsrc), q1 = *(const bf16x8*)(qsrc + 32);
+    bf16x8 k0 = *(const bf16x8*)(qsrc + C), k1 = *(const bf16x8*)(qsrc + C + 32);
+    if (fr >= T) {
+        k0 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        k1 = k0;
+    }
+    // V rows -> LDS (row = key, 64 d); rows >= T are zero
+    uint16_t* vs = vst[wave];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = i * 8 + (lane >> 3);
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (key < T) v = *(const uint4*)(base + key * frame_stride + 2 * C + (lane & 7) * 8);
+        *(uint4*)(vs + key * TV_LD + (lane & 7) * 8) = v;
+    }
+    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, st, 0, 0, 0);
+    // softmax over keys 4*fq + r for query fr
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sv[r] = (fq * 4 + r) < T ? st[r] * scale_log2e : -INFINITY;
+        mx = fmaxf(mx, sv[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float p[4], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { p[r] = exp2f(sv[r] - mx); l += p[r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    union { uint32_t u[4]; bf16x8 v; } pv;
+    pv.u[0] = pack2bf(p[0], p[1]); pv.u[1] = pack2bf(p[2], p[3]); pv.u[2] = 0u; pv.u[3] = 0u;
+    // make the staged V visible to the whole wave (same wave wrote it; wait for the LDS writes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool store = fr < T;
+    uint16_t* dst = O + ((b * T + tq) * S + s) * ldo + h * 64 + fq * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int dcol = d * 16 + fr;
+        union { uint32_t u[4]; bf16x8 v; } va;
+        const uint32_t e0 = vs[(fq * 4 + 0) * TV_LD + dcol], e1 = vs[(fq * 4 + 1) * TV_LD + dcol];
+        const uint32_t e2 = vs[(fq * 4 + 2) * TV_LD + dcol], e3 = vs[(fq * 4 + 3) * TV_LD + dcol];
+        va.u[0] = e0 | (e1 << 16); va.u[1] = e2 | (e3 << 16); va.u[2] = 0u; va.u[3] = 0u;
+        f32x4 ot = f32x4{0.f, 0.f, 0.f, 0.f};
+        ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, ot, 0, 0, 0);
+        if (store) {
+            uint2 pk;
+            pk.x = pack2bf(ot[0] * inv, ot[1] * inv);
+            pk.y = pack2bf(ot[2] * inv, ot[3] * inv);
+            *(uint2*)(dst + d * 16) = pk;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
+                                     int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
+                                     const void* zeros) {
+    WIW_REQUIRE(QK && Vt && O && zeros, "attn_spatial: null pointer");
+    WIW_REQUIRE(frames > 0 && S > 0 && heads > 0, "attn_spatial: bad sizes");
+    WIW_REQUIRE(S % 8 == 0, "attn_spatial: S (= h*w of the level) must be a multiple of 8");
+    WIW_REQUIRE(ldqk % 8 == 0 && k_col_off % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attn_spatial: misaligned strides");
+    const int q_tiles = (S + QB - 1) / QB;
+    const int64_t nb = (int64_t)q_tiles * heads * frames;
+    WIW_REQUIRE(nb < (1ll << 31), "attn_spatial: grid too large");
+    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QK,
+                       ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
+                       (const char*)zeros);
+    return wiw_check_launch("wiw_attn_spatial_bf16");
+}
+
+extern "C" int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, int ldo, int batch, int T,
+                                      int S, int heads, float scale) {
+    WIW_REQUIRE(QKV && O, "attn_temporal: null pointer");
+    WIW_REQUIRE(batch > 0 && S > 0 && heads > 0, "attn_temporal: bad sizes");
+    WIW_REQUIRE(T >= 1 && T <= 16, "attn_temporal: 1 <= T <= 16");
+    WIW_REQUIRE(ldqkv % 8 == 0 && ldqkv >= 3 * heads * 64 && ldo % 4 == 0, "attn_temporal: misaligned strides");
+    const int64_t total = (int64_t)batch * S * heads;
+    const int64_t nb = (total + 3) / 4;
+    WIW_REQUIRE(nb < (1ll << 31), "attn_temporal: grid too large");
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QKV,
+                       ldqkv, (uint16_t*)O, ldo, T, S, heads, total, scale * LOG2E);
+    return wiw_check_launch("wiw_attn_temporal_bf16");
+}

@@ -1,0 +1,53 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wiw_svd.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one 16-byte MFMA operand
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef uint16_t bf16_t;
+
+#define WIW_DEV __device__ __forceinline__
+
+WIW_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+WIW_DEV uint16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite on this path)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+WIW_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+WIW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+WIW_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+WIW_DEV void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+WIW_DEV uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// wave-wide (64-lane) reductions by butterfly shuffles
+WIW_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Host-side error bookkeeping (api.cpp)
+void wiw_set_error(const char* msg);
+#define WIW_REQUIRE(cond, msg)        \
+    do {                              \
+        if (!(cond)) {                \
+            wiw_set_error(msg);       \
+            return WIW_EINVAL;        \
+        }                             \
+    } while (0)
+int wiw_check_launch(const char* what);

@@ -1,0 +1,168 @@
+// Library bookkeeping + the small HBM-bound kernels around the UNet: conditioning-embedding combine,
+// UNet input assembly (scale_model_input + CFG doubling + channel concat, NCHW fp32 -> NHWC bf16)
+// and the fused CFG-combine + Euler step.  All are pure streaming kernels: coalesced 16-byte
+// accesses on the wide side, grid-stride, no LDS.
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// error bookkeeping
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+void wiw_set_error(const char* msg) {
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+
+int wiw_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return WIW_ELAUNCH;
+    }
+    return WIW_OK;
+}
+
+extern "C" int wiw_abi_version(void) { return WIW_ABI_VERSION; }
+extern "C" const char* wiw_last_error(void) { return g_err; }
+
+extern "C" int wiw_device_check(int dev, char* name, int name_len) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        wiw_set_error("no HIP device");
+        return WIW_ENODEV;
+    }
+    if (name && name_len > 0) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof(g_err), "device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+        return WIW_ENODEV;
+    }
+    return WIW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// out[(i*T + t)][c] = silu(time[i][c] + act[((i % B)*T + t)][c] + noise[i][c])      (bf16)
+__global__ void emb_combine_kernel(const float* __restrict__ time, const float* __restrict__ act,
+                                   const float* __restrict__ noise, int Bc, int B, int T, int E, uint16_t* out) {
+    const int64_t total = (int64_t)Bc * T * E;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % E);
+        const int row = (int)(idx / E);
+        const int i = row / T, t = row - i * T;
+        const float v = time[(int64_t)i * E + c] + act[((int64_t)(i % B) * T + t) * E + c] + noise[(int64_t)i * E + c];
+        out[idx] = f2bf(silu_f(v));
+    }
+}
+
+// One thread per output pixel row (NHWC, Cpad channels = Cpad/8 chunks of 16 B).
+__global__ void prep_input_kernel(const float* __restrict__ lat, const float* __restrict__ img, int B, int T, int hw,
+                                  float inv_scale, int Cpad, uint16_t* X) {
+    const int chunks = Cpad >> 3;
+    const int64_t total = (int64_t)2 * B * T * hw * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % chunks);
+        const int64_t row = idx / chunks;          // (i*T + t)*hw + p
+        uint4 o = uint4{0u, 0u, 0u, 0u};
+        if (ch == 0) {
+            const int p = (int)(row % hw);
+            const int64_t ft = row / hw;           // i*T + t
+            const int t = (int)(ft % T), i = (int)(ft / T);
+            const int b = i % B;
+            float v[8];
+            const float* l = lat + (((int64_t)b * T + t) * 4) * hw + p;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = l[(int64_t)c * hw] * inv_scale;
+            if (i >= B) {
+                const float* im = img + ((int64_t)b * 4) * hw + p;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[4 + c] = im[(int64_t)c * hw];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[4 + c] = 0.f;
+            }
+            o = pack8(v);
+        }
+        *(uint4*)(X + row * Cpad + ch * 8) = o;
+    }
+}
+
+// One thread per (b, t, p): 4 channels.
+__global__ void cfg_euler_kernel(const float* __restrict__ V, int ldv, float* lat, int B, int T, int hw, float sigma,
+                                 float sigma_next, float gmin, float gmax) {
+    const int64_t total = (int64_t)B * T * hw;
+    const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
+    const float c_skip = 1.0f / (sigma * sigma + 1.0f);
+    const float dt = sigma_next - sigma;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % hw);
+        const int64_t bt = idx / hw;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float g = (T > 1) ? gmin + (gmax - gmin) * (float)t / (float)(T - 1) : gmin;
+        const float* vu = V + (((int64_t)b * T + t) * hw + p) * ldv;
+        const float* vc = V + ((((int64_t)(B + b)) * T + t) * hw + p) * ldv;
+        float* x = lat + (((int64_t)b * T + t) * 4) * hw + p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float v = vu[c] + g * (vc[c] - vu[c]);
+            const float xv = x[(int64_t)c * hw];
+            const float x0 = v * c_out + xv * c_skip;
+            x[(int64_t)c * hw] = xv + (xv - x0) / sigma * dt;
+        }
+    }
+}
+
+inline int grid_for(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    if (g > 2048 * 8) g = 2048 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int wiw_fill_f32(void* stream, float* p, int64_t n, float value) {
+    WIW_REQUIRE(p != nullptr && n > 0, "fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+    return wiw_check_launch("wiw_fill_f32");
+}
+
+extern "C" int wiw_emb_combine(void* stream, const float* time, const float* act, const float* noise, int Bc, int B,
+                               int T, int E, void* out) {
+    WIW_REQUIRE(time && act && noise && out, "emb_combine: null pointer");
+    WIW_REQUIRE(Bc > 0 && B > 0 && Bc % B == 0 && T > 0 && E > 0, "emb_combine: bad sizes");
+    hipLaunchKernelGGL(emb_combine_kernel, dim3(grid_for((int64_t)Bc * T * E, 256)), dim3(256), 0, (hipStream_t)stream,
+                       time, act, noise, Bc, B, T, E, (uint16_t*)out);
+    return wiw_check_launch("wiw_emb_combine");
+}
+
+extern "C" int wiw_prep_unet_input(void* stream, const float* latents, const float* image_latents, int B, int T,
+                                   int hw, float sigma, int Cpad, void* X) {
+    WIW_REQUIRE(latents && image_latents && X, "prep_unet_input: null pointer");
+    WIW_REQUIRE(B > 0 && T > 0 && hw > 0 && Cpad >= 8 && Cpad % 8 == 0, "prep_unet_input: bad sizes");
+    const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);
+    const int64_t total = (int64_t)2 * B * T * hw * (Cpad / 8);
+    hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, latents,
+                       image_latents, B, T, hw, inv, Cpad, (uint16_t*)X);
+    return wiw_check_launch("wiw_prep_unet_input");
+}
+
+extern "C" int wiw_cfg_euler_step(void* stream, const float* V, int ldv, float* latents, int B, int T, int hw,
+                                  float sigma, float sigma_next, float gmin, float gmax) {
+    WIW_REQUIRE(V && latents, "cfg_euler_step: null pointer");
+    WIW_REQUIRE(B > 0 && T > 0 && hw > 0 && ldv >= 4 && sigma > 0.f, "cfg_euler_step: bad sizes");
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for((int64_t)B * T * hw, 256)), dim3(256), 0, (hipStream_t)stream, V,
+                       ldv, latents, B, T, hw, sigma, sigma_next, gmin, gmax);
+    return wiw_check_launch("wiw_cfg_euler_step");
+}

@@ -1,0 +1,246 @@
+// GroupNorm(32) in NHWC (statistics / finalize / fused apply + SiLU) and LayerNorm with fused
+// pre-add.  HBM-bound kernels: every global access is 16 B per lane on channel-contiguous rows,
+// reductions use wave shuffles + LDS atomics, statistics are fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int GROUPS = 32;
+
+// ---------------------------------------------------------------------------------------------
+// statistics: grid = (row_splits, units).  A block reduces rows [r0, r1) of one unit for ALL channels.
+// Threads are laid out (channel chunk, row lane); a thread keeps per-channel partial sums of its
+// 8 channels in registers, so the inner loop has no group arithmetic.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X1, int C1,
+                                                        const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
+                                                        int rows_per_block, float* stats) {
+    __shared__ float bins[GROUPS * 2];
+    const int tid = threadIdx.x;
+    if (tid < GROUPS * 2) bins[tid] = 0.f;
+    __syncthreads();
+    const int C = C1 + C2;
+    const int cg = C / GROUPS;
+    const int chunks = C >> 3;
+    const int cpb = chunks < 256 ? chunks : 256;   // chunk columns handled per pass
+    const int rp = 256 / cpb;                       // row lanes
+    const int ci = tid % cpb, rl = tid / cpb;
+    const int unit = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows_per_unit) r1 = rows_per_unit;
+    const int64_t base_row = (int64_t)unit * rows_per_unit;
+    if (rl < rp) {
+        for (int cbase = 0; cbase < chunks; cbase += cpb) {
+            const int chunk = cbase + ci;
+            if (chunk >= chunks) break;
+            const int c0 = chunk * 8;
+            const uint16_t* src;
+            int ld, coff;
+            if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
+            float s[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+            for (int r = r0 + rl; r < r1; r += rp) {
+                float f[8];
+                unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+            // fold channels of the same group before touching LDS
+            int g_prev = c0 / cg;
+            float gs = 0.f, gq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (c0 + e) / cg;
+                if (g != g_prev) {
+                    atomicAdd(&bins[g_prev * 2], gs);
+                    atomicAdd(&bins[g_prev * 2 + 1], gq);
+                    gs = 0.f; gq = 0.f; g_prev = g;
+                }
+                gs += s[e]; gq += q[e];
+            }
+            atomicAdd(&bins[g_prev * 2], gs);
+            atomicAdd(&bins[g_prev * 2 + 1], gq);
+        }
+    }
+    __syncthreads();
+    if (tid < GROUPS * 2) atomicAdd(&stats[(int64_t)unit * GROUPS * 2 + tid], bins[tid]);
+}
+
+// ab[unit][0][c] = rstd*gamma[c];  ab[unit][1][c] = beta[c] - mean*rstd*gamma[c]
+__global__ void gn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, int units, int C, float inv_count, float eps,
+                                   float* ab) {
+    const int total = units * C;
+    const int cg = C / GROUPS;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int u = idx / C, c = idx - u * C;
+        const int g = c / cg;
+        const float mean = stats[(u * GROUPS + g) * 2] * inv_count;
+        float var = stats[(u * GROUPS + g) * 2 + 1] * inv_count - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        const float rstd = rsqrtf(var + eps);
+        const float a = rstd * gamma[c];
+        ab[((int64_t)u * 2) * C + c] = a;
+        ab[((int64_t)u * 2 + 1) * C + c] = beta[c] - mean * a;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X1, int C1,
+                                                        const uint16_t* __restrict__ X2, int C2, int64_t rows,
+                                                        int rows_per_unit, const float* __restrict__ ab, int silu,
+                                                        uint16_t* out) {
+    const int C = C1 + C2;
+    const int chunks = C >> 3;
+    const int64_t total = rows * chunks;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int chunk = (int)(idx % chunks);
+        const int64_t row = idx / chunks;
+        const int c0 = chunk * 8;
+        const int unit = (int)(row / rows_per_unit);
+        float f[8];
+        if (c0 < C1) unpack8(*(const uint4*)(X1 + row * C1 + c0), f);
+        else unpack8(*(const uint4*)(X2 + row * C2 + (c0 - C1)), f);
+        const float* a = ab + ((int64_t)unit * 2) * C + c0;
+        const float* b = a + C;
+        const float4 a0 = *(const float4*)a, a1 = *(const float4*)(a + 4);
+        const float4 b0 = *(const float4*)b, b1 = *(const float4*)(b + 4);
+        f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
+        f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+        }
+        *(uint4*)(out + row * C + c0) = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 2048 -> <= 4 chunks of 8 per lane),
+// exact two-pass mean / variance with 64-lane butterfly reductions.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 4;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, int64_t rows, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, const float* __restrict__ addvec, int addvec_ld,
+                                                         int rows_per_vec, uint16_t* sum_out, uint16_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int chunks = C >> 3;
+    const float inv_c = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[LN_MAXCH][8];
+        const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int chunk = lane + k * 64;
+            if (chunk < chunks) {
+                unpack8(*(const uint4*)(X + row * C + chunk * 8), v[k]);
+                if (av) {
+                    const float4 a0 = *(const float4*)(av + chunk * 8), a1 = *(const float4*)(av + chunk * 8 + 4);
+                    v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
+                    v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
+                    if (sum_out) {
+                        // the stored sum is bf16 (the residual stream dtype); normalise what is stored
+                        const uint4 pk = pack8(v[k]);
+                        *(uint4*)(sum_out + row * C + chunk * 8) = pk;
+                        unpack8(pk, v[k]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[k][e];
+            }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int chunk = lane + k * 64;
+            if (chunk < chunks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < LN_MAXCH; ++k) {
+            const int chunk = lane + k * 64;
+            if (chunk < chunks) {
+                const float4 g0 = *(const float4*)(gamma + chunk * 8), g1 = *(const float4*)(gamma + chunk * 8 + 4);
+                const float4 b0 = *(const float4*)(beta + chunk * 8), b1 = *(const float4*)(beta + chunk * 8 + 4);
+                float o[8];
+                o[0] = (v[k][0] - mean) * rstd * g0.x + b0.x; o[1] = (v[k][1] - mean) * rstd * g0.y + b0.y;
+                o[2] = (v[k][2] - mean) * rstd * g0.z + b0.z; o[3] = (v[k][3] - mean) * rstd * g0.w + b0.w;
+                o[4] = (v[k][4] - mean) * rstd * g1.x + b1.x; o[5] = (v[k][5] - mean) * rstd * g1.y + b1.y;
+                o[6] = (v[k][6] - mean) * rstd * g1.z + b1.z; o[7] = (v[k][7] - mean) * rstd * g1.w + b1.w;
+                *(uint4*)(out + row * C + chunk * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+inline int grid_for(int64_t total, int block, int cap) {
+    int64_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                                   int rows_per_unit, float* stats) {
+    WIW_REQUIRE(X1 && stats, "groupnorm_stats: null pointer");
+    WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_stats: X2 iff C2 > 0");
+    const int C = C1 + C2;
+    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0, "groupnorm_stats: channels must be %8 and C %32");
+    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats: bad rows");
+    const int units = (int)(rows / rows_per_unit);
+    // enough blocks to fill the chip, each reducing >= 64 rows
+    int splits = (2048 + units - 1) / units;
+    const int max_splits = (rows_per_unit + 63) / 64;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int rows_per_block = (rows_per_unit + splits - 1) / splits;
+    splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
+                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, stats);
+    return wiw_check_launch("wiw_groupnorm_stats");
+}
+
+extern "C" int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta,
+                                      int units, int C, int rows_per_unit, float eps, float* ab) {
+    WIW_REQUIRE(stats && gamma && beta && ab, "groupnorm_finalize: null pointer");
+    WIW_REQUIRE(units > 0 && C > 0 && C % GROUPS == 0 && rows_per_unit > 0, "groupnorm_finalize: bad sizes");
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / GROUPS));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(grid_for((int64_t)units * C, 256, 1024)), dim3(256), 0,
+                       (hipStream_t)stream, stats, gamma, beta, units, C, inv_count, eps, ab);
+    return wiw_check_launch("wiw_groupnorm_finalize");
+}
+
+extern "C" int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                                   int rows_per_unit, const float* ab, int silu, void* out) {
+    WIW_REQUIRE(X1 && ab && out, "groupnorm_apply: null pointer");
+    WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_apply: X2 iff C2 > 0");
+    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "groupnorm_apply: channels must be multiples of 8");
+    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_apply: bad rows");
+    const int64_t total = rows * ((C1 + C2) / 8);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256, 2048 * 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)X1, C1, (const uint16_t*)X2, C2, rows, rows_per_unit, ab, silu, (uint16_t*)out);
+    return wiw_check_launch("wiw_groupnorm_apply");
+}
+
+extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma,
+                                  const float* beta, float eps, const float* addvec, int addvec_ld, int rows_per_vec,
+                                  void* sum_out, void* out) {
+    WIW_REQUIRE(X && gamma && beta && out, "layernorm: null pointer");
+    WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LN_MAXCH * 64 * 8, "layernorm: C must be %8 and <= 2048");
+    WIW_REQUIRE(addvec == nullptr || (rows_per_vec > 0 && addvec_ld % 4 == 0), "layernorm: bad addvec layout");
+    WIW_REQUIRE(sum_out == nullptr || addvec != nullptr, "layernorm: sum_out requires addvec");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows, 4, 2048 * 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)X, rows, C, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,
+                       (uint16_t*)sum_out, (uint16_t*)out);
+    return wiw_check_launch("wiw_layernorm_bf16");
+}

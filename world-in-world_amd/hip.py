@@ -1,0 +1,184 @@
+"""ctypes binding of libwiwsvd.so (C ABI: include/wiw_svd.h).
+
+PyTorch supplies device memory (`tensor.data_ptr()`) and the HIP stream; every operator below is a
+hand-written gfx950 kernel.  There is NO fallback: a missing library or a failing call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwiwsvd.so")
+
+A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3 = 0, 1, 2, 3, 4
+EPI_GEGLU, EPI_SILU, EPI_OUT_F32 = 1, 2, 4
+GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
+
+
+class WiwGemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("zeros", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("C1", C.c_int32), ("C2", C.c_int32), ("mode", C.c_int32),
+        ("H", C.c_int32), ("Wd", C.c_int32), ("T", C.c_int32),
+        ("ldo", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("n_out", C.c_int32),
+        ("rowvec_ld", C.c_int32), ("rows_per_vec", C.c_int32),
+        ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("epilogue", C.c_int32),
+    ]
+
+
+EXPORTS = {
+    "wiw_abi_version": (C.c_int, []),
+    "wiw_last_error": (C.c_char_p, []),
+    "wiw_device_check": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "wiw_gemm_bf16": (C.c_int, [C.c_void_p, C.POINTER(WiwGemmArgs)]),
+    "wiw_attn_spatial_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "wiw_attn_temporal_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_float]),
+    "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                      C.c_void_p]),
+    "wiw_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_float, C.c_void_p]),
+    "wiw_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
+    "wiw_layernorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wiw_emb_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p]),
+    "wiw_prep_unet_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_int, C.c_void_p]),
+    "wiw_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_float, C.c_float, C.c_float]),
+    "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the C-ABI library and declare every prototype of include/wiw_svd.h.  Raises if absent."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is required (build it with "
+            f"`python world-in-world_amd/build.py`); there is no CPU or PyTorch fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Hip:
+    """Thin operator layer over the C ABI: argument checking + pointer marshalling only."""
+
+    def __init__(self, device: torch.device):
+        self.lib = load_library()
+        if self.lib.wiw_abi_version() != 1:
+            raise RuntimeError("libwiwsvd.so ABI version mismatch")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the HIP path needs a ROCm device (torch device type 'cuda')")
+        name = C.create_string_buffer(64)
+        rc = self.lib.wiw_device_check(self.device.index or 0, name, 64)
+        if rc != 0:
+            raise RuntimeError(f"wiw_device_check: {self.lib.wiw_last_error().decode()}")
+        self.arch = name.value.decode()
+        self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
+        # entries are (start_event, end_event, algorithmic_flops, mode)
+        self.gemm_profile = None
+
+    # ---- helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.wiw_last_error().decode()}")
+
+    # ---- operators
+    def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
+             rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,
+             ldo=None, epilogue=0, n_out=0):
+        a = WiwGemmArgs()
+        a.A, a.A2, a.W, a.out = _p(A), _p(A2), _p(W), _p(out)
+        a.bias, a.rowvec, a.res1, a.res2 = _p(bias), _p(rowvec), _p(res1), _p(res2)
+        a.zeros = self.zeros.data_ptr()
+        a.M, a.N, a.K, a.C1, a.C2, a.mode = M, N, K, C1, C2, mode
+        a.H, a.Wd, a.T = H, Wd, T
+        a.ldo = ldo if ldo is not None else (n_out if epilogue & EPI_GEGLU else N)
+        a.ldr1, a.ldr2, a.n_out = ldr1, ldr2, n_out
+        a.rowvec_ld, a.rows_per_vec = rowvec_ld, rows_per_vec
+        a.alpha, a.beta1, a.beta2 = alpha, beta1, beta2
+        a.epilogue = epilogue
+        if self.gemm_profile is None:
+            self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
+            return out
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
+        e1.record()
+        self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode))
+        return out
+
+    def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale):
+        self._ck(self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
+                                                frames, S, heads, scale, self.zeros.data_ptr()), "wiw_attn_spatial_bf16")
+        return O
+
+    def attn_temporal(self, QKV, ldqkv, O, ldo, batch, T, S, heads, scale):
+        self._ck(self.lib.wiw_attn_temporal_bf16(self._stream(), _p(QKV), ldqkv, _p(O), ldo, batch, T, S, heads, scale),
+                 "wiw_attn_temporal_bf16")
+        return O
+
+    def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None):
+        """stats -> finalize -> apply; returns the normalised (and SiLU'd) bf16 tensor [rows, C1+C2]."""
+        Ct = C1 + C2
+        units = rows // rows_per_unit
+        stats = torch.empty(units * 64, dtype=torch.float32, device=self.device)
+        ab = torch.empty(units * 2 * Ct, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
+        s = self._stream()
+        self._ck(self.lib.wiw_fill_f32(s, stats.data_ptr(), units * 64, 0.0), "wiw_fill_f32")
+        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr()),
+                 "wiw_groupnorm_stats")
+        self._ck(self.lib.wiw_groupnorm_finalize(s, stats.data_ptr(), _p(gamma), _p(beta), units, Ct, rows_per_unit,
+                                                 eps, ab.data_ptr()), "wiw_groupnorm_finalize")
+        self._ck(self.lib.wiw_groupnorm_apply(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, ab.data_ptr(),
+                                              1 if silu else 0, out.data_ptr()), "wiw_groupnorm_apply")
+        return out
+
+    def layernorm(self, X, rows, Cn, gamma, beta, eps=1e-5, addvec=None, addvec_ld=0, rows_per_vec=1, sum_out=None,
+                  out=None):
+        if out is None:
+            out = torch.empty((rows, Cn), dtype=torch.bfloat16, device=self.device)
+        self._ck(self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
+                                             addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16")
+        return out
+
+    def emb_combine(self, time, act, noise, Bc, B, T, E, out):
+        self._ck(self.lib.wiw_emb_combine(self._stream(), _p(time), _p(act), _p(noise), Bc, B, T, E, _p(out)),
+                 "wiw_emb_combine")
+        return out
+
+    def prep_unet_input(self, latents, image_latents, B, T, hw, sigma, Cpad, X):
+        self._ck(self.lib.wiw_prep_unet_input(self._stream(), _p(latents), _p(image_latents), B, T, hw, sigma, Cpad,
+                                              _p(X)), "wiw_prep_unet_input")
+        return X
+
+    def cfg_euler_step(self, V, ldv, latents, B, T, hw, sigma, sigma_next, gmin, gmax):
+        self._ck(self.lib.wiw_cfg_euler_step(self._stream(), _p(V), ldv, _p(latents), B, T, hw, sigma, sigma_next,
+                                             gmin, gmax), "wiw_cfg_euler_step")
+        return latents

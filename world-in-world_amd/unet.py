@@ -1,0 +1,452 @@
+"""Spatio-temporal UNet forward on the HIP kernels (host orchestration).
+
+Mirrors `UNetSpatioTemporalConditionModel.forward` of the reference
+(FTsvd/diffusers-private/diffusers/models/unets/unet_spatio_temporal_condition.py:402-575,
+`micro_cond` action strategy) — same weights (diffusers state dict), same arguments — but laid out
+for MI355X:
+
+  * activations are token-major bf16 [B*T*H*W, C] (NHWC); the (B*T,S,C) <-> (B*S,T,C) and
+    (BT,C,H,W) <-> (B,C,T,H,W) permutes of the reference (attention.py:720-722, resnet.py:698-715)
+    are address arithmetic inside the kernels, never materialised;
+  * every conv / linear is one call of the MFMA GEMM kernel with fused bias / time-embedding /
+    residual / GEGLU / AlphaBlender epilogues; GroupNorm+SiLU and LayerNorm(+pre-add) are the only
+    standalone normalisation passes;
+  * the two single-key cross-attentions per transformer layer are evaluated in closed form
+    (softmax over one key == 1  =>  attn2(x) = to_out(to_v(ctx))): one [C] vector
+    per CFG-batch item, computed once per request and added inside the following LayerNorm kernel;
+  * batch >= 2 follows the contract "candidate i == reference B=1 run on candidate i" (§9.2).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .config import UNetConfig
+from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI_GEGLU, EPI_OUT_F32, EPI_SILU,
+                  GEGLU_TILE, Hip)
+from .weights import validate_state_dict
+
+CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
+
+
+def sinusoid(t: np.ndarray, dim: int) -> np.ndarray:
+    """get_timestep_embedding (dp/models/embeddings.py:27-78), flip_sin_to_cos=True, shift 0: [cos | sin]."""
+    half = dim // 2
+    freq = np.exp(-math.log(10000.0) * np.arange(half, dtype=np.float32) / np.float32(half)).astype(np.float32)
+    arg = t.astype(np.float32)[:, None] * freq[None, :]
+    return np.concatenate([np.cos(arg), np.sin(arg)], axis=-1).astype(np.float32)
+
+
+def action_features(action_ids: np.ndarray) -> np.ndarray:
+    """ActionEmbedder_ features (dp/models/embeddings.py:922-939): (B,T,Ch) -> (B*T, Ch*12), channel-major."""
+    x = action_ids.astype(np.float32)
+    feats = []
+    for k in (1.0, 2.0, 4.0, 6.0, 8.0, 10.0):
+        feats += [np.cos(np.float32(k) * x), np.sin(np.float32(k) * x)]
+    f = np.stack(feats, axis=-1)
+    return f.reshape(x.shape[0] * x.shape[1], x.shape[2] * 12)
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    """Re-order the GEGLU projection [8C, K] (value rows then gate rows, activations.py:122) into tiles of
+    160 rows = [80 value | 80 gate] so the GEMM epilogue finds both halves in one block tile."""
+    n_half = w.shape[0] // 2
+    pad = (-n_half) % GEGLU_TILE
+    wv, wg = w[:n_half], w[n_half:]
+    bv, bg = b[:n_half], b[n_half:]
+    if pad:
+        wv = torch.cat([wv, wv.new_zeros(pad, w.shape[1])])
+        wg = torch.cat([wg, wg.new_zeros(pad, w.shape[1])])
+        bv = torch.cat([bv, bv.new_zeros(pad)])
+        bg = torch.cat([bg, bg.new_zeros(pad)])
+    nt = (n_half + pad) // GEGLU_TILE
+    wp = torch.stack([wv.reshape(nt, GEGLU_TILE, -1), wg.reshape(nt, GEGLU_TILE, -1)], dim=1).reshape(2 * (n_half + pad), -1)
+    bp = torch.stack([bv.reshape(nt, GEGLU_TILE), bg.reshape(nt, GEGLU_TILE)], dim=1).reshape(-1)
+    return wp.contiguous(), bp.contiguous(), n_half
+
+
+@dataclass
+class RequestCond:
+    """Step-invariant conditioning of one request (everything but time_embedding(t))."""
+    B: int
+    Bc: int
+    act_emb: torch.Tensor    # fp32 [B*T, E]
+    noise_emb: torch.Tensor  # fp32 [Bc, E]
+    ehs_bf16: torch.Tensor   # bf16 [Bc, Dctx]
+    cross: Dict[str, torch.Tensor]   # attn2 prefix -> fp32 [Bc, C]
+    pos_emb: Dict[str, torch.Tensor]  # transformer prefix -> fp32 [Bc*T, C]
+
+
+class UNetHIP:
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
+                 hip: Optional[Hip] = None):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.hip = hip or Hip(self.device)
+        validate_state_dict(cfg, state_dict)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.alpha: Dict[str, float] = {}
+        self._prepare(state_dict)
+
+    # ------------------------------------------------------------------------------------------
+    # weight re-layout (once, at load)
+    # ------------------------------------------------------------------------------------------
+    def _t(self, sd, name) -> torch.Tensor:
+        v = sd[name]
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        return v.to(self.device, torch.float32)
+
+    def _prepare(self, sd):
+        cfg, w = self.cfg, self.w
+        bf = torch.bfloat16
+        temb_w, temb_b = [], []
+        self.temb_off: Dict[str, int] = {}
+        off = 0
+
+        def lin(p, bias=True):
+            w[p + ".weight"] = self._t(sd, p + ".weight").to(bf).contiguous()
+            if bias:
+                w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
+
+        def norm(p):
+            w[p + ".weight"] = self._t(sd, p + ".weight").contiguous()
+            w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
+
+        def conv3(p, cin_pad=0):
+            x = self._t(sd, p + ".weight").permute(0, 2, 3, 1)  # OIHW -> OHWI
+            if cin_pad and x.shape[-1] < cin_pad:
+                x = torch.cat([x, x.new_zeros(*x.shape[:-1], cin_pad - x.shape[-1])], dim=-1)
+            w[p + ".weight"] = x.reshape(x.shape[0], -1).to(bf).contiguous()
+            w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
+
+        def convt(p):
+            x = self._t(sd, p + ".weight")[:, :, :, 0, 0].permute(0, 2, 1)  # (O,I,3) -> (O,3,I)
+            w[p + ".weight"] = x.reshape(x.shape[0], -1).to(bf).contiguous()
+            w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
+
+        def res(p):
+            nonlocal off
+            s, t = p + ".spatial_res_block", p + ".temporal_res_block"
+            norm(s + ".norm1"); conv3(s + ".conv1"); norm(s + ".norm2"); conv3(s + ".conv2")
+            if s + ".conv_shortcut.weight" in sd:
+                x = self._t(sd, s + ".conv_shortcut.weight")[:, :, 0, 0]
+                w[s + ".conv_shortcut.weight"] = x.to(bf).contiguous()
+                w[s + ".conv_shortcut.bias"] = self._t(sd, s + ".conv_shortcut.bias").contiguous()
+            norm(t + ".norm1"); convt(t + ".conv1"); norm(t + ".norm2"); convt(t + ".conv2")
+            for q in (s, t):  # all time_emb_proj layers are evaluated by ONE batched GEMM per step
+                tw = self._t(sd, q + ".time_emb_proj.weight")
+                self.temb_off[q] = off
+                off += tw.shape[0]
+                temb_w.append(tw)
+                temb_b.append(self._t(sd, q + ".time_emb_proj.bias"))
+            self.alpha[p] = float(torch.sigmoid(self._t(sd, p + ".time_mixer.mix_factor")).item())
+
+        def ff(p):
+            wp, bp, n_half = pack_geglu(self._t(sd, p + ".net.0.proj.weight"), self._t(sd, p + ".net.0.proj.bias"))
+            w[p + ".net.0.proj.weight"] = wp.to(bf).contiguous()
+            w[p + ".net.0.proj.bias"] = bp.contiguous()
+            lin(p + ".net.2")
+
+        def transformer(p):
+            norm(p + ".norm"); lin(p + ".proj_in"); lin(p + ".proj_out")
+            b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
+            norm(b + ".norm1"); norm(b + ".norm3"); norm(t + ".norm_in"); norm(t + ".norm1"); norm(t + ".norm3")
+            w[b + ".attn1.to_qk.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"),
+                                                      self._t(sd, b + ".attn1.to_k.weight")]).to(bf).contiguous()
+            lin(b + ".attn1.to_v", bias=False); lin(b + ".attn1.to_out.0")
+            w[t + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, t + ".attn1.to_q.weight"),
+                                                       self._t(sd, t + ".attn1.to_k.weight"),
+                                                       self._t(sd, t + ".attn1.to_v.weight")]).to(bf).contiguous()
+            lin(t + ".attn1.to_out.0")
+            for q in (b, t):  # single-key cross-attention: only to_v and to_out matter (§9.3)
+                lin(q + ".attn2.to_v", bias=False); lin(q + ".attn2.to_out.0")
+            ff(b + ".ff"); ff(t + ".ff_in"); ff(t + ".ff")
+            lin(p + ".time_pos_embed.linear_1"); lin(p + ".time_pos_embed.linear_2")
+            self.alpha[p] = float(torch.sigmoid(self._t(sd, p + ".time_mixer.mix_factor")).item())
+
+        conv3("conv_in", cin_pad=CIN_PAD)
+        conv3("conv_out")
+        norm("conv_norm_out")
+        for p in ("time_embedding", "add_embedding_action", "add_embedding_noise"):
+            lin(p + ".linear_1"); lin(p + ".linear_2")
+        # action projection: K = 12 * channels padded to a multiple of 64
+        aw = self._t(sd, "add_action_proj.proj.weight")
+        self.act_kpad = (-aw.shape[1]) % 64
+        w["add_action_proj.proj.weight"] = torch.cat([aw, aw.new_zeros(aw.shape[0], self.act_kpad)], dim=1).to(bf).contiguous()
+        w["add_action_proj.proj.bias"] = self._t(sd, "add_action_proj.proj.bias").contiguous()
+        n = len(cfg.block_out_channels)
+        self.res_names: List[str] = []
+        self.tr_names: List[str] = []
+        for i in range(n):
+            for j in range(cfg.layers_per_block):
+                self.res_names.append(f"down_blocks.{i}.resnets.{j}")
+                if i < n - 1:
+                    self.tr_names.append(f"down_blocks.{i}.attentions.{j}")
+            if i < n - 1:
+                conv3(f"down_blocks.{i}.downsamplers.0.conv")
+        self.res_names += ["mid_block.resnets.0", "mid_block.resnets.1"]
+        self.tr_names.append("mid_block.attentions.0")
+        for i in range(n):
+            for j in range(cfg.layers_per_block + 1):
+                self.res_names.append(f"up_blocks.{i}.resnets.{j}")
+                if i > 0:
+                    self.tr_names.append(f"up_blocks.{i}.attentions.{j}")
+            if i < n - 1:
+                conv3(f"up_blocks.{i}.upsamplers.0.conv")
+        for p in self.res_names:
+            res(p)
+        for p in self.tr_names:
+            transformer(p)
+        w["temb_all.weight"] = torch.cat(temb_w).to(bf).contiguous()
+        w["temb_all.bias"] = torch.cat(temb_b).contiguous()
+        self.temb_total = off
+        # frame-position embeddings depend only on the frame index -> computed once (transformer_temporal.py:329-339)
+        T = cfg.num_frames
+        self.pos_emb_T: Dict[str, torch.Tensor] = {}
+        for p in self.tr_names:
+            Cn = w[p + ".proj_in.weight"].shape[0]
+            feat = torch.from_numpy(sinusoid(np.arange(T), Cn)).to(self.device, bf)
+            self.pos_emb_T[p] = self._mlp(p + ".time_pos_embed", feat, T)
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------------------------------
+    # small helpers
+    # ------------------------------------------------------------------------------------------
+    def _empty(self, *shape, dtype=torch.bfloat16):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, **kw):
+        W = self.w[p + ".weight"]
+        N, K = W.shape
+        out = self._empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        epi = (EPI_OUT_F32 if out_f32 else 0) | (EPI_SILU if silu else 0)
+        return self.hip.gemm(x, W, out, M=M, N=N, K=K, C1=K, bias=self.w.get(p + ".bias"), epilogue=epi,
+                             res1=res1, ldr1=N if res1 is not None else 0, beta1=1.0 if res1 is not None else 0.0, **kw)
+
+    def _mlp(self, p, x_bf16, M) -> torch.Tensor:
+        """TimestepEmbedding (embeddings.py:804-816): linear_1 -> SiLU -> linear_2; fp32 result [M, out]."""
+        h = self._linear(x_bf16, p + ".linear_1", M, silu=True)
+        return self._linear(h, p + ".linear_2", M, out_f32=True)
+
+    def _geglu_ff(self, a, p, M, Cn, **epi_kw):
+        """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue."""
+        W1 = self.w[p + ".net.0.proj.weight"]
+        g = self._empty(M, 4 * Cn)
+        self.hip.gemm(a, W1, g, M=M, N=W1.shape[0], K=Cn, C1=Cn, bias=self.w[p + ".net.0.proj.bias"],
+                      epilogue=EPI_GEGLU, n_out=4 * Cn)
+        W2 = self.w[p + ".net.2.weight"]
+        out = self._empty(M, Cn)
+        return self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"], **epi_kw)
+
+    # ------------------------------------------------------------------------------------------
+    # request-level (step-invariant) conditioning
+    # ------------------------------------------------------------------------------------------
+    def prepare_request(self, image_embeddings: torch.Tensor, action_ids: np.ndarray, noise_aug_strength: float = 0.02,
+                        cfg_batch: bool = True) -> RequestCond:
+        """image_embeddings: (B,1,Dctx) CLIP embeds of the cond halves (uncond halves are zeros,
+        pipeline:221-227); action_ids: (B,T,Ch) from `action_ids_idx_encode`."""
+        cfg, w = self.cfg, self.w
+        B = image_embeddings.shape[0]
+        Bc = 2 * B if cfg_batch else B
+        T = cfg.num_frames
+        bf = torch.bfloat16
+        ie = image_embeddings.reshape(B, -1).to(self.device, torch.float32)
+        ehs = torch.cat([torch.zeros_like(ie), ie]) if cfg_batch else ie
+        ehs = ehs.to(bf).contiguous()
+        # actions: Fourier features -> proj -> MLP (unet:472, 274-280)
+        feat = action_features(np.asarray(action_ids))
+        if self.act_kpad:
+            feat = np.concatenate([feat, np.zeros((feat.shape[0], self.act_kpad), np.float32)], axis=1)
+        feat = torch.from_numpy(feat).to(self.device, bf)
+        proj = self._linear(feat, "add_action_proj.proj", B * T)
+        act = self._mlp("add_embedding_action", proj, B * T)
+        # noise-aug embedding (unet:484-486); same value for every CFG row
+        nfeat = torch.from_numpy(sinusoid(np.full((Bc,), noise_aug_strength, np.float32), cfg.addition_time_embed_dim))
+        noise = self._mlp("add_embedding_noise", nfeat.to(self.device, bf), Bc)
+        cross, pos = {}, {}
+        for p in self.tr_names:
+            for q in (p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"):
+                v = self._linear(ehs, q + ".attn2.to_v", Bc)
+                cross[q] = self._linear(v, q + ".attn2.to_out.0", Bc, out_f32=True)
+            pos[p] = self.pos_emb_T[p].repeat(Bc, 1).contiguous()
+        return RequestCond(B=B, Bc=Bc, act_emb=act, noise_emb=noise, ehs_bf16=ehs, cross=cross, pos_emb=pos)
+
+    # ------------------------------------------------------------------------------------------
+    # blocks
+    # ------------------------------------------------------------------------------------------
+    def _res_block(self, p, x1, C1, x2, C2, Cout, M, H, W, temb_all, eps):
+        """SpatioTemporalResBlock (resnet.py:686-716) on token-major tensors; (x1|x2) is the channel concat."""
+        hip, w, T = self.hip, self.w, self.cfg.num_frames
+        S = H * W
+        s, t = p + ".spatial_res_block", p + ".temporal_res_block"
+        Cin = C1 + C2
+        xn = hip.groupnorm(x1, C1, x2, C2, M, S, w[s + ".norm1.weight"], w[s + ".norm1.bias"], eps, True)
+        h = self._empty(M, Cout)
+        hip.gemm(xn, w[s + ".conv1.weight"], h, M=M, N=Cout, K=9 * Cin, C1=Cin, mode=A_CONV3X3, H=H, Wd=W,
+                 bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
+                 rows_per_vec=S)
+        hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
+        if s + ".conv_shortcut.weight" in w:
+            sc = self._empty(M, Cout)
+            hip.gemm(x1, w[s + ".conv_shortcut.weight"], sc, M=M, N=Cout, K=Cin, C1=C1, A2=x2, C2=C2,
+                     bias=w[s + ".conv_shortcut.bias"])
+        else:
+            assert x2 is None
+            sc = x1
+        xs = self._empty(M, Cout)
+        hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
+                 bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0)
+        # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
+        xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True)
+        hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
+                 bias=w[t + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[t]:], rowvec_ld=self.temb_total,
+                 rows_per_vec=S)
+        hn = hip.groupnorm(h, Cout, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], eps, True, out=hn)
+        a = self.alpha[p]
+        out = self._empty(M, Cout)
+        # AlphaBlender: a*xs + (1-a)*(xs + conv2(h) + b) = xs + (1-a)*(acc + b)   (resnet.py:784-797)
+        hip.gemm(hn, w[t + ".conv2.weight"], out, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
+                 bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0)
+        return out
+
+    def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
+        """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer."""
+        hip, w, T = self.hip, self.w, self.cfg.num_frames
+        S = H * W
+        frames = M // S
+        batch = frames // T
+        b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
+        scale = 1.0 / math.sqrt(64.0)
+        xn = hip.groupnorm(x, Cn, None, 0, M, S, w[p + ".norm.weight"], w[p + ".norm.bias"], 1e-6, False)
+        h = self._linear(xn, p + ".proj_in", M)
+        # ---- spatial block (attention.py:462-582)
+        a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
+        qk = self._empty(M, 2 * Cn)
+        hip.gemm(a, w[b + ".attn1.to_qk.weight"], qk, M=M, N=2 * Cn, K=Cn, C1=Cn)
+        vt = self._empty(Cn, M)  # V^T = Wv . a^T  (operands swapped: keys become the contiguous dim)
+        hip.gemm(w[b + ".attn1.to_v.weight"], a, vt, M=Cn, N=M, K=Cn, C1=Cn)
+        o = self._empty(M, Cn)
+        hip.attn_spatial(qk, 2 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
+        h = self._linear(o, b + ".attn1.to_out.0", M, res1=h)
+        a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
+                          rows_per_vec=T * S, sum_out=h, out=a)
+        hs = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0)
+        # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
+        hm = self._empty(M, Cn)
+        a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
+                          addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
+        hm = self._geglu_ff(a, t + ".ff_in", M, Cn, res1=hm, ldr1=Cn, beta1=1.0)
+        a = hip.layernorm(hm, M, Cn, w[t + ".norm1.weight"], w[t + ".norm1.bias"], out=a)
+        qkv = self._empty(M, 3 * Cn)
+        hip.gemm(a, w[t + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
+        hip.attn_temporal(qkv, 3 * Cn, o, Cn, batch, T, S, heads, scale)
+        hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm)
+        a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
+                          rows_per_vec=T * S, sum_out=hm, out=a)
+        am = self.alpha[p]
+        # AlphaBlender: am*hs + (1-am)*(hm + ff(a))
+        hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
+                            beta2=am)
+        return self._linear(hb, p + ".proj_out", M, res1=x)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def time_embedding(self, t: float, cond: RequestCond) -> torch.Tensor:
+        """silu(emb) rows for every (cfg item, frame): bf16 [Bc*T, E]  (unet:449-487 + resnet.py:343-344)."""
+        cfg = self.cfg
+        feat = torch.from_numpy(sinusoid(np.full((cond.Bc,), t, np.float32), cfg.block_out_channels[0]))
+        temb = self._mlp("time_embedding", feat.to(self.device, torch.bfloat16), cond.Bc)
+        out = self._empty(cond.Bc * cfg.num_frames, cfg.time_embed_dim)
+        return self.hip.emb_combine(temb, cond.act_emb, cond.noise_emb, cond.Bc, cond.B, cfg.num_frames,
+                                    cfg.time_embed_dim, out)
+
+    def forward(self, x_in: torch.Tensor, emb_silu: torch.Tensor, cond: RequestCond, h: int, w_: int) -> torch.Tensor:
+        """x_in: bf16 [Bc*T*h*w, 64] (wiw_prep_unet_input); emb_silu: bf16 [Bc*T, E] (time_embedding()).
+        Returns fp32 [Bc*T*h*w, 4] (token-major v-prediction)."""
+        cfg, hip, w = self.cfg, self.hip, self.w
+        T = cfg.num_frames
+        ch = cfg.block_out_channels
+        n = len(ch)
+        L = cfg.layers_per_block
+        frames = cond.Bc * T
+        M = frames * h * w_
+        assert x_in.shape == (M, CIN_PAD) and (h % (1 << (n - 1)) == 0) and (w_ % (1 << (n - 1)) == 0)
+        temb_all = self._empty(frames, self.temb_total, dtype=torch.float32)
+        hip.gemm(emb_silu, w["temb_all.weight"], temb_all, M=frames, N=self.temb_total, K=cfg.time_embed_dim,
+                 C1=cfg.time_embed_dim, bias=w["temb_all.bias"], epilogue=EPI_OUT_F32)
+        x = self._empty(M, ch[0])
+        hip.gemm(x_in, w["conv_in.weight"], x, M=M, N=ch[0], K=9 * CIN_PAD, C1=CIN_PAD, mode=A_CONV3X3, H=h, Wd=w_,
+                 bias=w["conv_in.bias"])
+        skips = [(x, ch[0])]
+        H, W, C = h, w_, ch[0]
+        for i in range(n):
+            p = f"down_blocks.{i}"
+            has_attn = i < n - 1
+            eps = 1e-6 if has_attn else 1e-5
+            for j in range(L):
+                x = self._res_block(f"{p}.resnets.{j}", x, C, None, 0, ch[i], M, H, W, temb_all, eps)
+                C = ch[i]
+                if has_attn:
+                    x = self._transformer(f"{p}.attentions.{j}", x, C, M, H, W, cfg.num_attention_heads[i], cond)
+                skips.append((x, C))
+            if i < n - 1:
+                H, W, M = H // 2, W // 2, M // 4
+                y = self._empty(M, C)
+                q = f"{p}.downsamplers.0.conv"
+                hip.gemm(x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_S2, H=H, Wd=W, bias=w[q + ".bias"])
+                x = y
+                skips.append((x, C))
+        x = self._res_block("mid_block.resnets.0", x, C, None, 0, C, M, H, W, temb_all, 1e-5)
+        x = self._transformer("mid_block.attentions.0", x, C, M, H, W, cfg.num_attention_heads[-1], cond)
+        x = self._res_block("mid_block.resnets.1", x, C, None, 0, C, M, H, W, temb_all, 1e-5)
+        rch = list(reversed(ch))
+        rheads = list(reversed(cfg.num_attention_heads))
+        for i in range(n):
+            p = f"up_blocks.{i}"
+            for j in range(L + 1):
+                sk, Cs = skips.pop()
+                x = self._res_block(f"{p}.resnets.{j}", x, C, sk, Cs, rch[i], M, H, W, temb_all, 1e-6)
+                C = rch[i]
+                if i > 0:
+                    x = self._transformer(f"{p}.attentions.{j}", x, C, M, H, W, rheads[i], cond)
+            if i < n - 1:
+                H, W, M = H * 2, W * 2, M * 4
+                y = self._empty(M, C)
+                q = f"{p}.upsamplers.0.conv"
+                hip.gemm(x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_UP, H=H, Wd=W, bias=w[q + ".bias"])
+                x = y
+        xn = hip.groupnorm(x, C, None, 0, M, H * W, w["conv_norm_out.weight"], w["conv_norm_out.bias"], 1e-5, True)
+        out = self._empty(M, cfg.out_channels, dtype=torch.float32)
+        hip.gemm(xn, w["conv_out.weight"], out, M=M, N=cfg.out_channels, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W,
+                 bias=w["conv_out.bias"], epilogue=EPI_OUT_F32)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # reference-shaped convenience entry point (same arguments as the reference forward)
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, sample: torch.Tensor, timestep: float, encoder_hidden_states: torch.Tensor,
+                 added_time_ids: torch.Tensor, added_action_ids: torch.Tensor) -> torch.Tensor:
+        """sample (Bc,T,8,h,w), encoder_hidden_states (Bc,1,D), added_time_ids (Bc,3), added_action_ids (B,T,Ch)
+        -> (Bc,T,4,h,w) fp32.  Layout conversion here is torch plumbing for tests; the served loop
+        (pipeline.py) assembles the token-major input with wiw_prep_unet_input instead."""
+        Bc, T, Cin, h, w_ = sample.shape
+        B = added_action_ids.shape[0]
+        assert Bc % B == 0 and T == self.cfg.num_frames
+        ehs = encoder_hidden_states.reshape(Bc, -1).to(self.device, torch.float32)
+        cond = self.prepare_request(ehs[Bc - B:].reshape(B, 1, -1), added_action_ids.cpu().numpy(),
+                                    float(added_time_ids[0, -1]), cfg_batch=(Bc == 2 * B))
+        # the general (non-zero uncond embeds) case: overwrite the embeds prepared above
+        if Bc == 2 * B and float(ehs[:B].abs().max()) != 0.0:
+            raise ValueError("uncond image embeddings must be zeros (pipeline:221-227)")
+        x = sample.to(self.device, torch.float32).permute(0, 1, 3, 4, 2).reshape(Bc * T * h * w_, Cin)
+        x_in = torch.zeros(Bc * T * h * w_, CIN_PAD, dtype=torch.bfloat16, device=self.device)
+        x_in[:, :Cin] = x.to(torch.bfloat16)
+        emb = self.time_embedding(float(timestep), cond)
+        out = self.forward(x_in, emb, cond, h, w_)
+        return out.reshape(Bc, T, h, w_, self.cfg.out_channels).permute(0, 1, 4, 2, 3).contiguous()
