@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Benchmark of the SVD denoising hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one full rollout of the hot loop: 25 Euler steps (prep_unet_input -> UNet forward ->
+CFG + Euler) over one batch of synthetic candidates at 576x1024x14 (BASELINE.json configs[1]; latent
+72x128, CFG batch 2 per candidate).  Inputs (cond latents, CLIP embeds, noise, actions) are already
+resident in HBM when the timed region starts; weights are seeded random-init of the exact served
+architecture (no checkpoint offline).  value = denoised frames/s of the whole job = N * B * 14 * K / t.
+
+N > 1: one process per GPU (RCCL over xGMI); rank 0 owns the request of N*B candidates, broadcasts the
+conditioning tensors, every rank denoises its slice, latents are gathered on rank 0 (weak scaling:
+B candidates per GPU).  Both collectives are inside the timed region.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (HIP-event timing of every GEMM
+launch inside the timed region, on the launch stream) and "cpu_baseline" (the CPU oracle timed on the
+host cores on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ALGO_TFLOP_PER_FORWARD = 89.604  # per UNet forward per candidate (CFG on), 576x1024x14
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+MODE_NAMES = {0: "gemm_kernel<dense>", 1: "gemm_kernel<conv3x3>", 2: "gemm_kernel<conv3x3_s2>",
+              3: "gemm_kernel<conv3x3_up>", 4: "gemm_kernel<conv_t3>"}
+
+
+def synth_actions(B, T):
+    base = [4] + [[1, 2, 1, 3][i % 4] for i in range(T - 1)]  # exercises both rolls
+    return np.tile(np.array(base, dtype=np.int64), (B, 1))
+
+
+def cpu_baseline(sd_cpu, cfg, threads):
+    """Oracle ("port") on the host cores: ONE fp32 UNet forward of BASELINE config 0 (256x256x8, CFG on)
+    = 1/10 of its 10-step rollout; frames/s extrapolated as 8 / (10 * t_forward)."""
+    import svd_oracle as O
+
+    torch.set_num_threads(threads)
+    T, h, w = 8, 32, 32
+    ocfg = dict(cfg.as_dict(), num_frames=T, action_input_channel=cfg.action_input_channel)
+    rs = np.random.RandomState(0)
+    sample = torch.from_numpy(rs.standard_normal((2, T, 8, h, w)).astype(np.float32))
+    ehs = torch.from_numpy(rs.standard_normal((2, 1, cfg.cross_attention_dim)).astype(np.float32))
+    tids = torch.tensor([[6, 127, 0.02]] * 2)
+    # the nav checkpoint embeds 14-channel action rows; the 8-frame config uses the first 8 frames' rows
+    aid = torch.from_numpy(O.action_ids_idx_encode(synth_actions(1, cfg.action_input_channel)))[:, :T]
+    t0 = time.time()
+    with torch.no_grad():
+        O.unet_forward(sd_cpu, ocfg, sample, torch.tensor(1.0), ehs, tids, aid)
+    dt = time.time() - t0
+    return {"value": round(8.0 / (10.0 * dt), 5), "unit": "frames/s", "cores": threads, "kind": "port",
+            "seconds_per_forward": round(dt, 3),
+            "sample": "1 of the 10 UNet forwards (CFG batch 2, fp32, full-size weights) of BASELINE config 0 "
+                      "(256x256x8, 10 steps); frames/s = 8 / (10 * t_forward)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed rollouts (each = num-inference-steps Euler steps)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="candidates per GPU")
+    ap.add_argument("--num-inference-steps", type=int, default=25)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.parallel import sharded_denoise
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict_torch
+
+    cfg = UNetConfig.tiny(14) if args.tiny else UNetConfig()
+    T = cfg.num_frames
+    h, w = args.height // 8, args.width // 8
+    sd = random_state_dict_torch(cfg, 0, device, torch.float32)
+    unet = UNetHIP(cfg, sd, device)
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    den = SVDDenoiser(unet)
+
+    B = args.batch
+    Btot = B * world
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    req = None
+    if rank == 0:
+        req = dict(image_latents=torch.randn(Btot, 4, h, w, generator=g).to(device),
+                   image_embeddings=torch.randn(Btot, 1, cfg.cross_attention_dim, generator=g).to(device),
+                   noise=torch.randn(Btot, T, 4, h, w, generator=torch.Generator().manual_seed(1)).to(device),
+                   actions=synth_actions(Btot, T))
+
+    def rollout():
+        if world == 1:
+            return den.denoise(req["image_latents"], req["image_embeddings"], req["noise"], req["actions"],
+                               num_steps=args.num_inference_steps)
+        r = req or dict(image_latents=None, image_embeddings=None, noise=None, actions=None)
+        return sharded_denoise(den.denoise, device, r["image_latents"], r["image_embeddings"], r["noise"], r["actions"],
+                               num_steps=args.num_inference_steps)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        rollout()
+    if not args.no_kernel_events:
+        unet.hip.gemm_profile = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = rollout()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    prof = unet.hip.gemm_profile
+    unet.hip.gemm_profile = None
+    if rank == 0:
+        assert out is not None and torch.isfinite(out).all(), "non-finite latents"
+        frames = Btot * T * args.steps
+        value = frames / dt
+        res = {
+            "metric": "denoised frames/sec (576x1024x14, 25 steps)", "value": round(value, 4), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
+                                   f"CFG on, {B} candidate(s)/GPU, random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
+                       "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}"},
+        }
+        fwd_per_step = args.num_inference_steps * B
+        algo = ALGO_TFLOP_PER_FORWARD * (h * w) / (72 * 128) * fwd_per_step  # linear in pixels & candidates
+        if not args.tiny:
+            res["mfma_util_algorithmic"] = round(algo * args.steps / dt / PEAK_BF16_TFLOPS, 4)
+            res["algorithmic_tflop_per_step"] = round(algo, 1)
+        if prof:
+            by_mode = {}
+            for e0, e1, fl, mode in prof:
+                d = by_mode.setdefault(mode, [0.0, 0.0, 0])
+                d[0] += e0.elapsed_time(e1) * 1e-3
+                d[1] += fl
+                d[2] += 1
+            dom = max(by_mode, key=lambda m: by_mode[m][0])
+            tsec, fl, cnt = by_mode[dom]
+            ach = fl / tsec / 1e12
+            res["roofline"] = {"kernel": MODE_NAMES[dom], "bound": "mfma", "achieved": round(ach, 1),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "traffic": None, "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
+                               "share_of_timed_region": round(tsec / dt, 3)}
+            res["gemm_kernels"] = {MODE_NAMES[m]: {"launches": v[2], "seconds": round(v[0], 4),
+                                                   "tflops": round(v[1] / v[0] / 1e12, 1)} for m, v in sorted(by_mode.items())}
+        if sd_cpu is not None:
+            try:
+                res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, os.cpu_count() or 1)
+            except Exception as e:  # the GPU number stands on its own; report why the baseline is absent
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

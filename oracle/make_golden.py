@@ -241,9 +241,33 @@ def gen_pipeline(ns):
         image_latents.append(cap["il"][1].numpy())  # cond half (uncond half is zeros)
         assert float(cap["il"][0].abs().max()) == 0.0 and float(cap["ie"][0].abs().max()) == 0.0
         image_embeds.append(cap["ie"][1].numpy())
+    # the reference's own bf16 run of the same loop (UNet in bf16, identical conditioning tensors): the
+    # yardstick for "bf16-class" error in the HIP parity test
+    pipe_bf = StableVideoDiffusionPipeline(vae=vae, image_encoder=clip, unet=ref_unet(ns, cfg, seed=3).to(torch.bfloat16),
+                                           scheduler=make_scheduler(ns), feature_extractor=CLIPImageProcessor())
+    pipe_bf.set_progress_bar_config(disable=True)
+    results_bf16 = []
+    for b in range(B):
+        queue = [img_noise, lat_noise]
+        orig = pl.randn_tensor
+        pl.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.from_numpy(queue.pop(0).copy()).to(dtype)
+        il = torch.from_numpy(image_latents[b])[None]
+        ie = torch.from_numpy(image_embeds[b])[None]
+        pipe_bf._encode_vae_image = lambda *a, **k: torch.cat([torch.zeros_like(il), il])
+        pipe_bf._encode_image = lambda *a, **k: torch.cat([torch.zeros_like(ie), ie]).to(torch.bfloat16)
+        try:
+            aid = ns.get_action_ids(1, torch.from_numpy(acts[b:b + 1]), "micro_cond", torch.bfloat16)
+            with torch.no_grad():
+                lat = pipe_bf([imgs[b]], height=H, width=W, num_frames=T, fps=7, motion_bucket_id=127,
+                              noise_aug_strength=0.02, num_inference_steps=steps, added_action_ids=aid,
+                              output_type="latent").frames
+        finally:
+            pl.randn_tensor = orig
+        results_bf16.append(lat[0].float().numpy())
     save("pipeline_tiny.npz", weight_seed=np.array(3), num_steps=np.array(steps), actions=acts,
          latent_noise=np.repeat(lat_noise, B, axis=0), image_latents=np.stack(image_latents),
-         image_embeddings=np.stack(image_embeds), latents_out=np.stack(results))
+         image_embeddings=np.stack(image_embeds), latents_out=np.stack(results),
+         latents_out_ref_bf16=np.stack(results_bf16))
 
 
 def main():
