@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dump-shapes", type=str, default="", help="write per-(M,N,K) GEMM timings to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,11 +176,15 @@ def main():
             res["algorithmic_tflop_per_step"] = round(algo, 1)
         if prof:
             by_mode = {}
-            for e0, e1, fl, mode in prof:
+            shapes = {}
+            for e0, e1, fl, mode, shp in prof:
                 d = by_mode.setdefault(mode, [0.0, 0.0, 0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += fl
                 d[2] += 1
+                sh = shapes.setdefault((mode,) + shp, [0.0, 0])
+                sh[0] += e0.elapsed_time(e1) * 1e-3
+                sh[1] += 1
             dom = max(by_mode, key=lambda m: by_mode[m][0])
             tsec, fl, cnt = by_mode[dom]
             ach = fl / tsec / 1e12
@@ -189,9 +194,15 @@ def main():
                                "share_of_timed_region": round(tsec / dt, 3)}
             res["gemm_kernels"] = {MODE_NAMES[m]: {"launches": v[2], "seconds": round(v[0], 4),
                                                    "tflops": round(v[1] / v[0] / 1e12, 1)} for m, v in sorted(by_mode.items())}
+            if args.dump_shapes:
+                rows = sorted(((k, v) for k, v in shapes.items()), key=lambda kv: -kv[1][0])
+                with open(args.dump_shapes, "w") as f:
+                    for (mode, M, N, K, epi), (sec, cnt) in rows:
+                        f.write(f"mode={mode} M={M} N={N} K={K} epi={epi} launches={cnt} total_ms={1e3 * sec:.2f} "
+                                f"avg_us={1e6 * sec / cnt:.1f} tflops={2.0 * M * N * K * cnt / sec / 1e12:.1f}\n")
         if sd_cpu is not None:
             try:
-                res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, os.cpu_count() or 1)
+                res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, min(os.cpu_count() or 1, 32))
             except Exception as e:  # the GPU number stands on its own; report why the baseline is absent
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

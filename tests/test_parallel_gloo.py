@@ -1,0 +1,73 @@
+"""Candidate sharding across ranks (world_size 2, gloo, CPU): the N>1 path of bench.py / the server."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import wiw_amd  # noqa: F401
+from wiw_amd.parallel import shard_bounds, sharded_denoise
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def fake_denoise(il, ie, noise, actions, num_steps=2, **kw):
+    a = torch.as_tensor(np.asarray(actions), dtype=torch.float32)[:, :, None, None, None]
+    return il[:, None] * (1 + a) + 0.5 * noise + ie.mean((1, 2))[:, None, None, None, None] * num_steps
+
+
+def _run(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        req = [None] * 4
+        if rank == 0:
+            g = torch.Generator().manual_seed(0)
+            req = [torch.randn(B, 4, 4, 8, generator=g), torch.randn(B, 1, 16, generator=g),
+                   torch.randn(B, 3, 4, 4, 8, generator=g), np.arange(B * 3).reshape(B, 3) % 5]
+        out = sharded_denoise(fake_denoise, torch.device("cpu"), *req, num_steps=3)
+        if rank == 0:
+            ref = fake_denoise(req[0], req[1], req[2], req[3], num_steps=3)
+            q.put(float((out - ref).abs().max()))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds():
+    assert shard_bounds(64, 8) == [(8 * i, 8 * i + 8) for i in range(8)]
+    assert shard_bounds(3, 2) == [(0, 2), (2, 3)]
+    assert shard_bounds(1, 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+
+
+def _spawn(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return err
+
+
+def test_sharded_equals_single_rank_even_and_ragged():
+    assert _spawn(4) == 0.0   # 2 + 2
+    assert _spawn(3) == 0.0   # 2 + 1 (ragged)
+    assert _spawn(1) == 0.0   # 1 + 0 (a rank with no candidate)

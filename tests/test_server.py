@@ -1,0 +1,209 @@
+"""Drop-in boundary tests (CPU): the wire protocol, the request/response schema, the manager-compatible
+worker loop and the standalone TCP server, driven by a minimal restatement of the reference CLIENT
+(`Solver.send_batch_to_server`, downstream/solver_base.py:645-688).  The HIP denoiser is replaced by a
+deterministic stand-in here (no GPU); the GPU end-to-end variant lives in tests/test_hip_server.py."""
+import io
+import json
+import os
+import pickle
+import socket
+import struct
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import wiw_amd  # noqa: F401
+from wiw_amd.server import plumbing as P
+from wiw_amd.server.protocol import DONE, dumps_frame, read_framed, read_pickled, write_framed, write_pickled
+from wiw_amd.server.worker import SVDWorker, build_arg_parser, serve_tcp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class ToyFrontend:
+    """8x downsampling 'VAE' + mean-pool 'CLIP' stand-ins with the Frontend interface."""
+
+    def encode(self, images, image_noise, noise_aug_strength):
+        x = images + noise_aug_strength * image_noise
+        B, _, H, W = x.shape
+        lat = x.reshape(B, 3, H // 8, 8, W // 8, 8).mean((3, 5))
+        lat = np.concatenate([lat, lat[:, :1]], 1).astype(np.float32)
+        emb = np.tile(x.mean((2, 3)), (1, 342))[:, None, :1024].astype(np.float32)
+        return lat, emb
+
+    def decode(self, latents):
+        B, T, _, h, w = latents.shape
+        return np.clip(np.repeat(np.repeat(latents[:, :, :3], 8, axis=3), 8, axis=4), -1, 1).astype(np.float32)
+
+
+def toy_denoise(image_latents, image_embeddings, noise, actions, num_steps=30, **kw):
+    B, T = noise.shape[:2]
+    a = np.asarray(actions, dtype=np.float32)[:, :, None, None, None] / 4.0
+    return (image_latents[:, None] * (1 - 0.1 * a) + 0.001 * noise).astype(np.float32)
+
+
+def make_worker(**kw):
+    return SVDWorker(toy_denoise, ToyFrontend(), width=128, height=64, out_width=48, out_height=40, **kw)
+
+
+def make_request(b, T=14, with_image=True, return_objects=True, tmp=None):
+    rs = np.random.RandomState(0)
+    acts = np.tile(np.array([[4, 1, 2, 1, 3, 1, 1, 2, 2, 1, 3, 3, 1, 1]], dtype=np.int64), (b, 1))
+    req = {"b_action": acts, "save_dirs": [os.path.join(str(tmp), f"PredA-{i}") for i in range(b)],
+           "request_model_name": "igen"}
+    if with_image:
+        req["b_image"] = rs.randint(0, 256, size=(b, 3, 64, 128), dtype=np.uint8)
+    if return_objects:
+        req["return_objects"] = [True] * b
+    return req
+
+
+def test_frame_format_is_bigendian_length_plus_pickle():
+    obj = {"a": np.arange(5), "s": "x"}
+    raw = dumps_frame(obj)
+    (n,) = struct.unpack(">I", raw[:4])
+    assert n == len(raw) - 4 and pickle.loads(raw[4:])["s"] == "x"
+    buf = io.BytesIO()
+    write_pickled(buf, (3, 7, obj))
+    buf.seek(0)
+    cid, tid, back = read_pickled(buf)
+    assert (cid, tid) == (3, 7) and (back["a"] == obj["a"]).all()
+    with pytest.raises(EOFError):
+        read_pickled(io.BytesIO(b"\x00\x00"))
+
+
+def test_request_validation_matches_reference_contract(tmp_path):
+    req = make_request(2, tmp=tmp_path)
+    P.check_inputdict(req)
+    bad = dict(req)
+    del bad["save_dirs"]
+    with pytest.raises(KeyError, match="Missing required keys"):
+        P.check_inputdict(bad)
+    with pytest.raises(AssertionError):
+        P.check_inputdict(dict(req, b_action=req["b_action"].astype(np.int32)))
+    with pytest.raises(AssertionError, match="does not match deployed"):
+        P.parse_request(dict(req, request_model_name="svd"))
+
+
+def test_worker_response_schema_and_uint8_truncation(tmp_path):
+    w = make_worker()
+    out = w(make_request(2, tmp=tmp_path))
+    assert set(out) == {"pred_frames", "save_dirs"}
+    pf = out["pred_frames"]
+    assert isinstance(pf, np.ndarray) and pf.dtype == np.uint8 and pf.shape == (2, 14, 3, 40, 48)
+    # process_output_dict truncates (api_models/__init__.py:230), numpy_to_pil rounds (image_processor.py:147)
+    v = np.array([[[[[0.999, 0.5, 0.00392]]]]], dtype=np.float32)
+    assert P.build_response(v, [[4]], ["d"], True)["pred_frames"].ravel().tolist() == [254, 127, 0]
+    assert np.asarray(P.frames_to_pil(np.full((1, 3, 1, 1), 0.999 * 2 - 1, np.float32))[0]).ravel().tolist() == [255] * 3
+
+
+def test_worker_file_mode_writes_reference_layout(tmp_path):
+    w = make_worker()
+    req = make_request(1, return_objects=False, tmp=tmp_path)
+    out = w(req)
+    assert set(out) == {"save_dirs"}
+    d = req["save_dirs"][0]
+    assert sorted(os.listdir(d)) == sorted([f"{i}.jpg" for i in range(14)] + ["action_seq.json"])
+    assert json.load(open(os.path.join(d, "action_seq.json"))) == req["b_action"][0].tolist()
+    assert Image.open(os.path.join(d, "0.jpg")).size == (48, 40)
+
+
+def test_worker_loads_cond_rgb_when_no_b_image(tmp_path):
+    req = make_request(1, with_image=False, tmp=tmp_path)
+    os.makedirs(req["save_dirs"][0])
+    Image.fromarray(np.zeros((64, 128, 3), np.uint8)).save(os.path.join(req["save_dirs"][0], "cond_rgb.png"))
+    assert make_worker()(req)["pred_frames"].shape[0] == 1
+
+
+def test_persistent_generator_semantics(tmp_path):
+    """The worker's generator persists across requests (eval_inference.py:97, 258): the second identical
+    request draws different noise; a fresh worker with the same seed reproduces the first."""
+    req = make_request(1, tmp=tmp_path)
+    w = make_worker(seed=1)
+    a, b = w(req)["pred_frames"], w(req)["pred_frames"]
+    c = make_worker(seed=1)(req)["pred_frames"]
+    assert (a == c).all() and (a != b).any()
+
+
+def _client_roundtrip(port, req):
+    """send_batch_to_server: connect, write_framed, blocking read_framed (solver_base.py:645-688)."""
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.connect(("127.0.0.1", port))
+    try:
+        P.check_inputdict(req)
+        write_framed(s, req)
+        out = read_framed(s)
+        write_framed(s, DONE)
+        return out
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("batch_size", [0, 1])
+def test_tcp_server_speaks_client_protocol(tmp_path, batch_size):
+    ready, stop = threading.Event(), threading.Event()
+    th = threading.Thread(target=serve_tcp, kwargs=dict(worker=make_worker(), port=0, batch_size=batch_size,
+                                                        ready=ready, stop=stop), daemon=True)
+    th.start()
+    assert ready.wait(10)
+    try:
+        req = make_request(3, tmp=tmp_path)
+        out = _client_roundtrip(ready.port, req)
+        assert out["save_dirs"] == req["save_dirs"]
+        pf = out["pred_frames"]
+        if batch_size == 0:   # true batching: ndarray, as when a client bypasses the manager
+            assert isinstance(pf, np.ndarray) and pf.shape == (3, 14, 3, 40, 48)
+        else:                  # manager-style split to 1 + list.extend recompose (worker_manager.py:471-481)
+            assert isinstance(pf, list) and len(pf) == 3 and pf[0].shape == (14, 3, 40, 48) and pf[0].dtype == np.uint8
+        # two clients in sequence on the same server
+        assert _client_roundtrip(ready.port, make_request(1, tmp=tmp_path))["save_dirs"]
+    finally:
+        stop.set()
+        th.join(5)
+
+
+def test_split_and_recompose_like_the_manager():
+    req = {"b_action": np.arange(6).reshape(3, 2), "save_dirs": ["a", "b", "c"], "request_model_name": "igen"}
+    parts = P.split_batch(req, 1)
+    assert len(parts) == 3 and parts[1]["save_dirs"] == ["b"] and parts[2]["request_model_name"] == "e"  # str sliced too: "igen"[2:3]
+    out = P.recompose([{"save_dirs": ["a"], "pred_frames": np.zeros((1, 2), np.uint8)},
+                       {"save_dirs": ["b"], "pred_frames": np.ones((1, 2), np.uint8)}])
+    assert out["save_dirs"] == ["a", "b"] and len(out["pred_frames"]) == 2
+
+
+def test_manager_compatible_pipe_worker(tmp_path):
+    """Launch the worker the way the manager does (worker_manager.py:303-346): tasks on stdin, results on an
+    inherited fd passed as the LAST argv; "DONE" ends the loop."""
+    r_fd, w_fd = os.pipe()
+    code = (
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import wiw_amd\n"
+        "from wiw_amd.server.worker import worker_main\n"
+        "from test_server import make_worker\n"
+        "worker_main(int(sys.argv[-1]), make_worker())\n" % (ROOT, os.path.join(ROOT, "tests")))
+    proc = subprocess.Popen([sys.executable, "-c", code, "--device", "cuda:0", str(w_fd)], stdin=subprocess.PIPE,
+                            pass_fds=[w_fd])
+    os.close(w_fd)
+    try:
+        req = make_request(1, tmp=tmp_path)
+        write_pickled(proc.stdin, (5, 42, req))
+        with os.fdopen(r_fd, "rb") as rf:
+            cid, tid, res = read_pickled(rf)
+            assert (cid, tid) == (5, 42) and res["pred_frames"].shape == (1, 14, 3, 40, 48)
+            write_pickled(proc.stdin, DONE)
+            assert proc.wait(30) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+
+
+def test_cli_accepts_the_reference_launcher_arguments():
+    args = build_arg_parser().parse_args(
+        "--width 1024 --height 576 --out_width 480 --out_height 480 --num_frames 14 --num_past_obs 1 "
+        "--task_type navigation --action_strategy micro_cond --action_input_channel 14 --device cuda:0 "
+        "--unet_path /x/unet --svd_path /y --log_dir logs --exp_id e1".split())
+    assert args.num_frames == 14 and args.action_input_channel == 14

@@ -20,7 +20,21 @@ WIW_DEV uint16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite on
 }
 WIW_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 WIW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-WIW_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (activations.py:109 `F.gelu`), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e.
+// fp32-roundoff class): 1 rcp + 1 exp + 6 fma instead of libm erff's ~40 instructions — the GEGLU
+// epilogue evaluates 10240 of these per block tile.
+WIW_DEV float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float erf_abs = 1.0f - poly * t * __expf(-z * z);
+    const float erf_v = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_v);
+}
 
 WIW_DEV void unpack8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
     const int n_valid = geglu ? p.n_out : p.N;
     const bool vec_ok = (n_valid % 8 == 0) && (p.ldo % 8 == 0) && (p.res1 == nullptr || p.ldr1 % 8 == 0) &&
                         (p.res2 == nullptr || p.ldr2 % 8 == 0);
+    const bool vec_rv = (((uintptr_t)p.bias | (uintptr_t)p.rowvec) & 15) == 0 && (p.rowvec_ld % 4 == 0);
     const int CH = geglu ? 10 : 20;
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
@@ -220,23 +221,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
                 const float4 t1 = *(const float4*)(st + row * EP_LD + 80 + cl + 4);
                 g[0] = t0.x; g[1] = t0.y; g[2] = t0.z; g[3] = t0.w;
                 g[4] = t1.x; g[5] = t1.y; g[6] = t1.z; g[7] = t1.w;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float bv = 0.f, bg = 0.f;
-                    if (p.bias) { bv = p.bias[n0 + cl + e]; bg = p.bias[n0 + 80 + cl + e]; }
-                    v[e] = (v[e] + bv) * gelu_erf_f(g[e] + bg);
+                if (p.bias) {   // packed bias: 16-byte aligned runs of 8 (n0, cl multiples of 8)
+                    const float4 bv0 = *(const float4*)(p.bias + n0 + cl), bv1 = *(const float4*)(p.bias + n0 + cl + 4);
+                    const float4 bg0 = *(const float4*)(p.bias + n0 + 80 + cl), bg1 = *(const float4*)(p.bias + n0 + 80 + cl + 4);
+                    v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w;
+                    v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
+                    g[0] += bg0.x; g[1] += bg0.y; g[2] += bg0.z; g[3] += bg0.w;
+                    g[4] += bg1.x; g[5] += bg1.y; g[6] += bg1.z; g[7] += bg1.w;
                 }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
             } else {
                 const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.rowvec_ld : nullptr;
+                if (vec_ok && vec_rv) {
+                    if (p.bias) {
+                        const float4 b0 = *(const float4*)(p.bias + ncol), b1 = *(const float4*)(p.bias + ncol + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    if (rv) {
+                        const float4 b0 = *(const float4*)(rv + ncol), b1 = *(const float4*)(rv + ncol + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = ncol + e;
+                        if (n < n_valid) {
+                            if (p.bias) v[e] += p.bias[n];
+                            if (rv) v[e] += rv[n];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int n = ncol + e;
-                    float y = v[e];
-                    if (n < n_valid) {
-                        if (p.bias) y += p.bias[n];
-                        if (rv) y += rv[n];
-                    }
-                    y *= p.alpha;
+                    float y = v[e] * p.alpha;
                     if (do_silu) y = silu_f(y);
                     v[e] = y;
                 }

@@ -96,7 +96,7 @@ class Hip:
         self.arch = name.value.decode()
         self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
         # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
-        # entries are (start_event, end_event, algorithmic_flops, mode)
+        # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
 
     # ---- helpers
@@ -129,7 +129,7 @@ class Hip:
         e0.record()
         self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
         e1.record()
-        self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode))
+        self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode, (M, N, K, epilogue)))
         return out
 
     def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale):

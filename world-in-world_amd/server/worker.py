@@ -1,0 +1,175 @@
+"""The SVD world-model worker: request dict -> 14-frame rollouts -> response dict.
+
+Mirrors `do_some_tasks` / `Navigator.inference` of the reference worker
+(FTsvd/eval_inference.py:228-266, 313-349) with the same fixed knobs (fps 7, motion bucket 127,
+noise_aug 0.02, 30 Euler steps served / 25 in the benchmark metric, output 480x480) and the same
+persistent seeded generator semantics (one generator for the worker's lifetime, :97, 258; draw order
+image-noise then latent-noise).
+
+The denoising loop runs on the HIP kernels (`SVDDenoiser`).  Image conditioning (CLIP embed + VAE
+encode) and latent decoding (temporal VAE) are PyTorch modules supplied through `frontend`
+(north_star: "PyTorch-ROCm only for tensor plumbing and the VAE encode/decode"); they are the
+"next" rows of SURVEY.md §8(f) and are injected so that the worker is testable without checkpoints.
+
+Two transports:
+  * `serve_tcp`   — speaks the client protocol directly (what `Solver.send_batch_to_server` expects,
+                    downstream/solver_base.py:645-688): one request -> one response, "DONE" closes;
+  * `worker_main` — manager-compatible loop: framed `(client_id, task_id, payload)` on stdin,
+                    framed `(client_id, task_id, result)` on the inherited fd given as last argv
+                    (downstream/utils/worker_manager.py:660-702).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import socket
+import sys
+import threading
+from typing import Callable, Optional, Protocol
+
+import numpy as np
+
+from . import plumbing as P
+from .protocol import DONE, read_framed, read_pickled, write_framed, write_pickled
+
+
+class Frontend(Protocol):
+    """PyTorch side of the worker (CLIP + VAE)."""
+
+    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float):
+        """images (B,3,H,W) in [-1,1]; returns (image_latents (B,4,h,w), image_embeddings (B,1,D)) float32."""
+
+    def decode(self, latents: np.ndarray) -> np.ndarray:
+        """latents (B,T,4,h,w) -> frames (B,T,3,H,W) in [-1,1] float32 (decode_latents, pipeline:282-309)."""
+
+
+class SVDWorker:
+    def __init__(self, denoise_fn: Callable[..., "np.ndarray"], frontend: Frontend, *, width=1024, height=576,
+                 out_width=480, out_height=480, num_frames=14, num_inference_steps=30, seed=1,
+                 world_model_name=P.WORLD_MODEL_NAME, noise_fn: Optional[Callable] = None):
+        self.denoise_fn = denoise_fn
+        self.frontend = frontend
+        self.width, self.height = width, height
+        self.out_size = (out_width, out_height)
+        self.num_frames = num_frames
+        self.num_inference_steps = num_inference_steps
+        self.world_model_name = world_model_name
+        # persistent generator: the draws of request k depend on requests 0..k-1, as in the reference
+        self._rng = np.random.Generator(np.random.Philox(seed))
+        self.noise_fn = noise_fn or (lambda shape: self._rng.standard_normal(shape, dtype=np.float32))
+
+    def __call__(self, request: dict) -> dict:
+        """do_some_tasks (eval_inference.py:313-349)."""
+        b_action, save_dirs, return_objects, images = P.parse_request(request, self.world_model_name)
+        b_action = np.asarray(b_action)
+        if b_action.ndim != 2 or b_action.shape[1] != self.num_frames:
+            raise AssertionError(f"navigation b_action must be (b, {self.num_frames}), got {b_action.shape}")
+        B = len(images)
+        x = np.stack([P.preprocess_image(im, self.width, self.height) for im in images])
+        img_noise = self.noise_fn(x.shape)                                   # draw 1 (pipeline:522)
+        image_latents, image_embeddings = self.frontend.encode(x, img_noise, 0.02)
+        h, w = image_latents.shape[-2:]
+        lat_noise = self.noise_fn((B, self.num_frames, 4, h, w))             # draw 2 (pipeline:765)
+        latents = self.denoise_fn(image_latents, image_embeddings, lat_noise, b_action,
+                                  num_steps=self.num_inference_steps, fps=7, motion_bucket_id=127,
+                                  noise_aug_strength=0.02)
+        frames = self.frontend.decode(np.asarray(latents, dtype=np.float32))  # (B,T,3,H,W) in [-1,1]
+        clips = [P.frames_to_pil(f) for f in frames]
+        video = P.images_to_tensor(clips, save_size=self.out_size)
+        out = P.build_response(video, b_action, list(save_dirs), return_objects)
+        P.check_outputdict(out)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# transports
+# ------------------------------------------------------------------------------------------------
+def _handle_client(conn: socket.socket, worker: Callable[[dict], dict], batch_size: int, lock: threading.Lock):
+    with conn:
+        while True:
+            try:
+                req = read_framed(conn)
+            except EOFError:
+                return
+            if isinstance(req, str) and req == DONE:
+                return
+            P.check_inputdict(req)
+            if batch_size and batch_size > 0:  # the manager's split / recompose (worker_manager.py:448-481)
+                parts = []
+                for sub in P.split_batch(req, batch_size):
+                    with lock:
+                        parts.append(worker(sub))
+                resp = P.recompose(parts)
+            else:
+                with lock:
+                    resp = worker(req)
+            write_framed(conn, resp)
+
+
+def serve_tcp(worker: Callable[[dict], dict], host="127.0.0.1", port=7000, batch_size: int = 0,
+              ready: Optional[threading.Event] = None, stop: Optional[threading.Event] = None) -> None:
+    """Accept loop (worker_manager.py:644-656): one thread per client, compute serialised by a lock.
+    batch_size > 0 reproduces the manager's split into sub-batches (responses then carry LISTS per key,
+    exactly what the reference's recompose yields); 0 hands the whole request to the worker (true batching)."""
+    lock = threading.Lock()
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind((host, port))
+    srv.listen(16)
+    srv.settimeout(0.2)
+    if ready is not None:
+        ready.port = srv.getsockname()[1]
+        ready.set()
+    try:
+        while stop is None or not stop.is_set():
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                continue
+            threading.Thread(target=_handle_client, args=(conn, worker, batch_size, lock), daemon=True).start()
+    finally:
+        srv.close()
+
+
+def worker_main(pipe_fd: int, task_fn: Callable[[dict], dict], stdin=None) -> None:
+    """Manager-compatible worker loop (worker_manager.py:660-702): strictly serial, exceptions are NOT
+    swallowed (the reference lets the process die; the manager then logs EOF)."""
+    stdin = stdin or sys.stdin.buffer
+    with os.fdopen(pipe_fd, "wb", buffering=2048 * 1024) as out:
+        while True:
+            try:
+                item = read_pickled(stdin)
+            except EOFError:
+                break
+            if isinstance(item, str) and item == DONE:
+                break
+            client_id, task_id, payload = item
+            if isinstance(payload, str) and payload == DONE:
+                break
+            result = task_fn(payload)
+            P.check_outputdict(result)
+            write_pickled(out, (client_id, task_id, result))
+
+
+def build_arg_parser() -> argparse.ArgumentParser:
+    """CLI surface the reference launcher passes (eval_inference.py:273-295, workers_cfg.py:23-30, 270-280)."""
+    ap = argparse.ArgumentParser(description="MI355X-native SVD world-model worker")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--out_width", type=int, default=480)
+    ap.add_argument("--out_height", type=int, default=480)
+    ap.add_argument("--log_dir", type=str, default="downstream/logs")
+    ap.add_argument("--exp_id", type=str, default="wiw_amd")
+    ap.add_argument("--num_frames", type=int, default=14)
+    ap.add_argument("--num_past_obs", type=int, default=1)
+    ap.add_argument("--task_type", type=str, default="navigation", choices=["navigation"])
+    ap.add_argument("--action_strategy", type=str, default="micro_cond", choices=["micro_cond"])
+    ap.add_argument("--action_input_channel", type=int, default=14)
+    ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--unet_path", type=str, default="")
+    ap.add_argument("--svd_path", type=str, default="")
+    ap.add_argument("--weight_dtype", type=str, default="bfloat16")
+    ap.add_argument("--num_inference_steps", type=int, default=30)
+    ap.add_argument("--port", type=int, default=0, help="> 0: standalone TCP server instead of the manager pipe loop")
+    ap.add_argument("--batch_size", type=int, default=0)
+    return ap
