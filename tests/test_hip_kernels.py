@@ -324,3 +324,64 @@ def test_emb_combine(hip):
     hip.emb_combine(dev_f(t), dev_f(a), dev_f(n), Bc, B, T, E, out)
     ref = t.repeat_interleave(T, 0) + a.reshape(B, T, E).repeat(Bc // B, 1, 1).reshape(Bc * T, E) + n.repeat_interleave(T, 0)
     check(out, F.silu(ref), what="emb_combine")
+
+
+# ----------------------------------------------------------------------------------------------
+# the BIG tile configuration (256 x 160, 8 waves, 3-stage LDS ring) is selected for large M only
+# ----------------------------------------------------------------------------------------------
+def test_gemm_big_tile_dense_and_geglu(hip):
+    from wiw_amd import hip as H
+    from wiw_amd.unet import pack_geglu
+
+    M, N, K = 49152 + 37, 320, 192      # ragged last M tile; 3 K tiles (prologue + steady state + drain)
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    bias, r1 = rnd(N, seed=3), bf(rnd(M, N, seed=5))
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K, bias=dev_f(bias), res1=dev_bf(r1), ldr1=N, beta1=1.0)
+    check(out, a @ w.t() + bias + r1, what="big-tile gemm + bias + residual")
+    for K1 in (64, 128):  # 1 and 2 K tiles: shorter than the DMA pipeline depth
+        hip.gemm(dev_bf(a[:, :K1].contiguous()), dev_bf(w[:, :K1].contiguous()), out, M=M, N=N, K=K1, C1=K1)
+        check(out, a[:, :K1] @ w[:, :K1].t(), what=f"big-tile gemm K={K1}")
+    Cn, Mg = 64, 24576 + 130
+    x = bf(rnd(Mg, Cn, seed=6))
+    wg, bg = rnd(8 * Cn, Cn, seed=7) / math.sqrt(Cn), rnd(8 * Cn, seed=8)
+    wp, bp, _ = pack_geglu(wg, bg)
+    og = torch.empty(Mg, 4 * Cn, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(x), dev_bf(wp), og, M=Mg, N=wp.shape[0], K=Cn, C1=Cn, bias=dev_f(bp), epilogue=H.EPI_GEGLU, n_out=4 * Cn)
+    hh = x @ bf(wg).t() + bg
+    val, gate = hh.chunk(2, dim=-1)
+    check(og, val * F.gelu(gate), what="big-tile geglu")
+
+
+def test_gemm_big_tile_conv_modes(hip):
+    from wiw_amd import hip as H
+
+    n, c, cout, h, w = 24, 64, 320, 32, 64          # M = 49152
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(cout, c, 3, 3, seed=2) / math.sqrt(9 * c))
+    b = rnd(cout, seed=3)
+    wk = dev_bf(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+    xt = dev_bf(nhwc(x))
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(xt, wk, out, M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+    check(from_nhwc(out, n, h, w), F.conv2d(x, wt, b, padding=1), what="big-tile conv3x3")
+    # temporal taps: B=4, T=6
+    wtt = bf(rnd(cout, c, 3, 1, 1, seed=4) / math.sqrt(3 * c))
+    wkt = dev_bf(wtt[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, -1))
+    hip.gemm(xt, wkt, out, M=M, N=cout, K=3 * c, C1=c, mode=H.A_CONV_T3, H=h, Wd=w, T=6, bias=dev_f(b))
+    x5 = x.reshape(4, 6, c, h, w).permute(0, 2, 1, 3, 4)
+    ref = F.conv3d(x5, wtt, b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(n, cout, h, w)
+    check(from_nhwc(out, n, h, w), ref, what="big-tile temporal conv")
+    # nearest-up + conv from a quarter-size input, and stride 2 from a 4x input
+    xs = bf(rnd(n, c, h // 2, w // 2, seed=5))
+    hip.gemm(dev_bf(nhwc(xs)), wk, out, M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3_UP, H=h, Wd=w, bias=dev_f(b))
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    check(from_nhwc(out, n, h, w), ref, what="big-tile up-conv")
+    xl = bf(rnd(6, c, 2 * h, 2 * w * 2, seed=6))     # 6 frames of 64 x 256 -> output 32 x 128, M = 24576 ... x 2 N tiles
+    Mo = 6 * h * (2 * w)
+    o2 = torch.empty(Mo, 640, dtype=torch.bfloat16, device=DEV)
+    wt2 = bf(rnd(640, c, 3, 3, seed=7) / math.sqrt(9 * c))
+    hip.gemm(dev_bf(nhwc(xl)), dev_bf(wt2.permute(0, 2, 3, 1).reshape(640, -1)), o2, M=Mo, N=640, K=9 * c, C1=c,
+             mode=H.A_CONV3X3_S2, H=h, Wd=2 * w)
+    check(from_nhwc(o2, 6, h, 2 * w), F.conv2d(xl, wt2, None, stride=2, padding=1), what="big-tile stride-2 conv")

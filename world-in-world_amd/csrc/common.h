@@ -13,12 +13,14 @@ typedef uint16_t bf16_t;
 #define WIW_DEV __device__ __forceinline__
 
 WIW_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-WIW_DEV uint16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite on this path)
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// float -> bf16, round-to-nearest-even, on the native gfx950 converter (v_cvt_pk_bf16_f32: 2 values/instr)
+typedef __bf16 wiw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wiw_f32x2 __attribute__((ext_vector_type(2)));
+WIW_DEV uint32_t pack2bf(float lo, float hi) {
+    const wiw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wiw_bf16x2));
 }
-WIW_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+WIW_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); }
 WIW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-erf GELU (activations.py:109 `F.gelu`), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e.
 // fp32-roundoff class): 1 rcp + 1 exp + 6 fma instead of libm erff's ~40 instructions — the GEGLU

@@ -2,32 +2,34 @@
 //
 //   acc[m][n] = sum_k Agather[m][k] * W[n][k]      (both operands K-contiguous: "A . B^T")
 //
-// Design (DESIGN.md §kernels/gemm):
-//   * block tile 128 (M) x 160 (N) x 64 (K), 256 threads = 4 waves as 2x2, each wave 64x80 =
-//     4x5 fragments of v_mfma_f32_16x16x32_bf16 (80 fp32 accumulator VGPRs/lane).  BN = 160 because
-//     every channel count of the served UNet is a multiple of 320, so no N tile is wasted.
-//   * operands go HBM -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip), two
-//     stages (2 x 36 KiB), one barrier per K tile; the implicit-GEMM gather (3x3 / stride-2 /
-//     nearest-upsample / temporal taps, zero padding) is done on the per-lane SOURCE address —
-//     padding taps read a 16-byte zero buffer.
+// Design (DESIGN.md §3.1):
+//   * two tile configurations of one kernel template:
+//       BIG   : 256 (M) x 160 (N) x 64 (K), 512 threads = 8 waves as 4x2, 3-stage LDS ring (156 KiB,
+//               one block per CU), two K tiles of LDS-DMA in flight behind the MFMAs (counted vmcnt);
+//       SMALL : 128 x 160 x 64, 256 threads = 4 waves as 2x2, 2 stages (72 KiB, two blocks per CU) —
+//               used when M is small (L3 / embeddings) so the grid still covers the 256 CUs.
+//     Each wave owns 64x80 = 4x5 fragments of v_mfma_f32_16x16x32_bf16 (80 fp32 accumulator
+//     VGPRs/lane).  BN = 160 because every channel count of the served UNet is a multiple of 320.
+//   * operands go HBM -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip); ONE raw
+//     s_barrier per K tile; waits are counted (`s_waitcnt vmcnt(N)`, never a drain while a later tile
+//     is still needed in flight).  The implicit-GEMM gather (3x3 / stride-2 / nearest-upsample /
+//     temporal taps, zero padding) is done on the per-lane SOURCE address — padding taps read a
+//     16-byte zero buffer.
 //   * LDS image: row r = 128 B (64 bf16); the 16-byte chunk c of row r is stored at chunk position
 //     c ^ (r & 7).  With LDS-DMA the destination is lane-linear, so the swizzle is applied to the
 //     source chunk each lane fetches and again on the ds_read_b128 — conflict-free fragment reads.
-//   * epilogue: accumulators are staged through LDS (64 rows at a time) so that bias / per-frame
-//     vector / residual reads and the bf16 store are 16 B per lane on full rows; GEGLU pairs
-//     column c with column c+80 of the same tile (weights are packed that way on the host).
+//   * epilogue: accumulators are staged through LDS so that bias / per-frame vector / residual reads
+//     and the bf16 store are 16 B per lane on full rows; GEGLU pairs column c with column c+80 of the
+//     same tile (weights are packed that way on the host).
 //   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous
 //     range of tiles, N fastest, so an XCD's resident blocks share A and W panels in its L2.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 160, BK = 64;
-constexpr int A_BYTES = BM * BK * 2;              // 16384
+constexpr int BN = 160, BK = 64;
 constexpr int B_BYTES = BN * BK * 2;              // 20480
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;    // 36864
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 73728  (2 blocks / CU)
-constexpr int EP_LD = 164;                        // fp32 staging row stride (64 x 164 x 4 = 41984 B)
+constexpr int EP_LD = 164;                        // fp32 staging row stride
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -36,8 +38,17 @@ WIW_DEV void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
+template <int MODE, int WM_, int STAGES>
+__global__ __launch_bounds__(WM_ * 128, 2) void gemm_kernel(const WiwGemmArgs p) {
+    constexpr int BM = WM_ * 64;
+    constexpr int NW = WM_ * 2;                       // waves per block
+    constexpr int NT = NW * 64;                       // threads per block
+    constexpr int A_BYTES = BM * BK * 2;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int B_FULL = 20 / NW;                   // full (8-row) W DMA instructions per wave
+    constexpr bool B_HALF = (20 % NW) != 0;           // plus one 4-row instruction per wave (NW = 8)
+    constexpr int LPT = 4 + B_FULL + (B_HALF ? 1 : 0);  // LDS-DMA instructions per wave per K tile
+    static_assert(B_FULL * NW + (B_HALF ? NW / 2 : 0) == 20, "W tile must be covered exactly");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
     int a_fb[4], a_y[4], a_x[4];   // conv: input-frame base row, output y / x  (mode 4: a_y = t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wave * 32 + i * 8 + rsub;
+        const int m = m0 + (wave * 4 + i) * 8 + rsub;
         a_m[i] = m;
         a_ok[i] = m < p.M;
         a_fb[i] = 0; a_y[i] = 0; a_x[i] = 0;
@@ -81,12 +92,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
             a_y[i] = (m / HW) % p.T;
         }
     }
-    const char* w_row[5];
+    const char* w_row[B_FULL + 1];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        int n = n0 + wave * 40 + i * 8 + rsub;
+    for (int i = 0; i < B_FULL; ++i) {
+        int n = n0 + (wave * B_FULL + i) * 8 + rsub;
         n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
         w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+    }
+    {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
+        const int r_h = B_FULL * NW * 8 + wave * 4 + (rsub & 3);   // tile row; r_h & 7 != rsub for odd waves
+        const int chunk_h = (lane & 7) ^ (r_h & 7);
+        int n = n0 + r_h;
+        n = n < p.N ? n : p.N - 1;
+        w_row[B_FULL] = (const char*)p.W + ((int64_t)n * p.K + chunk_h * 8) * 2;
     }
 
     // address of the 16 bytes lane fetches for A row i, K tile (tap, cc)
@@ -124,11 +142,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
     const int Ctot = p.C1 + p.C2;
     auto issue = [&](int stage, int kt, int tap, int cc) {
         char* sA = smem + stage * STAGE_BYTES + wave * 4 * 1024;
-        char* sB = smem + stage * STAGE_BYTES + A_BYTES + wave * 5 * 1024;
+        char* sB = smem + stage * STAGE_BYTES + A_BYTES + wave * B_FULL * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(a_src(i, tap, cc), sA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) glds16(w_row[i] + (int64_t)kt * (BK * 2), sB + i * 1024);
+        for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)kt * (BK * 2), sB + i * 1024);
+        if (B_HALF) {
+            char* sH = smem + stage * STAGE_BYTES + A_BYTES + B_FULL * NW * 1024 + wave * 512;
+            if (lane < 32) glds16(w_row[B_FULL] + (int64_t)kt * (BK * 2), sH);
+        }
     };
 
     f32x4 acc[4][5];
@@ -157,24 +179,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
         }
     };
 
-    // ---- main loop: stage(t+1) in flight while computing stage(t); one barrier per K tile
+    // ---- main loop: STAGES-1 K tiles of LDS-DMA in flight ahead of the MFMAs; one barrier per K tile.
+    //   iteration kt:  wait(tile kt landed)  ->  barrier  ->  issue(tile kt+D into the stage that
+    //   compute(kt-1) just released)  ->  compute(tile kt).  The barrier orders (a) every wave's DMA
+    //   portion of tile kt before anybody's ds_read of it and (b) everybody's reads of stage (kt-1)
+    //   before it is overwritten.
+    constexpr int D = STAGES - 1;
     const int nk = p.K / BK;
     int tap = 0, cc = 0;
-    issue(0, 0, tap, cc);
-    cc += BK;
-    if (cc == Ctot) { cc = 0; ++tap; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            issue((kt + 1) & 1, kt + 1, tap, cc);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (j < nk) {
+            issue(j, j, tap, cc);
             cc += BK;
             if (cc == Ctot) { cc = 0; ++tap; }
         }
-        compute(kt & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    int st_c = 0, st_i = D % STAGES;   // stage computed / stage issued into
+    for (int kt = 0; kt < nk; ++kt) {
+        if (D == 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + D < nk) {
+            issue(st_i, kt + D, tap, cc);
+            cc += BK;
+            if (cc == Ctot) { cc = 0; ++tap; }
+        }
+        compute(st_c);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are done before it arrives at the next barrier
+        st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
+        st_i = (st_i + 1 == STAGES) ? 0 : st_i + 1;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // ---- epilogue through LDS, 64 rows per pass
     float* st = (float*)smem;
@@ -188,22 +226,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
     const int CH = geglu ? 10 : 20;
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
+    // rows staged per pass: as many 64-row wave bands as fit in the LDS ring
+    constexpr int ROWS_PP = (STAGES * STAGE_BYTES >= 128 * EP_LD * 4) ? 128 : 64;
+    constexpr int PASSES = BM / ROWS_PP;
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < PASSES; ++half) {
         if (half) __syncthreads();
-        if (wm == half) {
+        if ((wm * 64) / ROWS_PP == half) {
+            const int rbase = (wm * 64) % ROWS_PP;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 5; ++ni)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        st[(mi * 16 + fq * 4 + r) * EP_LD + wn * 80 + ni * 16 + frow] = acc[mi][ni][r];
+                        st[(rbase + mi * 16 + fq * 4 + r) * EP_LD + wn * 80 + ni * 16 + frow] = acc[mi][ni][r];
         }
         __syncthreads();
-        for (int item = tid; item < 64 * CH; item += 256) {
+        for (int item = tid; item < ROWS_PP * CH; item += NT) {
             const int row = item / CH, ch = item - row * CH;
-            const int m = m0 + half * 64 + row;
+            const int m = m0 + half * ROWS_PP + row;
             if (m >= p.M) continue;
             const int cl = ch * 8;                             // column inside the tile
             const int ncol = geglu ? tile_n * 80 + cl : n0 + cl;  // output column
@@ -296,20 +338,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const WiwGemmArgs p) {
     }
 }
 
-template <int MODE>
-int launch(hipStream_t s, const WiwGemmArgs& a) {
+template <int MODE, int WM_, int STAGES>
+int launch_cfg(hipStream_t s, const WiwGemmArgs& a) {
+    constexpr int BM = WM_ * 64;
+    constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<MODE, WM_, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM) != hipSuccess) {
             wiw_set_error("hipFuncSetAttribute(gemm) failed");
             return WIW_ELAUNCH;
         }
         attr_set = true;
     }
     const int Mt = (a.M + BM - 1) / BM, Nt = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(Mt * Nt), dim3(256), SMEM_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_kernel<MODE, WM_, STAGES>), dim3(Mt * Nt), dim3(WM_ * 128), SMEM, s, a);
     return wiw_check_launch("wiw_gemm_bf16");
+}
+
+// BIG (256-row, 3-stage, 1 block/CU) unless M is too small to fill the chip or would waste > 10 % more rows
+inline bool use_big_tile(const WiwGemmArgs& a) {
+    const int64_t Nt = (a.N + BN - 1) / BN;
+    const int64_t mt256 = (a.M + 255) / 256, mt128 = (a.M + 127) / 128;
+    if (mt256 * Nt < 384) return false;
+    return (double)(mt256 * 256) <= 1.1 * (double)(mt128 * 128);
+}
+
+template <int MODE>
+int launch(hipStream_t s, const WiwGemmArgs& a) {
+    return use_big_tile(a) ? launch_cfg<MODE, 4, 3>(s, a) : launch_cfg<MODE, 2, 2>(s, a);
 }
 
 }  // namespace
