@@ -3,33 +3,41 @@
 //   acc[m][n] = sum_k Agather[m][k] * W[n][k]      (both operands K-contiguous: "A . B^T")
 //
 // Design:
+//   * PERSISTENT blocks: one block per CU (BIG) walks a contiguous range of output tiles, N fastest.
+//     The LDS-DMA stream never drains at a tile boundary: the first K tiles of the NEXT output tile are
+//     already in flight while the waves run the epilogue of the current one.
 //   * two tile configurations of one kernel template:
-//       BIG   : 256 (M) x 160 (N) x 64 (K), 512 threads = 8 waves as 4x2, 3-stage LDS ring (156 KiB,
-//               one block per CU), two K tiles of LDS-DMA in flight behind the MFMAs (counted vmcnt);
-//       SMALL : 128 x 160 x 64, 256 threads = 4 waves as 2x2, 2 stages (72 KiB, two blocks per CU) —
-//               used when M is small (L3 / embeddings) so the grid still covers the 256 CUs.
-//     Each wave owns 64x80 = 4x5 fragments of v_mfma_f32_16x16x32_bf16 (80 fp32 accumulator
-//     VGPRs/lane).  BN = 160 because every channel count of the served UNet is a multiple of 320.
+//       BIG   : 256 (M) x 160 (N) x 64 (K), 512 threads = 8 waves, 3-stage LDS ring (156 KiB), two K
+//               tiles of DMA in flight behind the MFMAs (counted vmcnt);
+//       SMALL : 128 x 160 x 64, 4 waves, 2 stages (72 KiB, two blocks per CU) for small M.
+//     Every wave owns 32 rows x ALL 160 columns = 2 x 10 fragments of v_mfma_f32_16x16x32_bf16
+//     (80 fp32 accumulator VGPRs/lane), so the GEGLU value/gate pair of a column lives in ONE lane.
+//     BN = 160 because every channel count of the served UNet is a multiple of 320.
+//   * MFMA operands are swapped (D = W_frag x A_frag): a lane then holds 4 CONSECUTIVE output columns of
+//     one row, so the epilogue packs 4 bf16 per LDS write / 16 B per global store.
 //   * operands go HBM -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip); ONE raw
-//     s_barrier per K tile; waits are counted (`s_waitcnt vmcnt(N)`, never a drain while a later tile
-//     is still needed in flight).  The implicit-GEMM gather (3x3 / stride-2 / nearest-upsample /
-//     temporal taps, zero padding) is done on the per-lane SOURCE address — padding taps read a
-//     16-byte zero buffer.
+//     s_barrier per K tile; waits are counted.  The implicit-GEMM gather (3x3 / stride-2 /
+//     nearest-upsample / temporal taps, zero padding) is done on the per-lane SOURCE address — padding
+//     taps read a 16-byte zero buffer.
 //   * LDS image: row r = 128 B (64 bf16); the 16-byte chunk c of row r is stored at chunk position
-//     c ^ (r & 7).  With LDS-DMA the destination is lane-linear, so the swizzle is applied to the
-//     source chunk each lane fetches and again on the ds_read_b128 — conflict-free fragment reads.
-//   * epilogue: accumulators are staged through LDS so that bias / per-frame vector / residual reads
-//     and the bf16 store are 16 B per lane on full rows; GEGLU pairs column c with column c+80 of the
-//     same tile (weights are packed that way on the host).
-//   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous
-//     range of tiles, N fastest, so an XCD's resident blocks share A and W panels in its L2.
+//     c ^ (r & 7) (swizzle on the DMA source chunk and again on the ds_read_b128: conflict-free).
+//   * epilogue is PER WAVE and barrier-free: alpha*acc (or the GEGLU product) goes as bf16 through a
+//     5 KiB per-wave LDS transpose (in the ring stage no DMA is targeting), then each lane owns 8
+//     consecutive columns of a row: + alpha*(bias + per-frame vector) + residuals, 16-byte stores.
+//     All global loads of the epilogue are issued before the LDS transpose so their latency overlaps it.
+//   * tile order is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous range of tiles.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BN = 160, BK = 64;
 constexpr int B_BYTES = BN * BK * 2;              // 20480
-constexpr int EP_LD = 164;                        // fp32 staging row stride
+constexpr int STG_ROWB = 336;                     // bytes per staged bf16 row (160 cols + 16 B skew)
+constexpr int STG_WAVE = 16 * STG_ROWB;           // 5376 B per wave (16 rows at a time)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -37,77 +45,99 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 WIW_DEV void glds16(const char* g, char* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
+// Sink for the epilogue stores / loads of lanes that own no valid output element: every epilogue VMEM
+// instruction is then executed by every wave unconditionally, which makes the number of stores queued behind the
+// prefetched LDS-DMA a compile-time constant (needed for the counted vmcnt waits below).
+__device__ uint4 g_dump[512 * 64];
 
-template <int MODE, int WM_, int STAGES>
-__global__ __launch_bounds__(WM_ * 128, 2) void gemm_kernel(const WiwGemmArgs p) {
-    constexpr int BM = WM_ * 64;
-    constexpr int NW = WM_ * 2;                       // waves per block
-    constexpr int NT = NW * 64;                       // threads per block
+template <int N>
+WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+WIW_DEV void wave_lds_sync() {   // order this wave's LDS writes before its following LDS reads (and vice versa)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE, int NW, int STAGES, bool GE>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
+    constexpr int BM = NW * 32;
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int B_FULL = 20 / NW;                   // full (8-row) W DMA instructions per wave
     constexpr bool B_HALF = (20 % NW) != 0;           // plus one 4-row instruction per wave (NW = 8)
     constexpr int LPT = 4 + B_FULL + (B_HALF ? 1 : 0);  // LDS-DMA instructions per wave per K tile
+    constexpr int D = STAGES - 1;                     // K tiles in flight ahead of the MFMAs
     static_assert(B_FULL * NW + (B_HALF ? NW / 2 : 0) == 20, "W tile must be covered exactly");
+    static_assert(NW * STG_WAVE <= STAGE_BYTES, "per-wave epilogue staging must fit in one ring stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
 
-    // ---- XCD-aware tile mapping (bijective for any grid size)
+    // ---- this block's contiguous tile range (XCD-aware: block b runs on XCD b % 8)
     const int Nt = (p.N + BN - 1) / BN;
-    const int nb = gridDim.x;
-    int bid = blockIdx.x;
+    const int Mt = (p.M + BM - 1) / BM;
+    const int total = Mt * Nt;
+    int t, t_end;
     {
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        t = (int)(((int64_t)lb * total) / nb);
+        t_end = (int)(((int64_t)(lb + 1) * total) / nb);
     }
-    const int tile_n = bid % Nt, tile_m = bid / Nt;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    if (t >= t_end) return;
 
-    // ---- per-thread source rows.  One wave instruction of global_load_lds moves 8 rows x 128 B.
-    const int rsub = lane >> 3;                       // row inside the 8-row group
+    // ---- loader state (per-thread source rows of the tile being fetched)
+    const int rsub = lane >> 3;                       // row inside the 8-row group of one DMA instruction
     const int chunk = (lane & 7) ^ (rsub & 7);        // logical 16-B chunk fetched into position lane&7
     const char* const Ab = (const char*)p.A;
     const char* const A2b = (const char*)p.A2;
     const char* const zeros = (const char*)p.zeros;
     const int HW = p.H * p.Wd;
+    const int Ctot = p.C1 + p.C2;
+    const int nk = p.K / BK;
 
-    int a_m[4];          // global output row
+    int a_m[4];
     bool a_ok[4];
-    int a_fb[4], a_y[4], a_x[4];   // conv: input-frame base row, output y / x  (mode 4: a_y = t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (wave * 4 + i) * 8 + rsub;
-        a_m[i] = m;
-        a_ok[i] = m < p.M;
-        a_fb[i] = 0; a_y[i] = 0; a_x[i] = 0;
-        if (MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_UP) {
-            const int n = m / HW, rem = m - n * HW;
-            a_y[i] = rem / p.Wd;
-            a_x[i] = rem - a_y[i] * p.Wd;
-            a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW : (MODE == WIW_A_CONV3X3_S2 ? n * HW * 4 : n * (HW >> 2));
-        } else if (MODE == WIW_A_CONV_T3) {
-            a_y[i] = (m / HW) % p.T;
-        }
-    }
+    int a_fb[4], a_y[4], a_x[4];   // conv: input-frame base row, output y / x  (temporal: a_y = t)
     const char* w_row[B_FULL + 1];
-#pragma unroll
-    for (int i = 0; i < B_FULL; ++i) {
-        int n = n0 + (wave * B_FULL + i) * 8 + rsub;
-        n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
-        w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
-    }
-    {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
-        const int r_h = B_FULL * NW * 8 + wave * 4 + (rsub & 3);   // tile row; r_h & 7 != rsub for odd waves
-        const int chunk_h = (lane & 7) ^ (r_h & 7);
-        int n = n0 + r_h;
-        n = n < p.N ? n : p.N - 1;
-        w_row[B_FULL] = (const char*)p.W + ((int64_t)n * p.K + chunk_h * 8) * 2;
-    }
+    int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
-    // address of the 16 bytes lane fetches for A row i, K tile (tap, cc)
+    auto setup_loader = [&](int tile) {
+        const int m0 = (tile / Nt) * BM, n0 = (tile % Nt) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (wave * 4 + i) * 8 + rsub;
+            a_m[i] = m;
+            a_ok[i] = m < p.M;
+            a_fb[i] = 0; a_y[i] = 0; a_x[i] = 0;
+            if (MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_UP) {
+                const int n = m / HW, rem = m - n * HW;
+                a_y[i] = rem / p.Wd;
+                a_x[i] = rem - a_y[i] * p.Wd;
+                a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW : (MODE == WIW_A_CONV3X3_S2 ? n * HW * 4 : n * (HW >> 2));
+            } else if (MODE == WIW_A_CONV_T3) {
+                a_y[i] = (m / HW) % p.T;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_FULL; ++i) {
+            int n = n0 + (wave * B_FULL + i) * 8 + rsub;
+            n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
+            w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+        }
+        {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
+            const int r_h = B_FULL * NW * 8 + wave * 4 + (rsub & 3);   // r_h & 7 != rsub for odd waves
+            const int chunk_h = (lane & 7) ^ (r_h & 7);
+            int n = n0 + r_h;
+            n = n < p.N ? n : p.N - 1;
+            w_row[B_FULL] = (const char*)p.W + ((int64_t)n * p.K + chunk_h * 8) * 2;
+        }
+    };
+
+    // address of the 16 bytes this lane fetches for A row i of K tile (tap, cc)
     auto a_src = [&](int i, int tap, int cc) -> const char* {
         if (MODE == WIW_A_DENSE) {
             if (!a_ok[i]) return zeros;
@@ -139,220 +169,326 @@ __global__ __launch_bounds__(WM_ * 128, 2) void gemm_kernel(const WiwGemmArgs p)
         }
     };
 
-    const int Ctot = p.C1 + p.C2;
-    auto issue = [&](int stage, int kt, int tap, int cc) {
+    // issue the DMA of the loader's next K tile into ring stage `stage`
+    auto issue_next = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES + wave * 4 * 1024;
         char* sB = smem + stage * STAGE_BYTES + A_BYTES + wave * B_FULL * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src(i, tap, cc), sA + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16(a_src(i, ld_tap, ld_cc), sA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)kt * (BK * 2), sB + i * 1024);
+        for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * (BK * 2), sB + i * 1024);
         if (B_HALF) {
             char* sH = smem + stage * STAGE_BYTES + A_BYTES + B_FULL * NW * 1024 + wave * 512;
-            if (lane < 32) glds16(w_row[B_FULL] + (int64_t)kt * (BK * 2), sH);
+            if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * (BK * 2), sH);
         }
+        ++ld_kt;
+        ld_cc += BK;
+        if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
     };
 
-    f32x4 acc[4][5];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 5; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fq = lane >> 4;
+    f32x4 acc[2][10];
     auto compute = [&](int stage) {
-        const char* sA = smem + stage * STAGE_BYTES + (wm * 64 + frow) * 128;
-        const char* sB = smem + stage * STAGE_BYTES + A_BYTES + (wn * 80 + frow) * 128;
+        const char* sA = smem + stage * STAGE_BYTES + (wave * 32 + frow) * 128;
+        const char* sB = smem + stage * STAGE_BYTES + A_BYTES + frow * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
-            bf16x8 a[4], b[5];
+            bf16x8 a[2], b[10];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *(const bf16x8*)(sA + mi * 2048 + sw);
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8*)(sA + mi * 2048 + sw);
 #pragma unroll
-            for (int ni = 0; ni < 5; ++ni) b[ni] = *(const bf16x8*)(sB + ni * 2048 + sw);
+            for (int ni = 0; ni < 10; ++ni) b[ni] = *(const bf16x8*)(sB + ni * 2048 + sw);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < 10; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < 5; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < 2; ++mi)   // swapped operands: lane gets n = 16*ni + 4*fq + r, m = 16*mi + frow
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
         }
     };
 
-    // ---- main loop: STAGES-1 K tiles of LDS-DMA in flight ahead of the MFMAs; one barrier per K tile.
-    //   iteration kt:  wait(tile kt landed)  ->  barrier  ->  issue(tile kt+D into the stage that
-    //   compute(kt-1) just released)  ->  compute(tile kt).  The barrier orders (a) every wave's DMA
-    //   portion of tile kt before anybody's ds_read of it and (b) everybody's reads of stage (kt-1)
-    //   before it is overwritten.
-    constexpr int D = STAGES - 1;
-    const int nk = p.K / BK;
-    int tap = 0, cc = 0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        if (j < nk) {
-            issue(j, j, tap, cc);
-            cc += BK;
-            if (cc == Ctot) { cc = 0; ++tap; }
-        }
-    }
-    int st_c = 0, st_i = D % STAGES;   // stage computed / stage issued into
-    for (int kt = 0; kt < nk; ++kt) {
-        if (D == 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + D < nk) {
-            issue(st_i, kt + D, tap, cc);
-            cc += BK;
-            if (cc == Ctot) { cc = 0; ++tap; }
-        }
-        compute(st_c);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads are done before it arrives at the next barrier
-        st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
-        st_i = (st_i + 1 == STAGES) ? 0 : st_i + 1;
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // ---- epilogue through LDS, 64 rows per pass
-    float* st = (float*)smem;
-    const bool geglu = (p.epilogue & WIW_EPI_GEGLU) != 0;
+    constexpr bool geglu = GE;   // compile-time: keeps the GEGLU-only / residual-only epilogue registers apart
     const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
     const bool out_f32 = (p.epilogue & WIW_EPI_OUT_F32) != 0;
     const int n_valid = geglu ? p.n_out : p.N;
-    const bool vec_ok = (n_valid % 8 == 0) && (p.ldo % 8 == 0) && (p.res1 == nullptr || p.ldr1 % 8 == 0) &&
-                        (p.res2 == nullptr || p.ldr2 % 8 == 0);
-    const bool vec_rv = (((uintptr_t)p.bias | (uintptr_t)p.rowvec) & 15) == 0 && (p.rowvec_ld % 4 == 0);
-    const int CH = geglu ? 10 : 20;
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
-    // rows staged per pass: as many 64-row wave bands as fit in the LDS ring
-    constexpr int ROWS_PP = (STAGES * STAGE_BYTES >= 128 * EP_LD * 4) ? 128 : 64;
-    constexpr int PASSES = BM / ROWS_PP;
-#pragma unroll 1
-    for (int half = 0; half < PASSES; ++half) {
-        if (half) __syncthreads();
-        if ((wm * 64) / ROWS_PP == half) {
-            const int rbase = (wm * 64) % ROWS_PP;
+    // staged (fast) epilogue: bf16 output on 16-byte aligned rows; everything else takes the direct path
+    const bool staged = !out_f32 && !do_silu && (n_valid % 8 == 0) && (p.ldo % 8 == 0) &&
+                        (r1 == nullptr || p.ldr1 % 8 == 0) && (r2 == nullptr || p.ldr2 % 8 == 0) &&
+                        ((((uintptr_t)p.bias | (uintptr_t)p.rowvec) & 15) == 0) && (p.rowvec_ld % 4 == 0);
+
+    // ---- prologue: first D K tiles of the first output tile
+    setup_loader(t);
+    ld_tap = 0; ld_cc = 0; ld_kt = 0;
+    int st_c = 0;   // ring stage holding the K tile the MFMAs consume next
+    int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 6 / 12)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+    for (int j = 0; j < D; ++j)
+        if (j < nk) issue_next(j);
+
+    for (; t < t_end; ++t) {
+        const int tile_n = t % Nt;
+        const int m0 = (t / Nt) * BM, n0 = tile_n * BN;
+        setup_loader(t);   // recomputed (not kept live across the previous epilogue: VGPR budget); counters ld_* persist
 #pragma unroll
-                for (int ni = 0; ni < 5; ++ni)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        st[(rbase + mi * 16 + fq * 4 + r) * EP_LD + wn * 80 + ni * 16 + frow] = acc[mi][ni][r];
-        }
-        __syncthreads();
-        for (int item = tid; item < ROWS_PP * CH; item += NT) {
-            const int row = item / CH, ch = item - row * CH;
-            const int m = m0 + half * ROWS_PP + row;
-            if (m >= p.M) continue;
-            const int cl = ch * 8;                             // column inside the tile
-            const int ncol = geglu ? tile_n * 80 + cl : n0 + cl;  // output column
-            if (ncol >= n_valid) continue;
-            float v[8];
-            {
-                const float4 t0 = *(const float4*)(st + row * EP_LD + cl);
-                const float4 t1 = *(const float4*)(st + row * EP_LD + cl + 4);
-                v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w;
-                v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-            }
-            if (geglu) {
-                float g[8];
-                const float4 t0 = *(const float4*)(st + row * EP_LD + 80 + cl);
-                const float4 t1 = *(const float4*)(st + row * EP_LD + 80 + cl + 4);
-                g[0] = t0.x; g[1] = t0.y; g[2] = t0.z; g[3] = t0.w;
-                g[4] = t1.x; g[5] = t1.y; g[6] = t1.z; g[7] = t1.w;
-                if (p.bias) {   // packed bias: 16-byte aligned runs of 8 (n0, cl multiples of 8)
-                    const float4 bv0 = *(const float4*)(p.bias + n0 + cl), bv1 = *(const float4*)(p.bias + n0 + cl + 4);
-                    const float4 bg0 = *(const float4*)(p.bias + n0 + 80 + cl), bg1 = *(const float4*)(p.bias + n0 + 80 + cl + 4);
-                    v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w;
-                    v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
-                    g[0] += bg0.x; g[1] += bg0.y; g[2] += bg0.z; g[3] += bg0.w;
-                    g[4] += bg1.x; g[5] += bg1.y; g[6] += bg1.z; g[7] += bg1.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
+            for (int ni = 0; ni < 10; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- main loop.  Iteration kt: wait(tile kt landed) -> barrier -> issue(tile kt+D into the stage
+        // compute(kt-1) released) -> compute(tile kt).  The barrier orders every wave's DMA portion of tile kt
+        // before anybody's ds_read of it, and everybody's reads of the released stage before it is refilled.
+        for (int kt = 0; kt < nk; ++kt) {
+            // vmcnt retires in issue order (loads and stores share the queue on gfx9-class parts), so "K tile kt has
+            // landed" == "at most <ops issued after it> outstanding".  Issued after tile kt's DMA: the DMA of tile kt+1
+            // (BIG only, if it exists) and — for the first D K tiles of a non-first output tile — the previous tile's
+            // epilogue stores (a compile-time count because they are unconditional).  The stores therefore get D K-tile
+            // computes to drain behind the MFMAs instead of stalling the wave at the tile boundary.
+            const bool dma_younger = (D == 2) && (kt + 1 < nk);
+            const int st_younger = (kt < D) ? pending_stores : 0;   // wave-uniform: 0, 6 (GEGLU) or 12
+            if (dma_younger) {
+                if (st_younger == 12) wait_vmcnt<LPT + 12>();
+                else if (st_younger == 6) wait_vmcnt<LPT + 6>();
+                else wait_vmcnt<LPT>();
             } else {
-                const float* rv = p.rowvec ? p.rowvec + (int64_t)(m / p.rows_per_vec) * p.rowvec_ld : nullptr;
-                if (vec_ok && vec_rv) {
-                    if (p.bias) {
-                        const float4 b0 = *(const float4*)(p.bias + ncol), b1 = *(const float4*)(p.bias + ncol + 4);
-                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                    }
-                    if (rv) {
-                        const float4 b0 = *(const float4*)(rv + ncol), b1 = *(const float4*)(rv + ncol + 4);
-                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                if (st_younger == 12) wait_vmcnt<12>();
+                else if (st_younger == 6) wait_vmcnt<6>();
+                else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + D < nk) {
+                int si = st_c + D;
+                si = si >= STAGES ? si - STAGES : si;
+                issue_next(si);
+            }
+            compute(st_c);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired before the next barrier
+            st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
+        }
+        __builtin_amdgcn_s_barrier();   // every wave is done with every ring stage
+        asm volatile("" ::: "memory");
+
+        // ---- epilogue, part 1: issue EVERY global load of the epilogue (bias, per-frame vector, residual) now,
+        // BEFORE the next tile's DMA: waiting for them later then never has to wait for anything younger.
+        // Lane -> output mapping of the row-major store phase: a lane keeps ONE 16-byte column chunk (lch) and
+        // sweeps rows lrow, lrow + RPS, ...; lanes / rows without a valid element read zeros and write g_dump.
+        const bool fast_st = staged && r2 == nullptr;   // counted-wait path (res2 would need loads behind the stores)
+        constexpr int ITEMS_P = 6, ITEMS_G = 3;         // row sweeps per 16-row pass: plain (RPS 3) / GEGLU (RPS 6)
+        constexpr int CHr = GE ? 10 : 20, RPSr = GE ? 6 : 3;
+        const int lch = lane % CHr, lrow = lane / CHr;
+        const int ncol = (geglu ? tile_n * 80 : n0) + lch * 8;
+        const bool lane_ok = lrow < RPSr && ncol < n_valid;
+        const int mw0 = m0 + wave * 32;                  // first row of this wave's 32-row band
+        float4 bvf[10];                                   // GEGLU: bias in fragment layout (value | gate)
+        float4 c0, c1, rv0[2], rv1[2];                    // plain: bias and the per-frame vector row of each 16-row pass
+        uint4 q1[2][ITEMS_P];
+        auto load_rv = [&](auto mi_tag) {
+            constexpr int mi = decltype(mi_tag)::value;
+            const int mr = mw0 + mi * 16;
+            const int vi = (mr < p.M ? mr : p.M - 1) / p.rows_per_vec;
+            const float* pa = lane_ok ? p.rowvec + (int64_t)vi * p.rowvec_ld + ncol : (const float*)zeros;
+            rv0[mi] = *(const float4*)pa;
+            rv1[mi] = *(const float4*)(lane_ok ? pa + 4 : (const float*)zeros);
+        };
+        auto load_q1 = [&](auto mi_tag) {   // residual rows of one 16-row pass (invalid lanes read the zero page)
+            constexpr int mi = decltype(mi_tag)::value;
+#pragma unroll
+            for (int k = 0; k < ITEMS_P; ++k) {
+                const int rr = lrow + k * 3;
+                const int m = mw0 + mi * 16 + rr;
+                const bool ok = lane_ok && rr < 16 && m < p.M;
+                q1[mi][k] = *(const uint4*)(ok ? (const char*)(r1 + (int64_t)m * p.ldr1 + ncol) : zeros);
+            }
+        };
+        c0 = float4{0.f, 0.f, 0.f, 0.f}; c1 = c0; rv0[0] = c0; rv0[1] = c0; rv1[0] = c0; rv1[1] = c0;
+        // per-frame vector: when rows_per_vec is a multiple of 16 every 16-row pass sees ONE vector row
+        const bool rv_fast = p.rowvec != nullptr && (p.rows_per_vec % 16) == 0;
+        if (staged) {
+            if (geglu) {
+                if (p.bias) {
+#pragma unroll
+                    for (int ni = 0; ni < 10; ++ni) bvf[ni] = *(const float4*)(p.bias + n0 + ni * 16 + fq * 4);
+                }
+            } else {
+                const float* zf = (const float*)zeros;
+                if (p.bias) {
+                    const float* bp = lane_ok ? p.bias + ncol : zf;
+                    c0 = *(const float4*)bp; c1 = *(const float4*)(lane_ok ? bp + 4 : zf);
+                }
+                if (rv_fast) load_rv(std::integral_constant<int, 0>{});
+                if (r1) load_q1(std::integral_constant<int, 0>{});
+            }
+        }
+
+        // ---- keep the DMA stream going: first D K tiles of the NEXT output tile -> stages st_c, st_c+1.
+        // Stage (st_c + D) % STAGES is not targeted until the next tile's first barrier: epilogue staging.
+        if (t + 1 < t_end) {
+            setup_loader(t + 1);
+            ld_tap = 0; ld_cc = 0; ld_kt = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                if (j < nk) {
+                    int sj = st_c + j;
+                    sj = sj >= STAGES ? sj - STAGES : sj;
+                    issue_next(sj);
+                }
+            }
+        }
+        int st_e = st_c + D;
+        st_e = st_e >= STAGES ? st_e - STAGES : st_e;
+        pending_stores = 0;
+
+        // ---- epilogue, part 2 (per wave, no block barrier)
+        if (staged) {
+            char* stg = smem + st_e * STAGE_BYTES + wave * STG_WAVE;
+            uint4* dump = g_dump + (blockIdx.x & 511) * 64 + lane;
+            auto half_pass = [&](auto ge_tag, auto mi_tag) {
+                constexpr int mi = decltype(mi_tag)::value;    // compile-time: acc[mi] must stay in registers
+                static_assert(decltype(ge_tag)::value == GE, "");
+                constexpr int RPS = GE ? 6 : 3;                // rows per sweep
+                constexpr int ITEMS = GE ? ITEMS_G : ITEMS_P;
+                const int mrow0 = mw0 + mi * 16;               // first of the 16 rows handled in this pass
+                // (a) fragment layout -> bf16 rows in LDS: lane owns row frow, columns 16*ni + 4*fq .. +3
+                char* wrow = stg + frow * STG_ROWB + fq * 8;
+                if (GE) {
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
+                        if (p.bias) {
+                            v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
+                            g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
+                        }
+                        uint2 pk;
+                        pk.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
+                        pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+                        *(uint2*)(wrow + ni * 32) = pk;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int n = ncol + e;
-                        if (n < n_valid) {
-                            if (p.bias) v[e] += p.bias[n];
-                            if (rv) v[e] += rv[n];
+                    for (int ni = 0; ni < 10; ++ni) {
+                        const f32x4 v = acc[mi][ni];
+                        uint2 pk;
+                        pk.x = pack2bf(v[0] * p.alpha, v[1] * p.alpha);
+                        pk.y = pack2bf(v[2] * p.alpha, v[3] * p.alpha);
+                        *(uint2*)(wrow + ni * 32) = pk;
+                    }
+                }
+                wave_lds_sync();
+                if (!GE && mi == 0) {   // acc[0]'s registers are free now: fetch pass 1's operands behind pass 0's math
+                    if (rv_fast) load_rv(std::integral_constant<int, 1>{});
+                    if (r1) load_q1(std::integral_constant<int, 1>{});
+                }
+                // (b) row-major: 8 consecutive columns per lane, residual / bias math in fp32, 16-byte stores.
+                //     The store is UNCONDITIONAL (invalid lanes hit g_dump) so that exactly ITEMS stores are issued.
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) {
+                    const int rr = lrow + k * RPS;
+                    const int m = mrow0 + rr;
+                    const bool ok = lane_ok && rr < 16 && m < p.M;
+                    const uint4 sv = *(const uint4*)(stg + rr * STG_ROWB + lch * 16);   // rr <= 17 stays inside the stage
+                    uint4 ov = sv;
+                    if (!GE) {
+                        float v[8], f[8];
+                        unpack8(sv, v);
+                        if (p.rowvec && !rv_fast) {      // odd rows_per_vec (tiny shapes): vector row per item
+                            const float* rv = p.rowvec + (int64_t)((ok ? m : 0) / p.rows_per_vec) * p.rowvec_ld + (ok ? ncol : 0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += ok ? p.alpha * rv[e] : 0.f;
+                        }
+                        const float al = p.alpha;
+                        v[0] += al * (c0.x + rv0[mi].x); v[1] += al * (c0.y + rv0[mi].y);
+                        v[2] += al * (c0.z + rv0[mi].z); v[3] += al * (c0.w + rv0[mi].w);
+                        v[4] += al * (c1.x + rv1[mi].x); v[5] += al * (c1.y + rv1[mi].y);
+                        v[6] += al * (c1.z + rv1[mi].z); v[7] += al * (c1.w + rv1[mi].w);
+                        if (r1) {
+                            unpack8(q1[mi][k], f);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += p.beta1 * f[e];
+                        }
+                        if (r2) {   // only the AlphaBlender GEMM: loaded late, this path drains at the next tile
+                            unpack8(*(const uint4*)(ok ? (const char*)(r2 + (int64_t)m * p.ldr2 + ncol) : zeros), f);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += p.beta2 * f[e];
+                        }
+                        ov = pack8(v);
+                    }
+                    uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + ncol) : dump;
+                    *dst = ov;
+                }
+                wave_lds_sync();
+            };
+            half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 0>{});
+            half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 1>{});
+            if (fast_st) pending_stores = geglu ? 2 * ITEMS_G : 2 * ITEMS_P;
+        } else {
+            // direct path (fp32 output, SiLU, unaligned N / strides): element-wise from the fragment layout.
+            // Every index into acc[][] is a compile-time constant (guards instead of break / continue).
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = m0 + wave * 32 + mi * 16 + frow;
+                const bool m_ok = m < p.M;
+                const int mc = m_ok ? m : p.M - 1;
+                const float* rv = p.rowvec ? p.rowvec + (int64_t)(mc / p.rows_per_vec) * p.rowvec_ld : nullptr;
+#pragma unroll
+                for (int ni = 0; ni < 10; ++ni) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = ni * 16 + fq * 4 + r;   // column inside the tile
+                        float y = acc[mi][ni][r];
+                        int n = n0 + c;
+                        bool ok = m_ok;
+                        if (geglu) {
+                            n = tile_n * 80 + c;
+                            ok = ok && ni < 5 && n < n_valid;
+                            if (ok) {
+                                const float bv = p.bias ? p.bias[n0 + c] : 0.f, bg = p.bias ? p.bias[n0 + 80 + c] : 0.f;
+                                y = (y + bv) * gelu_erf_f(acc[mi][ni < 5 ? ni + 5 : ni][r] + bg);
+                            }
+                        } else {
+                            ok = ok && n < n_valid;
+                            if (ok) {
+                                if (p.bias) y += p.bias[n];
+                                if (rv) y += rv[n];
+                                y *= p.alpha;
+                                if (do_silu) y = silu_f(y);
+                                if (r1) y += p.beta1 * bf2f(r1[(int64_t)m * p.ldr1 + n]);
+                                if (r2) y += p.beta2 * bf2f(r2[(int64_t)m * p.ldr2 + n]);
+                            }
+                        }
+                        if (ok) {
+                            if (out_f32) ((float*)p.out)[(int64_t)m * p.ldo + n] = y;
+                            else ((uint16_t*)p.out)[(int64_t)m * p.ldo + n] = f2bf(y);
                         }
                     }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float y = v[e] * p.alpha;
-                    if (do_silu) y = silu_f(y);
-                    v[e] = y;
-                }
-            }
-            if (vec_ok) {
-                if (r1) {
-                    float f[8];
-                    unpack8(*(const uint4*)(r1 + (int64_t)m * p.ldr1 + ncol), f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += p.beta1 * f[e];
-                }
-                if (r2) {
-                    float f[8];
-                    unpack8(*(const uint4*)(r2 + (int64_t)m * p.ldr2 + ncol), f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += p.beta2 * f[e];
-                }
-                if (out_f32) {
-                    float* o = (float*)p.out + (int64_t)m * p.ldo + ncol;
-                    *(float4*)o = float4{v[0], v[1], v[2], v[3]};
-                    *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
-                } else {
-                    *(uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + ncol) = pack8(v);
-                }
-            } else {
-                for (int e = 0; e < 8; ++e) {
-                    const int n = ncol + e;
-                    if (n >= n_valid) break;
-                    float y = v[e];
-                    if (r1) y += p.beta1 * bf2f(r1[(int64_t)m * p.ldr1 + n]);
-                    if (r2) y += p.beta2 * bf2f(r2[(int64_t)m * p.ldr2 + n]);
-                    if (out_f32) ((float*)p.out)[(int64_t)m * p.ldo + n] = y;
-                    else ((uint16_t*)p.out)[(int64_t)m * p.ldo + n] = f2bf(y);
                 }
             }
         }
     }
 }
 
-template <int MODE, int WM_, int STAGES>
-int launch_cfg(hipStream_t s, const WiwGemmArgs& a) {
-    constexpr int BM = WM_ * 64;
+template <int MODE, int NW, int STAGES, bool GE>
+int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
+    constexpr int BM = NW * 32;
     constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES);
     static bool attr_set = false;
+    static int num_cu = 256;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<MODE, WM_, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SMEM) != hipSuccess) {
             wiw_set_error("hipFuncSetAttribute(gemm) failed");
             return WIW_ELAUNCH;
         }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cu = prop.multiProcessorCount;
         attr_set = true;
     }
-    const int Mt = (a.M + BM - 1) / BM, Nt = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kernel<MODE, WM_, STAGES>), dim3(Mt * Nt), dim3(WM_ * 128), SMEM, s, a);
+    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    int64_t grid = (int64_t)num_cu * blocks_per_cu;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a);
     return wiw_check_launch("wiw_gemm_bf16");
 }
 
@@ -366,7 +502,11 @@ inline bool use_big_tile(const WiwGemmArgs& a) {
 
 template <int MODE>
 int launch(hipStream_t s, const WiwGemmArgs& a) {
-    return use_big_tile(a) ? launch_cfg<MODE, 4, 3>(s, a) : launch_cfg<MODE, 2, 2>(s, a);
+    static const char* force = getenv("WIW_GEMM_TILE");   // tuning knob: "big" / "small" overrides the heuristic
+    const bool big = force ? (force[0] == 'b') : use_big_tile(a);
+    if (MODE == WIW_A_DENSE && (a.epilogue & WIW_EPI_GEGLU))
+        return big ? launch_cfg<WIW_A_DENSE, 8, 3, true>(s, a, 1) : launch_cfg<WIW_A_DENSE, 4, 2, true>(s, a, 2);
+    return big ? launch_cfg<MODE, 8, 3, false>(s, a, 1) : launch_cfg<MODE, 4, 2, false>(s, a, 2);
 }
 
 }  // namespace
@@ -393,6 +533,8 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     if (a.epilogue & WIW_EPI_GEGLU) {
         WIW_REQUIRE(a.N % BN == 0 && a.n_out > 0 && a.n_out <= a.N / 2, "gemm: GEGLU needs N % 160 == 0 and n_out");
         WIW_REQUIRE(a.rowvec == nullptr && a.res1 == nullptr && a.res2 == nullptr, "gemm: GEGLU takes bias only");
+        WIW_REQUIRE((((uintptr_t)a.bias) & 15) == 0, "gemm: GEGLU bias must be 16-byte aligned");
+        WIW_REQUIRE(a.mode == WIW_A_DENSE, "gemm: GEGLU only in dense mode");
     }
     hipStream_t s = (hipStream_t)stream;
     switch (a.mode) {
