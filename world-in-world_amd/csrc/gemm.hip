@@ -187,24 +187,37 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     };
 
     f32x4 acc[2][10];
-    auto compute = [&](int stage) {
-        const char* sA = smem + stage * STAGE_BYTES + (wave * 32 + frow) * 128;
-        const char* sB = smem + stage * STAGE_BYTES + A_BYTES + frow * 128;
+    // Fragment registers of ONE 32-deep k-step: filled in a wave's "read" slot, consumed in its "MFMA" slot.
+    // Every wave runs  R(kk=0) | M | R(kk=1) | M  per K tile with a barrier between slots; the second wave group
+    // (waves NW/2..NW-1, one per SIMD next to a wave of the first group) runs ONE SLOT BEHIND, so on every SIMD one
+    // wave streams ds_read_b128 (and issues the DMA) while the other issues 20 MFMAs back to back.
+    bf16x8 fa[2], fb[10];
+    auto read_frags = [&](int stage, int kk) {
+        const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
+        const char* sA = smem + stage * STAGE_BYTES + (wave * 32 + frow) * 128 + sw;
+        const char* sB = smem + stage * STAGE_BYTES + A_BYTES + frow * 128 + sw;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
-            bf16x8 a[2], b[10];
+        for (int mi = 0; mi < 2; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 2048);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8*)(sA + mi * 2048 + sw);
-#pragma unroll
-            for (int ni = 0; ni < 10; ++ni) b[ni] = *(const bf16x8*)(sB + ni * 2048 + sw);
-#pragma unroll
-            for (int ni = 0; ni < 10; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)   // swapped operands: lane gets n = 16*ni + 4*fq + r, m = 16*mi + frow
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
-        }
+        for (int ni = 0; ni < 10; ++ni) fb[ni] = *(const bf16x8*)(sB + ni * 2048);
     };
+    auto mma = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 10; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)   // swapped operands: lane gets n = 16*ni + 4*fq + r, m = 16*mi + frow
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_barrier = [&]() {   // close a slot: this wave's LDS reads are retired, then rendezvous
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const bool lag = wave >= NW / 2;   // wave-uniform: second wave group
 
     constexpr bool geglu = GE;   // compile-time: keeps the GEGLU-only / residual-only epilogue registers apart
     const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
@@ -235,17 +248,20 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
 #pragma unroll
             for (int ni = 0; ni < 10; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // ---- main loop.  Iteration kt: wait(tile kt landed) -> barrier -> issue(tile kt+D into the stage
-        // compute(kt-1) released) -> compute(tile kt).  The barrier orders every wave's DMA portion of tile kt
-        // before anybody's ds_read of it, and everybody's reads of the released stage before it is refilled.
-        for (int kt = 0; kt < nk; ++kt) {
-            // vmcnt retires in issue order (loads and stores share the queue on gfx9-class parts), so "K tile kt has
-            // landed" == "at most <ops issued after it> outstanding".  Issued after tile kt's DMA: the DMA of tile kt+1
-            // (BIG only, if it exists) and — for the first D K tiles of a non-first output tile — the previous tile's
-            // epilogue stores (a compile-time count because they are unconditional).  The stores therefore get D K-tile
-            // computes to drain behind the MFMAs instead of stalling the wave at the tile boundary.
-            const bool dma_younger = (D == 2) && (kt + 1 < nk);
-            const int st_younger = (kt < D) ? pending_stores : 0;   // wave-uniform: 0, 6 (GEGLU) or 12
+        // ---- main loop.  Local slots of K tile kt:  [4kt] issue DMA(kt+D), R(kt,0)  [4kt+1] M  [4kt+2] R(kt,1),
+        // wait(tile kt+1)  [4kt+3] M.   The lagging group executes one extra barrier before its first slot and the
+        // leading group one after its last, so a lagging wave's local barrier b is the leading waves' barrier b+1:
+        //   * DMA into the stage of tile kt-1 is issued after local barrier 4kt; by then the other group has passed
+        //     its barrier 4kt-1, i.e. finished R(kt-1,1) — the last read of that stage;
+        //   * tile j is first read in local slot 4j of the LEADING group = barrier 4j-1 of the lagging group, so
+        //     every wave confirms "my DMA portion of tile j landed" before its local barrier 4j-1 (end of slot 4j-2).
+        // vmcnt retires in issue order (loads and stores share the queue on gfx9-class parts): "tile j landed" ==
+        // "at most <ops issued after it> outstanding" = the DMA of tile j+1 (BIG) plus, for the first D tiles of a
+        // non-first output tile, the previous epilogue's stores (compile-time count: they are unconditional) — the
+        // stores drain behind the MFMAs instead of stalling the wave at the tile boundary.
+        auto wait_tile = [&](int j) {   // wait until this wave's DMA portion of K tile j has landed
+            const bool dma_younger = (D == 2) && (j + 1 < nk);
+            const int st_younger = (j < D) ? pending_stores : 0;   // wave-uniform: 0, 6 (GEGLU) or 12
             if (dma_younger) {
                 if (st_younger == 12) wait_vmcnt<LPT + 12>();
                 else if (st_younger == 6) wait_vmcnt<LPT + 6>();
@@ -255,19 +271,53 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                 else if (st_younger == 6) wait_vmcnt<6>();
                 else wait_vmcnt<0>();
             }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + D < nk) {
-                int si = st_c + D;
-                si = si >= STAGES ? si - STAGES : si;
-                issue_next(si);
+        };
+        wait_tile(0);
+        if (NW == 8) {
+            if (lag) slot_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                slot_barrier();                                  // local barrier 4kt
+                if (kt + D < nk) {
+                    int si = st_c + D;
+                    si = si >= STAGES ? si - STAGES : si;
+                    issue_next(si);
+                }
+                read_frags(st_c, 0);
+                slot_barrier();                                  // 4kt+1
+                mma();
+                slot_barrier();                                  // 4kt+2
+                read_frags(st_c, 1);
+                if (kt + 1 < nk) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_tile(kt + 1);
+                }
+                slot_barrier();                                  // 4kt+3
+                mma();
+                st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
             }
-            compute(st_c);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads retired before the next barrier
-            st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
+            if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
+        } else {
+            // SMALL (4 waves, one per SIMD, two blocks per CU): the co-resident block provides the overlap; one
+            // barrier per K tile, both k-steps back to back
+            for (int kt = 0; kt < nk; ++kt) {
+                slot_barrier();
+                if (kt + D < nk) {
+                    int si = st_c + D;
+                    si = si >= STAGES ? si - STAGES : si;
+                    issue_next(si);
+                }
+                read_frags(st_c, 0);
+                mma();
+                read_frags(st_c, 1);
+                mma();
+                if (kt + 1 < nk) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_tile(kt + 1);
+                }
+                st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
+            }
+            slot_barrier();             // every wave is done reading the ring
         }
-        __builtin_amdgcn_s_barrier();   // every wave is done with every ring stage
-        asm volatile("" ::: "memory");
 
         // ---- epilogue, part 1: issue EVERY global load of the epilogue (bias, per-frame vector, residual) now,
         // BEFORE the next tile's DMA: waiting for them later then never has to wait for anything younger.
