@@ -108,31 +108,37 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 s[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[f][1], z, 0, 0, 0);
             }
         }
-        // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag
-        const bool tail = (kt + 1) * KB > S;
+        // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag.
+        // Scores stay unscaled: p = exp2(s*c - m) with c = log2(e)/sqrt(d) folded into one FMA; the running max
+        // m is kept in the scaled domain.  v_exp_f32 is used raw (arguments <= 0; denormal results flush to 0).
+        if ((kt + 1) * KB > S) {   // wave-uniform: only the last, partial tile masks keys >= S
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * KB + kf * 16 + fq * 4 + r >= S) s[kf][f][r] = -INFINITY;
+        }
         uint32_t pb[2][2][4];   // [query frag][key step][4 dwords] = packed bf16x8 B operands
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            float mx = -INFINITY;
+            float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
 #pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kf][f][r] * scale_log2e;
-                    if (tail && (kt * KB + kf * 16 + fq * 4 + r) >= S) v = -INFINITY;
-                    s[kf][f][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+            for (int kf = 1; kf < 4; ++kf)
+                mx = fmaxf(fmaxf(mx, fmaxf(s[kf][f][0], s[kf][f][1])), fmaxf(s[kf][f][2], s[kf][f][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[f], mx);
-            const float alpha = exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
+            const float m_new = fmaxf(m_run[f], mx * scale_log2e);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
             m_run[f] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
-                float p0 = exp2f(s[kf][f][0] - m_new), p1 = exp2f(s[kf][f][1] - m_new);
-                float p2 = exp2f(s[kf][f][2] - m_new), p3 = exp2f(s[kf][f][3] - m_new);
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][0], scale_log2e, -m_new));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][1], scale_log2e, -m_new));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][2], scale_log2e, -m_new));
+                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][3], scale_log2e, -m_new));
                 ps += (p0 + p1) + (p2 + p3);
                 pb[f][kf >> 1][(kf & 1) * 2 + 0] = pack2bf(p0, p1);
                 pb[f][kf >> 1][(kf & 1) * 2 + 1] = pack2bf(p2, p3);

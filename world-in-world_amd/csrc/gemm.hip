@@ -221,6 +221,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
 
     constexpr bool geglu = GE;   // compile-time: keeps the GEGLU-only / residual-only epilogue registers apart
     const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
+    const bool scale_acc = p.alpha != 1.0f;   // wave-uniform: most GEMMs skip the alpha multiply
     const bool out_f32 = (p.epilogue & WIW_EPI_OUT_F32) != 0;
     const int n_valid = geglu ? p.n_out : p.N;
     const uint16_t* r1 = (const uint16_t*)p.res1;
@@ -417,10 +418,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                 } else {
 #pragma unroll
                     for (int ni = 0; ni < 10; ++ni) {
-                        const f32x4 v = acc[mi][ni];
+                        f32x4 v = acc[mi][ni];
+                        if (scale_acc) { v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha; }
                         uint2 pk;
-                        pk.x = pack2bf(v[0] * p.alpha, v[1] * p.alpha);
-                        pk.y = pack2bf(v[2] * p.alpha, v[3] * p.alpha);
+                        pk.x = pack2bf(v[0], v[1]);
+                        pk.y = pack2bf(v[2], v[3]);
                         *(uint2*)(wrow + ni * 32) = pk;
                     }
                 }
