@@ -27,6 +27,9 @@
 //     All global loads of the epilogue are issued before the LDS transpose so their latency overlaps it.
 //   * tile order is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous range of tiles.
 #include <stdlib.h>
+#ifndef WIW_ABLATE
+#define WIW_ABLATE 0
+#endif
 
 #include <type_traits>
 
@@ -76,18 +79,41 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
 
-    // ---- this block's contiguous tile range (XCD-aware: block b runs on XCD b % 8)
+    // ---- tile schedule.  Per-XCD L2s are private and the DMA stream is what bounds this kernel (52 KiB per
+    // 5.2 MFLOP K tile: ~10 TB/s of cache-hierarchy traffic at 1 PFLOP/s), so the blocks that are resident on ONE
+    // XCD at the same time work on a compact sm x sn super-tile of output tiles: every A panel is fetched into that
+    // L2 once and read by sn blocks, every W panel once and read by sm blocks (blocks advance in near lock-step —
+    // equal work per K tile — and 4 MiB of L2 absorbs several K tiles of skew).  Block b is assumed to run on XCD
+    // b % 8 (observed dispatch order; a different placement changes speed only).
     const int Nt = (p.N + BN - 1) / BN;
     const int Mt = (p.M + BM - 1) / BM;
     const int total = Mt * Nt;
-    int t, t_end;
-    {
-        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        t = (int)(((int64_t)lb * total) / nb);
+    const int nb = gridDim.x;
+    const bool super = (nb & 7) == 0 && nb >= 64;      // otherwise: small grid, contiguous ranges
+    int sn = 1;
+    while (sn < 8 && sn * 2 <= Nt) sn *= 2;            // power of two <= min(Nt, 8); divides nb / 8 (32 or 64)
+    const int bpx = nb >> 3, sm = bpx / sn;
+    const int SNt = (Nt + sn - 1) / sn, SMt = (Mt + sm - 1) / sm;
+    const int n_super = SNt * SMt;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    int q = xcd, t_end = 0;
+    // next output tile of this block at or after schedule position `pos` (-1: done); advances pos
+    auto next_tile = [&](int& pos) -> int {
+        if (!super) return pos < t_end ? pos : -1;
+        for (; pos < n_super; pos += 8) {
+            const int tm = (pos / SNt) * sm + jx / sn, tn = (pos % SNt) * sn + jx % sn;
+            if (tm < Mt && tn < Nt) return tm * Nt + tn;
+        }
+        return -1;
+    };
+    if (!super) {
+        const int qq = nb >> 3, r = nb & 7, idx = blockIdx.x >> 3;
+        const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+        q = (int)(((int64_t)lb * total) / nb);
         t_end = (int)(((int64_t)(lb + 1) * total) / nb);
     }
-    if (t >= t_end) return;
+    int t = next_tile(q);
+    if (t < 0) return;
 
     // ---- loader state (per-thread source rows of the tile being fetched)
     const int rsub = lane >> 3;                       // row inside the 8-row group of one DMA instruction
@@ -193,6 +219,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     // wave streams ds_read_b128 (and issues the DMA) while the other issues 20 MFMAs back to back.
     bf16x8 fa[2], fb[10];
     auto read_frags = [&](int stage, int kk) {
+#if WIW_ABLATE == 2
+        return;
+#endif
         const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
         const char* sA = smem + stage * STAGE_BYTES + (wave * 32 + frow) * 128 + sw;
         const char* sB = smem + stage * STAGE_BYTES + A_BYTES + frow * 128 + sw;
@@ -202,6 +231,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
         for (int ni = 0; ni < 10; ++ni) fb[ni] = *(const bf16x8*)(sB + ni * 2048);
     };
     auto mma = [&]() {
+#if WIW_ABLATE == 1
+        asm volatile("" :: "v"(fa[0]), "v"(fb[0]));
+        return;
+#endif
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < 10; ++ni)
@@ -240,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     for (int j = 0; j < D; ++j)
         if (j < nk) issue_next(j);
 
-    for (; t < t_end; ++t) {
+    while (t >= 0) {
         const int tile_n = t % Nt;
         const int m0 = (t / Nt) * BM, n0 = tile_n * BN;
         setup_loader(t);   // recomputed (not kept live across the previous epilogue: VGPR budget); counters ld_* persist
@@ -374,8 +407,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
 
         // ---- keep the DMA stream going: first D K tiles of the NEXT output tile -> stages st_c, st_c+1.
         // Stage (st_c + D) % STAGES is not targeted until the next tile's first barrier: epilogue staging.
-        if (t + 1 < t_end) {
-            setup_loader(t + 1);
+        int q_next = q + (super ? 8 : 1);
+        const int t_next = next_tile(q_next);
+        if (t_next >= 0) {
+            setup_loader(t_next);
             ld_tap = 0; ld_cc = 0; ld_kt = 0;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -516,6 +551,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                 }
             }
         }
+        t = t_next;
+        q = q_next;
     }
 }
 
@@ -538,8 +575,8 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
         attr_set = true;
     }
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    int64_t grid = (int64_t)num_cu * blocks_per_cu;
-    if (grid > tiles) grid = tiles;
+    int64_t grid = (int64_t)num_cu * blocks_per_cu;   // persistent: every CU slot gets one block
+    if (tiles < grid) grid = tiles >= 64 ? (tiles / 8) * 8 : tiles;   // keep the per-XCD super-tile schedule usable
     hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a);
     return wiw_check_launch("wiw_gemm_bf16");
 }
