@@ -21,7 +21,9 @@ WIW_DEV uint32_t pack2bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wiw_bf16x2));
 }
 WIW_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); }
-WIW_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+WIW_DEV float silu_f(float x) {   // x * sigmoid(x) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; output is bf16)
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 // exact-erf GELU (activations.py:109 `F.gelu`), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e.
 // fp32-roundoff class) instead of libm erff's ~40 instructions — the GEGLU epilogue evaluates
 // 20480 of these per 256x160 block tile and VALU issue time there is NOT hidden behind MFMAs.

@@ -87,32 +87,46 @@ __global__ void gn_finalize_kernel(const float* __restrict__ stats, const float*
     }
 }
 
+// apply: grid = (row_splits, units) like the statistics kernel; a thread keeps the scale/shift of its 8 channels in
+// registers and walks rows with 32-bit index arithmetic only (no per-element division).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X1, int C1,
-                                                        const uint16_t* __restrict__ X2, int C2, int64_t rows,
-                                                        int rows_per_unit, const float* __restrict__ ab, int silu,
+                                                        const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
+                                                        int rows_per_block, const float* __restrict__ ab, int silu,
                                                         uint16_t* out) {
+    const int tid = threadIdx.x;
     const int C = C1 + C2;
     const int chunks = C >> 3;
-    const int64_t total = rows * chunks;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int chunk = (int)(idx % chunks);
-        const int64_t row = idx / chunks;
+    const int cpb = chunks < 256 ? chunks : 256;
+    const int rp = 256 / cpb;
+    const int ci = tid % cpb, rl = tid / cpb;
+    if (rl >= rp) return;
+    const int unit = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows_per_unit) r1 = rows_per_unit;
+    const int64_t base_row = (int64_t)unit * rows_per_unit;
+    for (int cbase = 0; cbase < chunks; cbase += cpb) {
+        const int chunk = cbase + ci;
+        if (chunk >= chunks) break;
         const int c0 = chunk * 8;
-        const int unit = (int)(row / rows_per_unit);
-        float f[8];
-        if (c0 < C1) unpack8(*(const uint4*)(X1 + row * C1 + c0), f);
-        else unpack8(*(const uint4*)(X2 + row * C2 + (c0 - C1)), f);
+        const uint16_t* src;
+        int ld, coff;
+        if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
         const float* a = ab + ((int64_t)unit * 2) * C + c0;
         const float* b = a + C;
         const float4 a0 = *(const float4*)a, a1 = *(const float4*)(a + 4);
         const float4 b0 = *(const float4*)b, b1 = *(const float4*)(b + 4);
-        f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
-        f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
-        if (silu) {
+        for (int r = r0 + rl; r < r1; r += rp) {
+            float f[8];
+            unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
+            f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
+            f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
+            if (silu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+            }
+            *(uint4*)(out + (base_row + r) * C + c0) = pack8(f);
         }
-        *(uint4*)(out + row * C + c0) = pack8(f);
     }
 }
 
@@ -121,17 +135,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 // exact two-pass mean / variance with 64-lane butterfly reductions.
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 4;
+constexpr int LN_RUN = 8;      // consecutive rows per wave
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, int64_t rows, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, const float* __restrict__ addvec, int addvec_ld,
                                                          int rows_per_vec, uint16_t* sum_out, uint16_t* out) {
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chunks = C >> 3;
     const float inv_c = 1.0f / (float)C;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    // every wave walks LN_RUN consecutive rows: the addvec row index is divided once per run and then only compared
+    for (int64_t run0 = ((int64_t)blockIdx.x * 4 + wave) * LN_RUN; run0 < rows; run0 += (int64_t)gridDim.x * 4 * LN_RUN) {
+      int vi = addvec ? (int)(run0 / rows_per_vec) : 0;
+      int64_t vnext = addvec ? (int64_t)(vi + 1) * rows_per_vec : rows;
+      const int64_t run1 = run0 + LN_RUN < rows ? run0 + LN_RUN : rows;
+      for (int64_t row = run0; row < run1; ++row) {
         float v[LN_MAXCH][8];
-        const float* av = addvec ? addvec + (row / rows_per_vec) * addvec_ld : nullptr;
+        if (row >= vnext) { ++vi; vnext += rows_per_vec; }
+        const float* av = addvec ? addvec + (int64_t)vi * addvec_ld : nullptr;
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < LN_MAXCH; ++k) {
@@ -178,6 +200,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
                 *(uint4*)(out + row * C + chunk * 8) = pack8(o);
             }
         }
+      }
     }
 }
 
@@ -226,9 +249,15 @@ extern "C" int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const v
     WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_apply: X2 iff C2 > 0");
     WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0, "groupnorm_apply: channels must be multiples of 8");
     WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_apply: bad rows");
-    const int64_t total = rows * ((C1 + C2) / 8);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total, 256, 2048 * 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)X1, C1, (const uint16_t*)X2, C2, rows, rows_per_unit, ab, silu, (uint16_t*)out);
+    const int units = (int)(rows / rows_per_unit);
+    int splits = (4096 + units - 1) / units;
+    const int max_splits = (rows_per_unit + 15) / 16;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int rows_per_block = (rows_per_unit + splits - 1) / splits;
+    splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
+                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, ab, silu, (uint16_t*)out);
     return wiw_check_launch("wiw_groupnorm_apply");
 }
 
@@ -239,7 +268,7 @@ extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int
     WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LN_MAXCH * 64 * 8, "layernorm: C must be %8 and <= 2048");
     WIW_REQUIRE(addvec == nullptr || (rows_per_vec > 0 && addvec_ld % 4 == 0), "layernorm: bad addvec layout");
     WIW_REQUIRE(sum_out == nullptr || addvec != nullptr, "layernorm: sum_out requires addvec");
-    hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows, 4, 2048 * 4)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows, 4 * LN_RUN, 2048 * 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)X, rows, C, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,
                        (uint16_t*)sum_out, (uint16_t*)out);
     return wiw_check_launch("wiw_layernorm_bf16");
