@@ -18,6 +18,7 @@ Fixtures written (all fp32 unless noted):
                            and the two B=1 runs that define the build's contract
   blocks_tiny.npz          inputs/outputs of one SpatioTemporalResBlock (with shortcut) and one
                            TransformerSpatioTemporalModel captured by forward hooks
+  frontend_tiny.npz        AutoencoderKLTemporalDecoder encode-mode / decode and `_resize_with_antialiasing` (tiny random VAE)
   pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
 """
@@ -270,6 +271,34 @@ def gen_pipeline(ns):
          latents_out_ref_bf16=np.stack(results_bf16))
 
 
+def gen_frontend(ns):
+    """VAE encode (mode) / temporal decode and the CLIP antialias resize of the reference, tiny random VAE."""
+    from diffusers import AutoencoderKLTemporalDecoder
+
+    from wiw_amd.frontend import vae_random_state_dict
+
+    pl = ns.pipeline_module
+    cfg = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)
+    vae = AutoencoderKLTemporalDecoder(down_block_types=("DownEncoderBlock2D",) * 4, latent_channels=4, force_upcast=True,
+                                       scaling_factor=0.18215, **cfg).eval()
+    sd = {k: torch.from_numpy(v) for k, v in vae_random_state_dict(7, **cfg).items()}
+    vae.load_state_dict(sd, strict=True)
+    rs = np.random.RandomState(9)
+    img = rs.uniform(-1, 1, size=(2, 3, 32, 64)).astype(np.float32)
+    T = 4
+    lat = rs.standard_normal((2 * T, 4, 4, 8)).astype(np.float32)
+    with torch.no_grad():
+        mode = vae.encode(torch.from_numpy(img)).latent_dist.mode()
+        dec = vae.decode(torch.from_numpy(lat), num_frames=T).sample
+        big = rs.uniform(-1, 1, size=(1, 3, 72, 128)).astype(np.float32)
+        rsz = pl._resize_with_antialiasing(torch.from_numpy(big), (224, 224))
+        small = rs.uniform(-1, 1, size=(1, 3, 576, 1024)).astype(np.float32)
+        rsz2 = pl._resize_with_antialiasing(torch.from_numpy(small), (224, 224))
+    save("frontend_tiny.npz", weight_seed=np.array(7), image=img, latent_mode=mode.numpy(), latents=lat, num_frames=np.array(T),
+         decoded=dec.numpy(), resize_in=big, resize_out=rsz.numpy(), resize_big_seed=np.array(9),
+         resize_big_out_sample=rsz2.numpy()[:, :, ::16, ::16])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
@@ -279,6 +308,7 @@ def main():
     gen_noise_rotation(ns)
     gen_unet(ns)
     gen_pipeline(ns)
+    gen_frontend(ns)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""End-to-end on the GPU: wire request -> SVDWorker (PyTorch frontend + HIP denoiser) -> uint8 response,
+compared with the same chain evaluated by the CPU oracle (fp32) on identical noise draws."""
+import numpy as np
+import pytest
+import torch
+
+import svd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_worker_end_to_end_matches_oracle_chain(tmp_path):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import frontend as FE
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.server import plumbing as P
+    from wiw_amd.server.worker import SVDWorker
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    T, H, W = 4, 128, 256
+    cfg = UNetConfig.tiny(T)
+    sd = random_state_dict(cfg, 21)
+    vcfg = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)
+    vsd = FE.vae_random_state_dict(22, **vcfg)
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=1024)).eval()
+    den = SVDDenoiser(UNetHIP(cfg, sd, "cuda:0"))
+    fe_gpu = FE.TorchFrontend(vsd, clip, device="cuda:0", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
+
+    def denoise(il, ie, nz, act, **kw):
+        return den.denoise(torch.from_numpy(il), torch.from_numpy(ie), torch.from_numpy(nz), act, **kw).cpu().numpy()
+
+    draws = []
+
+    def noise_fn(shape):
+        rs = np.random.RandomState(100 + len(draws))
+        draws.append(rs.standard_normal(shape).astype(np.float32))
+        return draws[-1]
+
+    worker = SVDWorker(denoise, fe_gpu, width=W, height=H, out_width=64, out_height=48, num_frames=T,
+                       num_inference_steps=3, noise_fn=noise_fn)
+    rs = np.random.RandomState(0)
+    req = {"b_action": np.array([[4, 2, 1, 3], [4, 1, 3, 3]], dtype=np.int64),
+           "save_dirs": [str(tmp_path / "a"), str(tmp_path / "b")], "request_model_name": "igen",
+           "b_image": rs.randint(0, 256, size=(2, 3, H, W), dtype=np.uint8), "return_objects": [True, True]}
+    out = worker(req)
+    pf = out["pred_frames"]
+    assert pf.shape == (2, T, 3, 48, 64) and pf.dtype == np.uint8
+
+    # the same chain on the CPU: fp32 frontend + oracle loop, same draws
+    fe_cpu = FE.TorchFrontend(vsd, clip, device="cpu", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
+    _, _, _, images = P.parse_request(req)
+    x = np.stack([P.preprocess_image(im, W, H) for im in images])
+    il, ie = fe_cpu.encode(x, draws[0], 0.02)
+    lat = O.denoise({k: torch.from_numpy(v) for k, v in sd.items()}, cfg.as_dict(), torch.from_numpy(il), torch.from_numpy(ie),
+                    torch.from_numpy(draws[1]), req["b_action"], num_steps=3).numpy()
+    frames = fe_cpu.decode(lat)
+    ref = P.build_response(P.images_to_tensor([P.frames_to_pil(f) for f in frames], save_size=(64, 48)),
+                           req["b_action"], req["save_dirs"], True)["pred_frames"]
+    diff = np.abs(pf.astype(np.int32) - ref.astype(np.int32))
+    mse = float((diff.astype(np.float64) ** 2).mean())
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    print(f"[parity] end-to-end uint8 frames: mean|diff|={diff.mean():.3f} levels, max={diff.max()}, PSNR={psnr:.1f} dB")
+    assert psnr > 30.0   # per-pixel metric of the reference (evaluation/FVD/calculate_psnr.py:6-15); FVD needs absent I3D weights
