@@ -212,6 +212,30 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
         if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
     };
 
+    // BIG: the 7 DMA instructions of a K tile are spread 2|2|2|1 over the four slots of the previous tile's
+    // iteration: an LDS-DMA instruction costs the issuing wave ~100 cycles, and a slot that carries all 7 is three
+    // times longer than the MFMA slot of the partner wave it is supposed to overlap.
+    auto issue_part = [&](int stage, auto part_tag) {
+        constexpr int part = decltype(part_tag)::value;
+        char* sA = smem + stage * STAGE_BYTES + wave * 4 * 1024;
+        char* sB = smem + stage * STAGE_BYTES + A_BYTES + wave * B_FULL * 1024;
+        if (part < 2) {
+            glds16(a_src(2 * part, ld_tap, ld_cc), sA + (2 * part) * 1024);
+            glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
+        } else if (part == 2) {
+#pragma unroll
+            for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * (BK * 2), sB + i * 1024);
+        } else {
+            if (B_HALF) {
+                char* sH = smem + stage * STAGE_BYTES + A_BYTES + B_FULL * NW * 1024 + wave * 512;
+                if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * (BK * 2), sH);
+            }
+            ++ld_kt;
+            ld_cc += BK;
+            if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
+        }
+    };
+
     f32x4 acc[2][10];
     // Fragment registers of ONE 32-deep k-step: filled in a wave's "read" slot, consumed in its "MFMA" slot.
     // Every wave runs  R(kk=0) | M | R(kk=1) | M  per K tile with a barrier between slots; the second wave group
@@ -235,13 +259,17 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
         asm volatile("" :: "v"(fa[0]), "v"(fb[0]));
         return;
 #endif
+#if WIW_ABLATE != 3
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int ni = 0; ni < 10; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)   // swapped operands: lane gets n = 16*ni + 4*fq + r, m = 16*mi + frow
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+#if WIW_ABLATE != 3
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto slot_barrier = [&]() {   // close a slot: this wave's LDS reads are retired, then rendezvous
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -249,6 +277,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto slot_barrier_i = [&]() {   // intra-tile slot boundary
+#if WIW_ABLATE != 4
+        slot_barrier();
+#endif
     };
     const bool lag = wave >= NW / 2;   // wave-uniform: second wave group
 
@@ -293,39 +326,46 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
         // "at most <ops issued after it> outstanding" = the DMA of tile j+1 (BIG) plus, for the first D tiles of a
         // non-first output tile, the previous epilogue's stores (compile-time count: they are unconditional) — the
         // stores drain behind the MFMAs instead of stalling the wave at the tile boundary.
-        auto wait_tile = [&](int j) {   // wait until this wave's DMA portion of K tile j has landed
+        // wait until this wave's DMA portion of K tile j has landed; `n_dma` = DMA instructions issued after it
+        auto wait_tile = [&](int j, auto ndma_tag) {
+            constexpr int n_dma = decltype(ndma_tag)::value;
             const bool dma_younger = (D == 2) && (j + 1 < nk);
             const int st_younger = (j < D) ? pending_stores : 0;   // wave-uniform: 0, 6 (GEGLU) or 12
             if (dma_younger) {
-                if (st_younger == 12) wait_vmcnt<LPT + 12>();
-                else if (st_younger == 6) wait_vmcnt<LPT + 6>();
-                else wait_vmcnt<LPT>();
+                if (st_younger == 12) wait_vmcnt<n_dma + 12>();
+                else if (st_younger == 6) wait_vmcnt<n_dma + 6>();
+                else wait_vmcnt<n_dma>();
             } else {
                 if (st_younger == 12) wait_vmcnt<12>();
                 else if (st_younger == 6) wait_vmcnt<6>();
                 else wait_vmcnt<0>();
             }
         };
-        wait_tile(0);
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using ILPT = std::integral_constant<int, LPT>; using I6 = std::integral_constant<int, LPT - 1>;
+        wait_tile(0, ILPT{});
         if (NW == 8) {
             if (lag) slot_barrier();
             for (int kt = 0; kt < nk; ++kt) {
                 slot_barrier();                                  // local barrier 4kt
-                if (kt + D < nk) {
-                    int si = st_c + D;
-                    si = si >= STAGES ? si - STAGES : si;
-                    issue_next(si);
-                }
+                const bool more = kt + D < nk;
+                int si = st_c + D;
+                si = si >= STAGES ? si - STAGES : si;
+                if (more) issue_part(si, I0{});
                 read_frags(st_c, 0);
-                slot_barrier();                                  // 4kt+1
+                slot_barrier_i();                                // 4kt+1
+                if (more) issue_part(si, I1{});
                 mma();
-                slot_barrier();                                  // 4kt+2
+                slot_barrier_i();                                // 4kt+2
+                if (more) issue_part(si, I2{});
                 read_frags(st_c, 1);
                 if (kt + 1 < nk) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_tile(kt + 1);
+                    wait_tile(kt + 1, I6{});                     // 6 of tile kt+2's 7 DMA instructions are younger
                 }
-                slot_barrier();                                  // 4kt+3
+                slot_barrier_i();                                // 4kt+3
+                if (more) issue_part(si, I3{});
                 mma();
                 st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
             }
@@ -346,7 +386,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                 mma();
                 if (kt + 1 < nk) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_tile(kt + 1);
+                    wait_tile(kt + 1, ILPT{});
                 }
                 st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
             }
