@@ -57,13 +57,16 @@ int wiw_device_check(int dev, char* name, int name_len);
  *        dp/models/resnet.py:269,285 (ResnetBlock2D.conv1/conv2), unet:130-135, 255-260.
  * mode WIW_A_CONV3X3_S2: 3x3, stride 2, pad 1; input is (2H, 2Wd)                 (K = 9 * C1)
  *        dp/models/downsampling.py:132-150 (Downsample2D).
+ * mode WIW_A_CONV3X3_S2P: 3x3, stride 2, zero pad (0,1,0,1) = bottom / right only; input is (2H, 2Wd)
+ *        dp/models/downsampling.py:132-150 with padding=0 (VAE encoder DownEncoderBlock2D).
  * mode WIW_A_CONV3X3_UP: nearest x2 upsample fused into a 3x3 conv; input (H/2, Wd/2)
  *        dp/models/upsampling.py:142-186 (Upsample2D).
  * mode WIW_A_CONV_T3   : (3,1,1) temporal conv, zero pad 1 over T; S = H*Wd       (K = 3 * C1)
  *        dp/models/resnet.py:570-592 (TemporalResnetBlock.conv1/conv2).
  * Constraints: C1 % 64 == 0, C2 % 64 == 0, K = taps * (C1 + C2); A2 only with WIW_A_DENSE.
  * ---------------------------------------------------------------------------------------------- */
-enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_UP = 3, WIW_A_CONV_T3 = 4 };
+enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_UP = 3, WIW_A_CONV_T3 = 4,
+       WIW_A_CONV3X3_S2P = 5 };
 enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4 };
 
 typedef struct WiwGemmArgs {
@@ -166,6 +169,29 @@ int wiw_prep_unet_input(void* stream, const float* latents, const float* image_l
  * ---------------------------------------------------------------------------------------------- */
 int wiw_cfg_euler_step(void* stream, const float* V, int ldv, float* latents, int B, int T, int hw, float sigma,
                        float sigma_next, float gmin, float gmax);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal VAE (SURVEY.md §8 rows a5 / a20 — the callers either side of the denoising loop).  The VAE
+ * reuses wiw_gemm_bf16 (3x3 / stride-2 / upsample / temporal convolutions, 1x1 shortcuts, attention
+ * projections) and the GroupNorm entry points; three operators exist only for it:
+ *
+ * wiw_softmax_rows_f32_bf16: P[r][0:cols] = softmax(X[r][0:cols]) per row, fp32 in, bf16 out.  Middle of the
+ *   single-head, head_dim = C attention of the VAE mid blocks (legacy AttnProcessor of
+ *   dp/models/attention_processor.py as instantiated by dp/models/unets/unet_2d_blocks.py UNetMidBlock2D and
+ *   unet_3d_blocks.py:930-990 MidBlockTemporalDecoder): scores = scale * Q.K^T and P.V are wiw_gemm_bf16 calls.
+ *   cols % 4 == 0, cols <= 16384, ldx / ldp % 4 == 0.
+ * wiw_vae_time_conv_out: the decoder's last layer, Conv3d(3, 3, (3,1,1), padding (1,0,0))
+ *   (dp/models/autoencoders/autoencoder_kl_temporal_decoder.py:87-161 `time_conv_out`) fused with the
+ *   NHWC -> NCHW frame layout:  Y fp32 [frames*HW][ldy] (channels 0..2, ldy % 4 == 0), weight fp32 [3][3][3]
+ *   = [co][ci][dt], out fp32 [frames][3][HW]; frames = batch * T, zero padding over T per batch item.
+ * wiw_nchw_f32_to_nhwc_bf16: out[(n*HW + p)][c] = c < Cin ? scale * X[n][c][p] : 0  (bf16, Cpad % 8 == 0):
+ *   latents / scaling_factor (pipeline:288) or pixels -> the padded NHWC rows conv_in consumes.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_softmax_rows_f32_bf16(void* stream, const float* X, int64_t ldx, int64_t rows, int cols, void* P, int64_t ldp);
+int wiw_vae_time_conv_out(void* stream, const float* Y, int ldy, const float* weight, const float* bias, int frames,
+                          int T, int HW, float* out);
+int wiw_nchw_f32_to_nhwc_bf16(void* stream, const float* X, int frames, int Cin, int HW, float scale, int Cpad,
+                              void* out);
 
 /* Utility: fill fp32 buffer (used to zero GroupNorm statistics inside captured graphs). */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);

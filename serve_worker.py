@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Launcher for the MI355X SVD world-model worker: the process the reference manager starts in place of
+FTsvd/eval_inference.py (downstream/utils/worker_manager.py:324-334 spawns `<python> <script> <args...> <w_fd>`),
+or a standalone TCP server with --port (client protocol of downstream/solver_base.py:645-688).
+
+    python serve_worker.py --unet_path <finetuned>/unet --svd_path <stable-video-diffusion-img2vid-xt> <w_fd>
+    python serve_worker.py --unet_path ... --svd_path ... --port 7000
+    python serve_worker.py --random_weights --port 7000          # no checkpoints: random-init weights (bring-up)
+
+The denoising loop and the VAE encode / decode run on the hand-written HIP path (libwiwsvd.so; no fallback);
+the CLIP image encoder is the third-party `transformers` module the reference uses, on PyTorch-ROCm.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+import wiw_amd  # noqa: F401  (registers the package under an importable name)
+from wiw_amd import frontend as FE
+from wiw_amd.config import UNetConfig
+from wiw_amd.pipeline import SVDDenoiser
+from wiw_amd.server.worker import SVDWorker, build_arg_parser, serve_tcp, worker_main
+from wiw_amd.unet import UNetHIP
+from wiw_amd.vae import HIPFrontend, VAEHIP
+from wiw_amd.weights import load_safetensors, random_state_dict
+
+
+def _find_safetensors(folder: str) -> str:
+    for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"):
+        p = os.path.join(folder, name)
+        if os.path.isfile(p):
+            return p
+    raise FileNotFoundError(f"no diffusion_pytorch_model[.fp16].safetensors under {folder}")
+
+
+def _clip(svd_path: str, random_weights: bool):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    if random_weights:   # ViT-H/14 geometry of the SVD image_encoder
+        torch.manual_seed(0)
+        return CLIPVisionModelWithProjection(CLIPVisionConfig(
+            hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
+            patch_size=14, projection_dim=1024, hidden_act="gelu")).eval()
+    return CLIPVisionModelWithProjection.from_pretrained(svd_path, subfolder="image_encoder").eval()
+
+
+def arg_parser():
+    ap = build_arg_parser()
+    ap.add_argument("--random_weights", action="store_true", help="random-init UNet / VAE / CLIP (no checkpoints)")
+    ap.add_argument("--host", type=str, default="127.0.0.1")
+    ap.add_argument("--frontend", choices=["hip", "torch"], default="hip", help="VAE encode/decode implementation")
+    ap.add_argument("pipe_fd", nargs="?", type=int, default=None, help="result-pipe fd appended by the manager")
+    return ap
+
+
+def build_worker(args) -> SVDWorker:
+    cfg = UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel)
+    if args.random_weights:
+        unet_sd, vae_sd = random_state_dict(cfg, 0), FE.vae_random_state_dict(1)
+    else:
+        unet_dir = args.unet_path if os.path.isdir(args.unet_path) else os.path.join(args.svd_path, "unet")
+        unet_sd = load_safetensors(_find_safetensors(unet_dir))
+        vae_sd = load_safetensors(_find_safetensors(os.path.join(args.svd_path, "vae")))
+    unet = UNetHIP(cfg, unet_sd, args.device)
+    den = SVDDenoiser(unet)
+    dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}[args.weight_dtype]
+    clip = _clip(args.svd_path, args.random_weights)
+    if args.frontend == "hip":     # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module
+        fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip), clip, dtype=dtype)
+    else:                          # everything around the denoiser through PyTorch-ROCm / MIOpen
+        fe = FE.TorchFrontend(vae_sd, clip, device=args.device, dtype=dtype)
+
+    def denoise(image_latents, image_embeddings, noise, actions, **kw) -> np.ndarray:
+        return den.denoise(torch.from_numpy(image_latents), torch.from_numpy(image_embeddings),
+                           torch.from_numpy(noise), actions, **kw).cpu().numpy()
+
+    return SVDWorker(denoise, fe, width=args.width, height=args.height, out_width=args.out_width,
+                     out_height=args.out_height, num_frames=args.num_frames,
+                     num_inference_steps=args.num_inference_steps)
+
+
+def main(argv=None) -> None:
+    ap = arg_parser()
+    args = ap.parse_args(list(sys.argv[1:] if argv is None else argv))
+    if args.port <= 0 and args.pipe_fd is None:
+        ap.error("either --port (standalone TCP server) or the manager's trailing pipe fd is required")
+    worker = build_worker(args)
+    if args.port > 0:
+        print(f"[serve_worker] listening on {args.host}:{args.port}", file=sys.stderr, flush=True)
+        serve_tcp(worker, host=args.host, port=args.port, batch_size=args.batch_size)
+    else:
+        worker_main(args.pipe_fd, worker)
+
+
+if __name__ == "__main__":
+    main()

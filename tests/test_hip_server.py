@@ -68,3 +68,35 @@ def test_worker_end_to_end_matches_oracle_chain(tmp_path):
     psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
     print(f"[parity] end-to-end uint8 frames: mean|diff|={diff.mean():.3f} levels, max={diff.max()}, PSNR={psnr:.1f} dB")
     assert psnr > 30.0   # per-pixel metric of the reference (evaluation/FVD/calculate_psnr.py:6-15); FVD needs absent I3D weights
+
+
+def test_serve_worker_full_size_over_tcp(tmp_path):
+    """The launcher at production geometry (576x1024x14, full-width UNet / VAE / CLIP, random-init weights):
+    one 2-candidate request through the TCP transport of solver_base.py:645-688, 2 Euler steps."""
+    import socket
+    import threading
+
+    import serve_worker
+    from wiw_amd.server import protocol as PR
+    from wiw_amd.server.worker import serve_tcp
+
+    args = serve_worker.arg_parser().parse_args(["--random_weights", "--num_inference_steps", "2", "--port", "1"])
+    worker = serve_worker.build_worker(args)
+    ready, stop = threading.Event(), threading.Event()
+    th = threading.Thread(target=serve_tcp, kwargs=dict(worker=worker, port=0, ready=ready, stop=stop), daemon=True)
+    th.start()
+    assert ready.wait(10)
+    rs = np.random.RandomState(0)
+    req = {"b_action": np.array([[4] + [1] * 13, [4] + [2] * 6 + [1] * 7], dtype=np.int64),
+           "save_dirs": [str(tmp_path / "a"), str(tmp_path / "b")], "request_model_name": "igen",
+           "b_image": rs.randint(0, 256, size=(2, 3, 576, 1024), dtype=np.uint8), "return_objects": [True, True]}
+    with socket.create_connection(("127.0.0.1", ready.port)) as c:
+        PR.write_framed(c, req)
+        out = PR.read_framed(c)
+        PR.write_framed(c, PR.DONE)
+    stop.set()
+    th.join(5)
+    pf = out["pred_frames"]
+    assert pf.shape == (2, 14, 3, 480, 480) and pf.dtype == np.uint8
+    assert np.isfinite(pf.astype(np.float32)).all() and pf.std() > 0
+    assert list(out["save_dirs"]) == req["save_dirs"]

@@ -139,11 +139,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
             a_m[i] = m;
             a_ok[i] = m < p.M;
             a_fb[i] = 0; a_y[i] = 0; a_x[i] = 0;
-            if (MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_UP) {
+            if (MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P || MODE == WIW_A_CONV3X3_UP) {
                 const int n = m / HW, rem = m - n * HW;
                 a_y[i] = rem / p.Wd;
                 a_x[i] = rem - a_y[i] * p.Wd;
-                a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW : (MODE == WIW_A_CONV3X3_S2 ? n * HW * 4 : n * (HW >> 2));
+                a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW
+                          : ((MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) ? n * HW * 4 : n * (HW >> 2));
             } else if (MODE == WIW_A_CONV_T3) {
                 a_y[i] = (m / HW) % p.T;
             }
@@ -181,8 +182,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                 const int iy = a_y[i] + dy, ix = a_x[i] + dx;
                 ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
                 row = a_fb[i] + iy * p.Wd + ix;
-            } else if (MODE == WIW_A_CONV3X3_S2) {
-                const int iy = 2 * a_y[i] + dy, ix = 2 * a_x[i] + dx;
+            } else if (MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) {
+                constexpr int o = (MODE == WIW_A_CONV3X3_S2P) ? 1 : 0;   // S2P: padding on the bottom / right only
+                const int iy = 2 * a_y[i] + dy + o, ix = 2 * a_x[i] + dx + o;
                 ok = (unsigned)iy < (unsigned)(2 * p.H) && (unsigned)ix < (unsigned)(2 * p.Wd);
                 row = a_fb[i] + iy * (2 * p.Wd) + ix;
             } else {
@@ -647,7 +649,7 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     WIW_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: M, N, K must be positive");
     WIW_REQUIRE(a.C1 > 0 && a.C1 % 64 == 0 && a.C2 >= 0 && a.C2 % 64 == 0, "gemm: C1/C2 must be multiples of 64");
     WIW_REQUIRE((a.C2 == 0) == (a.A2 == nullptr), "gemm: A2 must be given iff C2 > 0");
-    WIW_REQUIRE(a.mode >= WIW_A_DENSE && a.mode <= WIW_A_CONV_T3, "gemm: unknown mode");
+    WIW_REQUIRE(a.mode >= WIW_A_DENSE && a.mode <= WIW_A_CONV3X3_S2P, "gemm: unknown mode");
     const int taps = a.mode == WIW_A_DENSE ? 1 : (a.mode == WIW_A_CONV_T3 ? 3 : 9);
     WIW_REQUIRE(a.mode == WIW_A_DENSE || a.C2 == 0, "gemm: concat input only in dense mode");
     WIW_REQUIRE(a.K == taps * (a.C1 + a.C2), "gemm: K != taps * (C1 + C2)");
@@ -671,6 +673,7 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
         case WIW_A_CONV3X3: return launch<WIW_A_CONV3X3>(s, a);
         case WIW_A_CONV3X3_S2: return launch<WIW_A_CONV3X3_S2>(s, a);
         case WIW_A_CONV3X3_UP: return launch<WIW_A_CONV3X3_UP>(s, a);
+        case WIW_A_CONV3X3_S2P: return launch<WIW_A_CONV3X3_S2P>(s, a);
         default: return launch<WIW_A_CONV_T3>(s, a);
     }
 }

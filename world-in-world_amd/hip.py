@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WIW_LIB", os.path.join(_HERE, "libwiwsvd.so"))
 
-A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3 = 0, 1, 2, 3, 4
+A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1, 2, 3, 4, 5
 EPI_GEGLU, EPI_SILU, EPI_OUT_F32 = 1, 2, 4
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 
@@ -58,6 +58,11 @@ EXPORTS = {
     "wiw_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_float, C.c_float]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
+    "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
+    "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
+    "wiw_nchw_f32_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                            C.c_void_p]),
 }
 
 
@@ -182,3 +187,18 @@ class Hip:
         self._ck(self.lib.wiw_cfg_euler_step(self._stream(), _p(V), ldv, _p(latents), B, T, hw, sigma, sigma_next,
                                              gmin, gmax), "wiw_cfg_euler_step")
         return latents
+
+    def softmax_rows(self, X, ldx, rows, cols, P, ldp):
+        self._ck(self.lib.wiw_softmax_rows_f32_bf16(self._stream(), _p(X), ldx, rows, cols, _p(P), ldp),
+                 "wiw_softmax_rows_f32_bf16")
+        return P
+
+    def vae_time_conv_out(self, Y, ldy, weight, bias, frames, T, HW, out):
+        self._ck(self.lib.wiw_vae_time_conv_out(self._stream(), _p(Y), ldy, _p(weight), _p(bias), frames, T, HW,
+                                                _p(out)), "wiw_vae_time_conv_out")
+        return out
+
+    def nchw_to_nhwc(self, X, frames, Cin, HW, scale, Cpad, out):
+        self._ck(self.lib.wiw_nchw_f32_to_nhwc_bf16(self._stream(), _p(X), frames, Cin, HW, scale, Cpad, _p(out)),
+                 "wiw_nchw_f32_to_nhwc_bf16")
+        return out
