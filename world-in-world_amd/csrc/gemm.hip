@@ -63,7 +63,7 @@ WIW_DEV void wave_lds_sync() {   // order this wave's LDS writes before its foll
 }
 
 template <int MODE, int NW, int STAGES, bool GE>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
+__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, const int stagger) {
     constexpr int BM = NW * 32;
     constexpr int A_BYTES = BM * BK * 2;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -90,9 +90,20 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     const int total = Mt * Nt;
     const int nb = gridDim.x;
     const bool super = (nb & 7) == 0 && nb >= 64;      // otherwise: small grid, contiguous ranges
+    // sn: power of two <= 8 (divides nb / 8) with the fewest padded (idle) tile slots; ties go to the wider super-tile
+    // (Nt = 6 with sn = 4 would leave a quarter of the blocks without work in every second super-tile column)
+    const int bpx = nb >> 3;
     int sn = 1;
-    while (sn < 8 && sn * 2 <= Nt) sn *= 2;            // power of two <= min(Nt, 8); divides nb / 8 (32 or 64)
-    const int bpx = nb >> 3, sm = bpx / sn;
+    {
+        int64_t best = -1;
+        for (int c = 1; c <= 8; c *= 2) {
+            if (c > bpx || (c > 1 && c > Nt)) break;
+            const int cm = bpx / c;
+            const int64_t slots = (int64_t)((Nt + c - 1) / c) * c * ((Mt + cm - 1) / cm) * cm;
+            if (best < 0 || slots <= best) { best = slots; sn = c; }
+        }
+    }
+    const int sm = bpx / sn;
     const int SNt = (Nt + sn - 1) / sn, SMt = (Mt + sm - 1) / sm;
     const int n_super = SNt * SMt;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
@@ -114,6 +125,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
     }
     int t = next_tile(q);
     if (t < 0) return;
+    // De-phase the blocks: every block has the same work per output tile, so without this all CUs run their main
+    // loops together and then write their tiles together; the epilogue's store burst (80 KB per CU) then drains at
+    // the HBM write rate while every MFMA pipe waits (stores retire in order ahead of the next tile's LDS-DMA).
+    if (stagger > 0) {
+        const int phase = ((blockIdx.x >> 3) + 2 * (blockIdx.x >> 8)) & 3;
+        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 cycles per iteration
+    }
 
     // ---- loader state (per-thread source rows of the tile being fetched)
     const int rsub = lane >> 3;                       // row inside the 8-row group of one DMA instruction
@@ -487,9 +505,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                             v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
                             g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
                         }
+                        // (a packed-fp32 polynomial erf without v_exp / v_rcp was measured 2 % SLOWER here)
+                        const wiw_f32x2 h01 = {v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])};
+                        const wiw_f32x2 h23 = {v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3])};
                         uint2 pk;
-                        pk.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
-                        pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+                        pk.x = pack2bf(h01.x, h01.y);
+                        pk.y = pack2bf(h23.x, h23.y);
                         *(uint2*)(wrow + ni * 32) = pk;
                     }
                 } else {
@@ -542,14 +563,41 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p) {
                         }
                         ov = pack8(v);
                     }
+#if WIW_ABLATE == 5
+                    uint4* dst = dump;
+#elif WIW_ABLATE == 7   // same bytes, but every store instruction writes 1 KiB contiguous (wrong layout: timing only)
+                    const int64_t lin = ((((int64_t)t * NW + wave) * 12 + (mi * 6 + k)) * 1024 + lane * 16) %
+                                        ((int64_t)p.M * p.ldo * 2 - 1024);
+                    uint4* dst = (uint4*)((char*)p.out + (lin & ~15ll));
+#else
                     uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + ncol) : dump;
+#endif
+#if WIW_ABLATE == 9
                     *dst = ov;
+#else
+                    // streaming (nt) store: the output tile is never re-read by this kernel, and a plain store
+                    // allocates it in the XCD's 4 MiB L2 where it evicts the A / W panels the super-tile schedule
+                    // keeps there (measured -17...-26 % on the K <= 1280 projections at L0)
+                    __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
+                    __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+#endif
                 }
                 wave_lds_sync();
             };
+#if WIW_ABLATE == 6
+            if (p.M < 0) {
+#endif
             half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 0>{});
             half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 1>{});
             if (fast_st) pending_stores = geglu ? 2 * ITEMS_G : 2 * ITEMS_P;
+#if WIW_ABLATE == 6
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 10; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+            }
+#endif
         } else {
             // direct path (fp32 output, SiLU, unaligned N / strides): element-wise from the fragment layout.
             // Every index into acc[][] is a compile-time constant (guards instead of break / continue).
@@ -619,7 +667,9 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     int64_t grid = (int64_t)num_cu * blocks_per_cu;   // persistent: every CU slot gets one block
     if (tiles < grid) grid = tiles >= 64 ? (tiles / 8) * 8 : tiles;   // keep the per-XCD super-tile schedule usable
-    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a);
+    static const char* stg_env = getenv("WIW_GEMM_STAGGER");
+    const int stagger = stg_env ? atoi(stg_env) : 0;
+    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16");
 }
 
