@@ -130,6 +130,11 @@ int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma,
                            int C, int rows_per_unit, float eps, float* ab);
 int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
                         int rows_per_unit, const float* ab, int silu, void* out);
+/* finalize + apply in one launch: scale / shift are derived from the raw `stats` inside the kernel.  With a pool of
+ * statistics buffers zeroed by ONE wiw_fill_f32 per forward this removes two tiny launches per GroupNorm. */
+int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                              int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
+                              int silu, void* out);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim with an optional fused pre-add of a per-row-group vector:

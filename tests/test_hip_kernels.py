@@ -262,6 +262,21 @@ def test_groupnorm(hip, n, c1, c2, h, w, unit_frames):
             ref = F.group_norm(x5, 32, gamma, beta, 1e-5).permute(0, 2, 1, 3, 4).reshape(n, C, h, w)
         ref = F.silu(ref) if silu else ref
         check(from_nhwc(out, n, h, w), ref, what=f"groupnorm C={c1}+{c2} unit={unit_frames} silu={silu}")
+        out4 = hip.groupnorm_unfused(x1, c1, x2, c2, rows, unit_frames * h * w, dev_f(gamma), dev_f(beta), 1e-5, silu)
+        check(from_nhwc(out4, n, h, w), ref, what=f"groupnorm (4 entry points) C={c1}+{c2} silu={silu}")
+
+
+def test_groupnorm_stats_pool_refill(hip):
+    """More GroupNorms than pool slots: statistics slots are re-zeroed in bulk and never reused dirty."""
+    n, C, h, w = 2, 64, 4, 8
+    x = bf(rnd(n, C, h, w, seed=4))
+    gamma, beta = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    x1 = dev_bf(nhwc(x))
+    ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+    g, b = dev_f(gamma), dev_f(beta)
+    outs = [hip.groupnorm(x1, C, None, 0, n * h * w, h * w, g, b, 1e-5, False) for _ in range(hip.STATS_POOL + 40)]
+    for i in (0, hip.STATS_POOL - 1, hip.STATS_POOL, len(outs) - 1):
+        check(from_nhwc(outs[i], n, h, w), ref, what=f"groupnorm call {i}")
 
 
 @pytest.mark.parametrize("rows,C", [(100, 64), (777, 320), (64, 1280), (50, 2048)])

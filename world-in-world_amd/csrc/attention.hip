@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
             for (int kf = 1; kf < 4; ++kf)
                 mx = fmaxf(fmaxf(mx, fmaxf(s[kf][f][0], s[kf][f][1])), fmaxf(s[kf][f][2], s[kf][f][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
             const float m_new = fmaxf(m_run[f], mx * scale_log2e);
             const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
             m_run[f] = m_new;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         float l = l_run[f];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         const float inv = 1.0f / l;
         const int qi = qt * QB + wave * 32 + f * 16 + fr;
         if (qi < S) {
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
         sv[r] = (fq * 4 + r) < T ? st[r] * scale_log2e : -INFINITY;
         mx = fmaxf(mx, sv[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor16_max(mx);
+    mx = xor32_max(mx);
     float p[4], l = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { p[r] = exp2f(sv[r] - mx); l += p[r]; }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xor16_sum(l);
+    l = xor32_sum(l);
     const float inv = 1.0f / l;
     union { uint32_t u[4]; bf16x8 v; } pv;
     pv.u[0] = pack2bf(p[0], p[1]); pv.u[1] = pack2bf(p[2], p[3]); pv.u[2] = 0u; pv.u[3] = 0u;

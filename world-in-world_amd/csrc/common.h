@@ -55,11 +55,45 @@ WIW_DEV uint4 pack8(const float* f) {
     return v;
 }
 
-// wave-wide (64-lane) reductions by butterfly shuffles
+// Cross-lane exchange WITHOUT the LDS crossbar (`__shfl_xor` compiles to ds_bpermute_b32: an LDS-pipe instruction
+// with > 100 cycles of latency; with two dependent ones per row a C = 320 LayerNorm was shuffle-bound at 2.7 TB/s):
+//   * within a row of 16 lanes: DPP row rotations folded into the VALU add (v_add_f32_dpp row_ror:n);
+//   * lane ^ 16 / lane ^ 32: gfx950's v_permlane16_swap / v_permlane32_swap (VALU).  With both operands = x the two
+//     results hold x of "my" half and x of the partner half for every lane.
+template <int CTRL>
+WIW_DEV float dpp_mov(float x) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+WIW_DEV float xor16_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+WIW_DEV float xor32_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+WIW_DEV float xor16_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+WIW_DEV float xor32_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// wave-wide (64-lane) reductions; every lane receives the result
 WIW_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1  -> every lane holds the sum of its row of 16
+    return xor32_sum(xor16_sum(v));
+}
+WIW_DEV float wave_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x122>(v));
+    v = fmaxf(v, dpp_mov<0x121>(v));
+    return xor32_max(xor16_max(v));
 }
 
 // Host-side error bookkeeping (api.cpp)

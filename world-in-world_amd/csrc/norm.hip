@@ -89,10 +89,13 @@ __global__ void gn_finalize_kernel(const float* __restrict__ stats, const float*
 
 // apply: grid = (row_splits, units) like the statistics kernel; a thread keeps the scale/shift of its 8 channels in
 // registers and walks rows with 32-bit index arithmetic only (no per-element division).
+// FUSED: `ab` is the raw statistics buffer [units][32][2]; scale / shift are derived here (no finalize launch).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X1, int C1,
                                                         const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
                                                         int rows_per_block, const float* __restrict__ ab, int silu,
-                                                        uint16_t* out) {
+                                                        uint16_t* out, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float inv_count, float eps) {
     const int tid = threadIdx.x;
     const int C = C1 + C2;
     const int chunks = C >> 3;
@@ -112,10 +115,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
         const uint16_t* src;
         int ld, coff;
         if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
-        const float* a = ab + ((int64_t)unit * 2) * C + c0;
-        const float* b = a + C;
-        const float4 a0 = *(const float4*)a, a1 = *(const float4*)(a + 4);
-        const float4 b0 = *(const float4*)b, b1 = *(const float4*)(b + 4);
+        float4 a0, a1, b0, b1;
+        if (FUSED) {
+            const int cg = C / GROUPS;
+            float av[8], bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = c0 + e, g = c / cg;
+                const float mean = ab[((int64_t)unit * GROUPS + g) * 2] * inv_count;
+                float var = ab[((int64_t)unit * GROUPS + g) * 2 + 1] * inv_count - mean * mean;
+                var = var < 0.f ? 0.f : var;
+                av[e] = rsqrtf(var + eps) * gamma[c];
+                bv[e] = beta[c] - mean * av[e];
+            }
+            a0 = float4{av[0], av[1], av[2], av[3]}; a1 = float4{av[4], av[5], av[6], av[7]};
+            b0 = float4{bv[0], bv[1], bv[2], bv[3]}; b1 = float4{bv[4], bv[5], bv[6], bv[7]};
+        } else {
+            const float* a = ab + ((int64_t)unit * 2) * C + c0;
+            const float* b = a + C;
+            a0 = *(const float4*)a; a1 = *(const float4*)(a + 4);
+            b0 = *(const float4*)b; b1 = *(const float4*)(b + 4);
+        }
         for (int r = r0 + rl; r < r1; r += rp) {
             float f[8];
             unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
@@ -137,6 +157,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 constexpr int LN_MAXCH = 4;
 constexpr int LN_RUN = 8;      // consecutive rows per wave
 
+// NCH = 16-byte chunk passes per row (C <= NCH * 512), R = rows whose loads are in flight together (R * NCH = 4):
+// at C = 320 one row is only 640 B, and one row in flight per wave leaves the kernel latency-bound.
+template <int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, int64_t rows, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, const float* __restrict__ addvec, int addvec_ld,
@@ -145,59 +168,102 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chunks = C >> 3;
     const float inv_c = 1.0f / (float)C;
+    float4 g0[NCH], g1[NCH], b0[NCH], b1[NCH], a0[NCH], a1[NCH];   // per-lane slices of gamma / beta / the add vector
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int chunk = lane + k * 64;
+        if (chunk < chunks) {
+            g0[k] = *(const float4*)(gamma + chunk * 8); g1[k] = *(const float4*)(gamma + chunk * 8 + 4);
+            b0[k] = *(const float4*)(beta + chunk * 8); b1[k] = *(const float4*)(beta + chunk * 8 + 4);
+        }
+    }
+    int vi_loaded = -1;
     // every wave walks LN_RUN consecutive rows: the addvec row index is divided once per run and then only compared
     for (int64_t run0 = ((int64_t)blockIdx.x * 4 + wave) * LN_RUN; run0 < rows; run0 += (int64_t)gridDim.x * 4 * LN_RUN) {
       int vi = addvec ? (int)(run0 / rows_per_vec) : 0;
       int64_t vnext = addvec ? (int64_t)(vi + 1) * rows_per_vec : rows;
       const int64_t run1 = run0 + LN_RUN < rows ? run0 + LN_RUN : rows;
-      for (int64_t row = run0; row < run1; ++row) {
-        float v[LN_MAXCH][8];
-        if (row >= vnext) { ++vi; vnext += rows_per_vec; }
-        const float* av = addvec ? addvec + (int64_t)vi * addvec_ld : nullptr;
-        float s = 0.f;
+      for (int64_t rowg = run0; rowg < run1; rowg += R) {
+        float v[R][NCH][8];
+        uint4 raw[R][NCH];
+        // ---- all loads of the R rows first
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
-            const int chunk = lane + k * 64;
-            if (chunk < chunks) {
-                unpack8(*(const uint4*)(X + row * C + chunk * 8), v[k]);
-                if (av) {
-                    const float4 a0 = *(const float4*)(av + chunk * 8), a1 = *(const float4*)(av + chunk * 8 + 4);
-                    v[k][0] += a0.x; v[k][1] += a0.y; v[k][2] += a0.z; v[k][3] += a0.w;
-                    v[k][4] += a1.x; v[k][5] += a1.y; v[k][6] += a1.z; v[k][7] += a1.w;
-                    if (sum_out) {
-                        // the stored sum is bf16 (the residual stream dtype); normalise what is stored
-                        const uint4 pk = pack8(v[k]);
-                        *(uint4*)(sum_out + row * C + chunk * 8) = pk;
-                        unpack8(pk, v[k]);
-                    }
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = rowg + r < run1 ? rowg + r : run1 - 1;   // tail rows re-read the last row (not stored)
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int chunk = lane + k * 64;
+                if (chunk < chunks) raw[r][k] = *(const uint4*)(X + row * C + chunk * 8);
+            }
+        }
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = rowg + r;
+            const bool live = row < run1;
+            if (live && row >= vnext) { ++vi; vnext += rows_per_vec; }
+            if (addvec && vi != vi_loaded) {   // wave-uniform; once per rows_per_vec rows
+                const float* av = addvec + (int64_t)vi * addvec_ld;
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int chunk = lane + k * 64;
+                    if (chunk < chunks) { a0[k] = *(const float4*)(av + chunk * 8); a1[k] = *(const float4*)(av + chunk * 8 + 4); }
                 }
+                vi_loaded = vi;
+            }
+            s[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[k][e];
+            for (int k = 0; k < NCH; ++k) {
+                const int chunk = lane + k * 64;
+                if (chunk < chunks) {
+                    unpack8(raw[r][k], v[r][k]);
+                    if (addvec) {
+                        v[r][k][0] += a0[k].x; v[r][k][1] += a0[k].y; v[r][k][2] += a0[k].z; v[r][k][3] += a0[k].w;
+                        v[r][k][4] += a1[k].x; v[r][k][5] += a1[k].y; v[r][k][6] += a1[k].z; v[r][k][7] += a1[k].w;
+                        if (sum_out) {
+                            // the stored sum is bf16 (the residual stream dtype); normalise what is stored
+                            const uint4 pk = pack8(v[r][k]);
+                            if (live) *(uint4*)(sum_out + row * C + chunk * 8) = pk;
+                            unpack8(pk, v[r][k]);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[r] += v[r][k][e];
+                }
             }
         }
-        const float mean = wave_sum(s) * inv_c;
-        float q = 0.f;
+        float mean[R], q[R];
 #pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
+        for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * inv_c;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            q[r] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int chunk = lane + k * 64;
+                if (chunk < chunks) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = v[r][k][e] - mean[r]; q[r] += d * d; }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] = rsqrtf(wave_sum(q[r]) * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
             const int chunk = lane + k * 64;
             if (chunk < chunks) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
-            }
-        }
-        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
-#pragma unroll
-        for (int k = 0; k < LN_MAXCH; ++k) {
-            const int chunk = lane + k * 64;
-            if (chunk < chunks) {
-                const float4 g0 = *(const float4*)(gamma + chunk * 8), g1 = *(const float4*)(gamma + chunk * 8 + 4);
-                const float4 b0 = *(const float4*)(beta + chunk * 8), b1 = *(const float4*)(beta + chunk * 8 + 4);
-                float o[8];
-                o[0] = (v[k][0] - mean) * rstd * g0.x + b0.x; o[1] = (v[k][1] - mean) * rstd * g0.y + b0.y;
-                o[2] = (v[k][2] - mean) * rstd * g0.z + b0.z; o[3] = (v[k][3] - mean) * rstd * g0.w + b0.w;
-                o[4] = (v[k][4] - mean) * rstd * g1.x + b1.x; o[5] = (v[k][5] - mean) * rstd * g1.y + b1.y;
-                o[6] = (v[k][6] - mean) * rstd * g1.z + b1.z; o[7] = (v[k][7] - mean) * rstd * g1.w + b1.w;
-                *(uint4*)(out + row * C + chunk * 8) = pack8(o);
+                for (int r = 0; r < R; ++r) {
+                    const int64_t row = rowg + r;
+                    const float m = mean[r], rs = q[r];
+                    float o[8];
+                    o[0] = (v[r][k][0] - m) * rs * g0[k].x + b0[k].x; o[1] = (v[r][k][1] - m) * rs * g0[k].y + b0[k].y;
+                    o[2] = (v[r][k][2] - m) * rs * g0[k].z + b0[k].z; o[3] = (v[r][k][3] - m) * rs * g0[k].w + b0[k].w;
+                    o[4] = (v[r][k][4] - m) * rs * g1[k].x + b1[k].x; o[5] = (v[r][k][5] - m) * rs * g1[k].y + b1[k].y;
+                    o[6] = (v[r][k][6] - m) * rs * g1[k].z + b1[k].z; o[7] = (v[r][k][7] - m) * rs * g1[k].w + b1[k].w;
+                    if (row < run1) *(uint4*)(out + row * C + chunk * 8) = pack8(o);
+                }
             }
         }
       }
@@ -256,9 +322,32 @@ extern "C" int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const v
     if (splits < 1) splits = 1;
     const int rows_per_block = (rows_per_unit + splits - 1) / splits;
     splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
-                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, ab, silu, (uint16_t*)out);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1,
+                       C1, (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, ab, silu, (uint16_t*)out, nullptr, nullptr,
+                       0.f, 0.f);
     return wiw_check_launch("wiw_groupnorm_apply");
+}
+
+extern "C" int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                                         int rows_per_unit, const float* stats, const float* gamma, const float* beta,
+                                         float eps, int silu, void* out) {
+    WIW_REQUIRE(X1 && stats && gamma && beta && out, "groupnorm_apply_stats: null pointer");
+    WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_apply_stats: X2 iff C2 > 0");
+    const int C = C1 + C2;
+    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0, "groupnorm_apply_stats: channels must be %8 and C %32");
+    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_apply_stats: bad rows");
+    const int units = (int)(rows / rows_per_unit);
+    int splits = (4096 + units - 1) / units;
+    const int max_splits = (rows_per_unit + 15) / 16;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int rows_per_block = (rows_per_unit + splits - 1) / splits;
+    splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / GROUPS));
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1,
+                       C1, (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, stats, silu, (uint16_t*)out, gamma, beta,
+                       inv_count, eps);
+    return wiw_check_launch("wiw_groupnorm_apply_stats");
 }
 
 extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma,
@@ -268,8 +357,13 @@ extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int
     WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LN_MAXCH * 64 * 8, "layernorm: C must be %8 and <= 2048");
     WIW_REQUIRE(addvec == nullptr || (rows_per_vec > 0 && addvec_ld % 4 == 0), "layernorm: bad addvec layout");
     WIW_REQUIRE(sum_out == nullptr || addvec != nullptr, "layernorm: sum_out requires addvec");
-    hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows, 4 * LN_RUN, 2048 * 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint16_t*)X, rows, C, gamma, beta, eps, addvec, addvec_ld, rows_per_vec,
-                       (uint16_t*)sum_out, (uint16_t*)out);
+    const dim3 grid(grid_for(rows, 4 * LN_RUN, 256 * 8));   // <= 8 blocks per CU, grid-stride over runs of LN_RUN rows
+#define WIW_LN_LAUNCH(NCH, R)                                                                                        \
+    hipLaunchKernelGGL((layernorm_kernel<NCH, R>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, \
+                       gamma, beta, eps, addvec, addvec_ld, rows_per_vec, (uint16_t*)sum_out, (uint16_t*)out)
+    if (C <= 512) WIW_LN_LAUNCH(1, 4);
+    else if (C <= 1024) WIW_LN_LAUNCH(2, 2);
+    else WIW_LN_LAUNCH(4, 1);
+#undef WIW_LN_LAUNCH
     return wiw_check_launch("wiw_layernorm_bf16");
 }

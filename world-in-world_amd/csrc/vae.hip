@@ -12,12 +12,6 @@ namespace {
 constexpr int SM_THREADS = 256;
 constexpr int SM_MAXV = 16;   // float4 per thread held in registers -> cols <= 256 * 4 * 16 = 16384
 
-WIW_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 __global__ __launch_bounds__(SM_THREADS) void softmax_rows_kernel(const float* __restrict__ X, int64_t ldx, int cols,
                                                                    uint16_t* __restrict__ P, int64_t ldp) {
     __shared__ float red[2][SM_THREADS / 64];
