@@ -400,3 +400,83 @@ def test_gemm_big_tile_conv_modes(hip):
     hip.gemm(dev_bf(nhwc(xl)), dev_bf(wt2.permute(0, 2, 3, 1).reshape(640, -1)), o2, M=Mo, N=640, K=9 * c, C1=c,
              mode=H.A_CONV3X3_S2, H=h, Wd=2 * w)
     check(from_nhwc(o2, 6, h, 2 * w), F.conv2d(xl, wt2, None, stride=2, padding=1), what="big-tile stride-2 conv")
+
+
+# ----------------------------------------------------------------------------------------------
+# the HUGE tile configuration (256 x 320, 4 x 2 waves of 64 x 160, gemm_huge.hip) takes bf16-output GEMMs with
+# N % 320 == 0 and >= 200 output tiles
+# ----------------------------------------------------------------------------------------------
+def test_gemm_huge_tile_dense(hip):
+    M, N, K = 256 * 210 + 37, 320, 704      # ragged last M tile; 11 K tiles
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    bias, r1, r2 = rnd(N, seed=3), bf(rnd(M, N, seed=5)), bf(rnd(M, N, seed=6))
+    rpv = 1024
+    rowvec = rnd((M + rpv - 1) // rpv, N + 8, seed=4)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K, bias=dev_f(bias), res1=dev_bf(r1), ldr1=N, beta1=1.0)
+    check(out, a @ w.t() + bias + r1, what="huge-tile gemm + bias + residual")
+    # the AlphaBlender form: alpha * (acc + bias + rowvec[frame]) + beta1 * res1 + beta2 * res2
+    hip.gemm(dev_bf(a), dev_bf(w), out, M=M, N=N, K=K, C1=K, bias=dev_f(bias), rowvec=dev_f(rowvec), rowvec_ld=N + 8,
+             rows_per_vec=rpv, alpha=0.3, res1=dev_bf(r1), ldr1=N, beta1=0.3, res2=dev_bf(r2), ldr2=N, beta2=0.7)
+    rv = rowvec[:, :N].repeat_interleave(rpv, dim=0)[:M]
+    check(out, 0.3 * (a @ w.t() + bias + rv) + 0.3 * r1 + 0.7 * r2, what="huge-tile gemm blend epilogue")
+    for K1 in (640,):  # the shortest K the HUGE tile takes (10 K tiles)
+        hip.gemm(dev_bf(a[:, :K1].contiguous()), dev_bf(w[:, :K1].contiguous()), out, M=M, N=N, K=K1, C1=K1)
+        check(out, a[:, :K1] @ w[:, :K1].t(), what=f"huge-tile gemm K={K1}")
+    # two N tiles (both wave columns of a second tile), concat input, back-to-back tiles per block
+    M2, N2 = 256 * 110 + 8, 640
+    a1, a2 = bf(rnd(M2, 320, seed=7)), bf(rnd(M2, 384, seed=8))
+    w2 = bf(rnd(N2, 704, seed=9) / math.sqrt(704))
+    o2 = torch.empty(M2, N2, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a1), dev_bf(w2), o2, M=M2, N=N2, K=704, C1=320, A2=dev_bf(a2), C2=384)
+    check(o2, torch.cat([a1, a2], dim=1) @ w2.t(), what="huge-tile gemm, 2 N tiles, concat A")
+
+
+def test_gemm_huge_tile_geglu(hip):
+    from wiw_amd import hip as H
+    from wiw_amd.unet import pack_geglu
+
+    Cn, Mg = 640, 256 * 25 + 130           # N packed = 5120 -> 16 N tiles x 26 M tiles
+    x = bf(rnd(Mg, Cn, seed=6))
+    wg, bg = rnd(8 * Cn, Cn, seed=7) / math.sqrt(Cn), rnd(8 * Cn, seed=8)
+    wp, bp, _ = pack_geglu(wg, bg)
+    assert wp.shape[0] % 320 == 0
+    og = torch.empty(Mg, 4 * Cn, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(x), dev_bf(wp), og, M=Mg, N=wp.shape[0], K=Cn, C1=Cn, bias=dev_f(bp), epilogue=H.EPI_GEGLU, n_out=4 * Cn)
+    hh = x @ bf(wg).t() + bg
+    val, gate = hh.chunk(2, dim=-1)
+    check(og, val * F.gelu(gate), what="huge-tile geglu")
+
+
+def test_gemm_huge_tile_conv_modes(hip):
+    from wiw_amd import hip as H
+
+    n, c, cout, h, w = 28, 256, 320, 32, 64         # M = 57344 -> 224 tiles; K = 2304 (3x3), 768 (temporal)
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(cout, c, 3, 3, seed=2) / math.sqrt(9 * c))
+    b = rnd(cout, seed=3)
+    wk = dev_bf(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+    xt = dev_bf(nhwc(x))
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(xt, wk, out, M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+    check(from_nhwc(out, n, h, w), F.conv2d(x, wt, b, padding=1), what="huge-tile conv3x3")
+    wtt = bf(rnd(cout, c, 3, 1, 1, seed=4) / math.sqrt(3 * c))
+    wkt = dev_bf(wtt[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, -1))
+    hip.gemm(xt, wkt, out, M=M, N=cout, K=3 * c, C1=c, mode=H.A_CONV_T3, H=h, Wd=w, T=7, bias=dev_f(b))
+    x5 = x.reshape(4, 7, c, h, w).permute(0, 2, 1, 3, 4)
+    ref = F.conv3d(x5, wtt, b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(n, cout, h, w)
+    check(from_nhwc(out, n, h, w), ref, what="huge-tile temporal conv")
+    xs = bf(rnd(n, c, h // 2, w // 2, seed=5))
+    hip.gemm(dev_bf(nhwc(xs)), wk, out, M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3_UP, H=h, Wd=w, bias=dev_f(b))
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+    check(from_nhwc(out, n, h, w), ref, what="huge-tile up-conv")
+    xl = bf(rnd(7, c, 2 * h, 4 * w, seed=6))         # 7 frames of 64 x 256 -> 32 x 128 outputs, M = 28672, 2 N tiles
+    Mo = 7 * h * (2 * w)
+    o2 = torch.empty(Mo, 640, dtype=torch.bfloat16, device=DEV)
+    wt2 = bf(rnd(640, c, 3, 3, seed=7) / math.sqrt(9 * c))
+    wk2 = dev_bf(wt2.permute(0, 2, 3, 1).reshape(640, -1))
+    hip.gemm(dev_bf(nhwc(xl)), wk2, o2, M=Mo, N=640, K=9 * c, C1=c, mode=H.A_CONV3X3_S2, H=h, Wd=2 * w)
+    check(from_nhwc(o2, 7, h, 2 * w), F.conv2d(xl, wt2, None, stride=2, padding=1), what="huge-tile stride-2 conv")
+    hip.gemm(dev_bf(nhwc(xl)), wk2, o2, M=Mo, N=640, K=9 * c, C1=c, mode=H.A_CONV3X3_S2P, H=h, Wd=2 * w)
+    check(from_nhwc(o2, 7, h, 2 * w), F.conv2d(F.pad(xl, (0, 1, 0, 1)), wt2, None, stride=2), what="huge-tile stride-2 (0,1,0,1) conv")

@@ -35,6 +35,10 @@
 
 #include "common.h"
 
+// 256 x 320 tile variant (gemm_huge.hip)
+bool wiw_gemm_huge_ok(const WiwGemmArgs& a);
+int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a);
+
 namespace {
 
 constexpr int BN = 160, BK = 64;
@@ -683,8 +687,9 @@ inline bool use_big_tile(const WiwGemmArgs& a) {
 
 template <int MODE>
 int launch(hipStream_t s, const WiwGemmArgs& a) {
-    static const char* force = getenv("WIW_GEMM_TILE");   // tuning knob: "big" / "small" overrides the heuristic
-    const bool big = force ? (force[0] == 'b') : use_big_tile(a);
+    static const char* force = getenv("WIW_GEMM_TILE");   // tuning knob: "huge" / "big" / "small" overrides the heuristic
+    if ((!force || force[0] == 'h') && wiw_gemm_huge_ok(a)) return wiw_gemm_huge_launch(s, a);   // gemm_huge.hip
+    const bool big = force ? (force[0] != 's') : use_big_tile(a);
     if (MODE == WIW_A_DENSE && (a.epilogue & WIW_EPI_GEGLU))
         return big ? launch_cfg<WIW_A_DENSE, 8, 3, true>(s, a, 1) : launch_cfg<WIW_A_DENSE, 4, 2, true>(s, a, 2);
     return big ? launch_cfg<MODE, 8, 3, false>(s, a, 1) : launch_cfg<MODE, 4, 2, false>(s, a, 2);

@@ -1,0 +1,495 @@
+// 256 x 320 x 64 output tile ("HUGE") of the bf16 MFMA GEMM / implicit-GEMM convolution (gfx950).
+//
+// Why a second tile shape: in gemm.hip's 256x160 tile every wave owns 32 rows x 160 columns, i.e. per 32-deep k-step
+// it reads 2 + 10 fragments from LDS for 20 MFMAs and the block moves 52 KiB of operands per 5.2 MFLOP through the
+// LDS-DMA; ablations there show the operand path (DMA issue + ds_read + barriers) alone takes 1.45x the MFMA time.
+// Here 8 waves form a 4 (M) x 2 (N) grid of 64 x 160 wave tiles on a 256 x 320 block tile:
+//     per k-step and wave: 4 + 10 fragment reads for 40 MFMAs          (0.35 vs 0.60 ds_read_b128 per MFMA)
+//     per K tile and block: 72 KiB of LDS-DMA for 10.5 MFLOP           (9 vs 7 DMA instructions per wave for 2x the MFMAs)
+// The wave still owns 160 consecutive columns, so the GEGLU value | gate pairing (tiles of 160 = [80 | 80]) and the
+// per-wave epilogue of gemm.hip carry over unchanged (4 passes of 16 rows instead of 2).
+//
+// Budget: 160 accumulator registers + 4 A and 5 B fragments (the 10 W fragments of a k-step are read in two halves)
+// inside the 256-VGPR budget of 2 waves / SIMD; LDS ring = 2 stages x 72 KiB (144 of 160 KiB), one K tile of DMA in
+// flight behind the one being consumed.
+//
+// Schedule per K tile (8 slots, a raw s_barrier between slots; waves 4..7 run one slot behind waves 0..3 so that on
+// every SIMD one wave reads LDS / issues DMA while its partner issues 20 MFMAs back to back):
+//     R(k0: A, W[0:5]) | M | R(k0: W[5:10]) | M | R(k1: A, W[0:5]) | M | R(k1: W[5:10]), confirm next tile | M
+// DMA of K tile kt+1 (9 instructions per wave) is issued 2|2|2|2|1 in slots 0..4 of tile kt.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HM = 256, HN = 320, HK = 64;
+constexpr int HA_BYTES = HM * HK * 2;            // 32768
+constexpr int HB_BYTES = HN * HK * 2;            // 40960
+constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 73728
+constexpr int H_SMEM = 2 * HSTAGE;               // 147456
+constexpr int HSTG_ROWB = 336;                   // bytes per staged bf16 row (160 cols + 16 B skew)
+constexpr int HSTG_WAVE = 16 * HSTG_ROWB;        // 5376 B per wave
+static_assert(8 * HSTG_WAVE <= HSTAGE, "epilogue staging must fit in one ring stage");
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
+
+__device__ uint4 g_dump_h[512 * 64];   // sink of the unconditional epilogue stores (see gemm.hip)
+
+template <int N>
+WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+WIW_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <int MODE, bool GE>
+__global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;       // wave (wm, wn) owns rows wm*64.., columns wn*160.. of the block tile
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- tile schedule: per-XCD sm x sn super-tiles (identical to gemm.hip, with this tile shape)
+    const int Nt = (p.N + HN - 1) / HN;
+    const int Mt = (p.M + HM - 1) / HM;
+    const int total = Mt * Nt;
+    const int nb = gridDim.x;
+    const bool super = (nb & 7) == 0 && nb >= 64;
+    const int bpx = nb >> 3;
+    int sn = 1;
+    {
+        int64_t best = -1;
+        for (int c = 1; c <= 8; c *= 2) {
+            if (c > bpx || (c > 1 && c > Nt)) break;
+            const int cm = bpx / c;
+            const int64_t slots = (int64_t)((Nt + c - 1) / c) * c * ((Mt + cm - 1) / cm) * cm;
+            if (best < 0 || slots <= best) { best = slots; sn = c; }
+        }
+    }
+    const int sm = super ? bpx / sn : 1;
+    const int SNt = (Nt + sn - 1) / sn, SMt = (Mt + sm - 1) / sm;
+    const int n_super = SNt * SMt;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    int q = xcd, t_end = 0;
+    auto next_tile = [&](int& pos) -> int {
+        if (!super) return pos < t_end ? pos : -1;
+        for (; pos < n_super; pos += 8) {
+            const int tm = (pos / SNt) * sm + jx / sn, tn = (pos % SNt) * sn + jx % sn;
+            if (tm < Mt && tn < Nt) return tm * Nt + tn;
+        }
+        return -1;
+    };
+    if (!super) {
+        const int qq = nb >> 3, r = nb & 7, idx = blockIdx.x >> 3;
+        const int lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+        q = (int)(((int64_t)lb * total) / nb);
+        t_end = (int)(((int64_t)(lb + 1) * total) / nb);
+    }
+    int t = next_tile(q);
+    if (t < 0) return;
+
+    // ---- loader state
+    const int rsub = lane >> 3;
+    const int chunk = (lane & 7) ^ (rsub & 7);
+    const char* const Ab = (const char*)p.A;
+    const char* const A2b = (const char*)p.A2;
+    const char* const zeros = (const char*)p.zeros;
+    const int HW = p.H * p.Wd;
+    const int Ctot = p.C1 + p.C2;
+    const int nk = p.K / HK;
+
+    int a_m[4];
+    bool a_ok[4];
+    int a_fb[4], a_y[4], a_x[4];
+    const char* w_row[5];
+    int ld_tap = 0, ld_cc = 0, ld_kt = 0;
+
+    auto setup_loader = [&](int tile) {
+        const int m0 = (tile / Nt) * HM, n0 = (tile % Nt) * HN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (wave * 4 + i) * 8 + rsub;
+            a_m[i] = m;
+            a_ok[i] = m < p.M;
+            a_fb[i] = 0; a_y[i] = 0; a_x[i] = 0;
+            if (MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P || MODE == WIW_A_CONV3X3_UP) {
+                const int n = m / HW, rem = m - n * HW;
+                a_y[i] = rem / p.Wd;
+                a_x[i] = rem - a_y[i] * p.Wd;
+                a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW
+                          : ((MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) ? n * HW * 4 : n * (HW >> 2));
+            } else if (MODE == WIW_A_CONV_T3) {
+                a_y[i] = (m / HW) % p.T;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int n = n0 + (wave * 5 + i) * 8 + rsub;
+            n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
+            w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+        }
+    };
+
+    auto a_src = [&](int i, int tap, int cc) -> const char* {
+        if (MODE == WIW_A_DENSE) {
+            if (!a_ok[i]) return zeros;
+            if (cc < p.C1) return Ab + ((int64_t)a_m[i] * p.C1 + cc + chunk * 8) * 2;
+            return A2b + ((int64_t)a_m[i] * p.C2 + (cc - p.C1) + chunk * 8) * 2;
+        } else if (MODE == WIW_A_CONV_T3) {
+            const int tt = a_y[i] + tap - 1;
+            if (!a_ok[i] || (unsigned)tt >= (unsigned)p.T) return zeros;
+            return Ab + (((int64_t)a_m[i] + (int64_t)(tap - 1) * HW) * p.C1 + cc + chunk * 8) * 2;
+        } else {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            int row;
+            bool ok;
+            if (MODE == WIW_A_CONV3X3) {
+                const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                row = a_fb[i] + iy * p.Wd + ix;
+            } else if (MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) {
+                constexpr int o = (MODE == WIW_A_CONV3X3_S2P) ? 1 : 0;
+                const int iy = 2 * a_y[i] + dy + o, ix = 2 * a_x[i] + dx + o;
+                ok = (unsigned)iy < (unsigned)(2 * p.H) && (unsigned)ix < (unsigned)(2 * p.Wd);
+                row = a_fb[i] + iy * (2 * p.Wd) + ix;
+            } else {
+                const int uy = a_y[i] + dy, ux = a_x[i] + dx;
+                ok = (unsigned)uy < (unsigned)p.H && (unsigned)ux < (unsigned)p.Wd;
+                row = a_fb[i] + (uy >> 1) * (p.Wd >> 1) + (ux >> 1);
+            }
+            if (!a_ok[i] || !ok) return zeros;
+            return Ab + ((int64_t)row * p.C1 + cc + chunk * 8) * 2;
+        }
+    };
+
+    // the 9 DMA instructions of a K tile in five parts: A0 A1 | A2 A3 | W0 W1 | W2 W3 | W4 (+ advance the K cursor)
+    auto issue_part = [&](int stage, auto part_tag) {
+        constexpr int part = decltype(part_tag)::value;
+        char* sA = smem + stage * HSTAGE + wave * 4 * 1024;
+        char* sB = smem + stage * HSTAGE + HA_BYTES + wave * 5 * 1024;
+        if (part < 2) {
+            glds16(a_src(2 * part, ld_tap, ld_cc), sA + (2 * part) * 1024);
+            glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
+        } else if (part < 4) {
+            const int i = 2 * (part - 2);
+            glds16(w_row[i] + (int64_t)ld_kt * (HK * 2), sB + i * 1024);
+            glds16(w_row[i + 1] + (int64_t)ld_kt * (HK * 2), sB + (i + 1) * 1024);
+        } else {
+            glds16(w_row[4] + (int64_t)ld_kt * (HK * 2), sB + 4 * 1024);
+            ++ld_kt;
+            ld_cc += HK;
+            if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
+        }
+    };
+    auto issue_all = [&](int stage) {
+        issue_part(stage, IC<0>{}); issue_part(stage, IC<1>{}); issue_part(stage, IC<2>{});
+        issue_part(stage, IC<3>{}); issue_part(stage, IC<4>{});
+    };
+
+    f32x4 acc[4][10];
+    bf16x8 fa[4], fb[5];
+    auto read_a = [&](int stage, int kk) {
+        const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
+        const char* sA = smem + stage * HSTAGE + (wm * 64 + frow) * 128 + sw;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 2048);
+    };
+    auto read_b = [&](int stage, int kk, auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+        const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
+        const char* sB = smem + stage * HSTAGE + HA_BYTES + (wn * 160 + h * 80 + frow) * 128 + sw;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) fb[j] = *(const bf16x8*)(sB + j * 2048);
+    };
+    auto mma = [&](auto h_tag) {
+        constexpr int h = decltype(h_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)   // swapped operands: lane gets n = 16*(5h+j) + 4*fq + r, m = 16*mi + frow
+                acc[mi][h * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[mi], acc[mi][h * 5 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const bool lag = wave >= 4;
+
+    const bool scale_acc = p.alpha != 1.0f;
+    const int n_valid = GE ? p.n_out : p.N;
+    const uint16_t* r1 = (const uint16_t*)p.res1;
+    const uint16_t* r2 = (const uint16_t*)p.res2;
+
+    // ---- prologue: K tile 0 of the first output tile
+    setup_loader(t);
+    int st_c = 0;
+    int pending_stores = 0;   // 0 / 12 (GEGLU) / 24
+    issue_all(0);
+
+    while (t >= 0) {
+        const int tile_n = t % Nt;
+        const int m0 = (t / Nt) * HM;
+        setup_loader(t);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 10; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // K tile 0 was issued BEFORE the previous tile's epilogue stores: it has landed once at most those stores are
+        // outstanding (in-order retirement; their number is a compile-time constant because they are unconditional)
+        if (pending_stores == 24) wait_vmcnt<24>();
+        else if (pending_stores == 12) wait_vmcnt<12>();
+        else wait_vmcnt<0>();
+
+        // Sync proof (same as gemm.hip with 8 slots): the lagging group's local barrier b is the leading group's b+1.
+        //   * DMA into the other stage (held tile kt-1) starts after local barrier 8kt: every wave has passed its
+        //     barrier 8kt-1, i.e. finished slot 8(kt-1)+6 — the last read of that stage;
+        //   * tile kt+1 is first read in the leading group's slot 8(kt+1) = after the lagging group's barrier 8kt+7,
+        //     so every wave confirms its DMA share before its local barrier 8kt+7 (end of slot 6).
+        if (lag) slot_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            const int si = st_c ^ 1;
+            slot_barrier();                                    // 8kt
+            if (more) issue_part(si, IC<0>{});
+            read_a(st_c, 0);
+            read_b(st_c, 0, IC<0>{});
+            slot_barrier();                                    // +1
+            if (more) issue_part(si, IC<1>{});
+            mma(IC<0>{});
+            slot_barrier();                                    // +2
+            if (more) issue_part(si, IC<2>{});
+            read_b(st_c, 0, IC<1>{});
+            slot_barrier();                                    // +3
+            if (more) issue_part(si, IC<3>{});
+            mma(IC<1>{});
+            slot_barrier();                                    // +4
+            if (more) issue_part(si, IC<4>{});
+            read_a(st_c, 1);
+            read_b(st_c, 1, IC<0>{});
+            slot_barrier();                                    // +5
+            mma(IC<0>{});
+            slot_barrier();                                    // +6
+            read_b(st_c, 1, IC<1>{});
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<0>();                               // my share of K tile kt+1 (and anything older) has landed
+            }
+            slot_barrier();                                    // +7
+            mma(IC<1>{});
+            st_c ^= 1;
+        }
+        if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
+
+        // ---- epilogue, part 1: bias + first pass operands, then the next tile's first K tile, then the 4 passes
+        constexpr int ITEMS_P = 6, ITEMS_G = 3;
+        constexpr int CHr = GE ? 10 : 20, RPSr = GE ? 6 : 3;
+        const int lch = lane % CHr, lrow = lane / CHr;
+        const int tile_nw = tile_n * 2 + wn;                 // index of this wave's 160-column tile
+        const int ncol = (GE ? tile_nw * 80 : tile_nw * 160) + lch * 8;
+        const bool lane_ok = lrow < RPSr && ncol < n_valid;
+        const int mw0 = m0 + wm * 64;
+        float4 bvf[10];
+        float4 c0, c1, rv0[2], rv1[2];
+        uint4 q1[2][ITEMS_P];
+        auto load_rv = [&](auto mi_tag) {
+            constexpr int mi = decltype(mi_tag)::value;
+            const int mr = mw0 + mi * 16;
+            const int vi = (mr < p.M ? mr : p.M - 1) / p.rows_per_vec;
+            const float* pa = lane_ok ? p.rowvec + (int64_t)vi * p.rowvec_ld + ncol : (const float*)zeros;
+            rv0[mi & 1] = *(const float4*)pa;
+            rv1[mi & 1] = *(const float4*)(lane_ok ? pa + 4 : (const float*)zeros);
+        };
+        auto load_q1 = [&](auto mi_tag) {
+            constexpr int mi = decltype(mi_tag)::value;
+#pragma unroll
+            for (int k = 0; k < ITEMS_P; ++k) {
+                const int rr = lrow + k * 3;
+                const int m = mw0 + mi * 16 + rr;
+                const bool ok = lane_ok && rr < 16 && m < p.M;
+                q1[mi & 1][k] = *(const uint4*)(ok ? (const char*)(r1 + (int64_t)m * p.ldr1 + ncol) : zeros);
+            }
+        };
+        c0 = float4{0.f, 0.f, 0.f, 0.f}; c1 = c0; rv0[0] = c0; rv0[1] = c0; rv1[0] = c0; rv1[1] = c0;
+        const bool rv_fast = p.rowvec != nullptr && (p.rows_per_vec % 16) == 0;
+        if (GE) {
+            if (p.bias) {
+#pragma unroll
+                for (int ni = 0; ni < 10; ++ni) bvf[ni] = *(const float4*)(p.bias + tile_nw * 160 + ni * 16 + fq * 4);
+            }
+        } else {
+            const float* zf = (const float*)zeros;
+            if (p.bias) {
+                const float* bp = lane_ok ? p.bias + ncol : zf;
+                c0 = *(const float4*)bp; c1 = *(const float4*)(lane_ok ? bp + 4 : zf);
+            }
+            if (rv_fast) load_rv(IC<0>{});
+            if (r1) load_q1(IC<0>{});
+        }
+
+        int q_next = q + (super ? 8 : 1);
+        const int t_next = next_tile(q_next);
+        if (t_next >= 0) {
+            setup_loader(t_next);
+            ld_tap = 0; ld_cc = 0; ld_kt = 0;
+            issue_all(st_c);            // stage st_c is free (it held K tile nk-2); staging uses the other one
+        }
+        pending_stores = 0;
+
+        // ---- epilogue, part 2 (per wave, no block barrier)
+        {
+            char* stg = smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE;
+            uint4* dump = g_dump_h + (blockIdx.x & 511) * 64 + lane;
+            auto pass = [&](auto mi_tag) {
+                constexpr int mi = decltype(mi_tag)::value;
+                constexpr int pb = mi & 1;
+                constexpr int RPS = GE ? 6 : 3;
+                constexpr int ITEMS = GE ? ITEMS_G : ITEMS_P;
+                const int mrow0 = mw0 + mi * 16;
+                char* wrow = stg + frow * HSTG_ROWB + fq * 8;
+                if (GE) {
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
+                        if (p.bias) {
+                            v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
+                            g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
+                        }
+                        uint2 pk;
+                        pk.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
+                        pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+                        *(uint2*)(wrow + ni * 32) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 10; ++ni) {
+                        f32x4 v = acc[mi][ni];
+                        if (scale_acc) { v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha; }
+                        uint2 pk;
+                        pk.x = pack2bf(v[0], v[1]);
+                        pk.y = pack2bf(v[2], v[3]);
+                        *(uint2*)(wrow + ni * 32) = pk;
+                    }
+                }
+                wave_lds_sync();
+                if (!GE && mi < 3) {   // operands of the next pass behind this pass's math
+                    if (rv_fast) load_rv(IC<(mi + 1) & 3>{});
+                    if (r1) load_q1(IC<(mi + 1) & 3>{});
+                }
+#pragma unroll
+                for (int k = 0; k < ITEMS; ++k) {
+                    const int rr = lrow + k * RPS;
+                    const int m = mrow0 + rr;
+                    const bool ok = lane_ok && rr < 16 && m < p.M;
+                    const uint4 sv = *(const uint4*)(stg + rr * HSTG_ROWB + lch * 16);
+                    uint4 ov = sv;
+                    if (!GE) {
+                        float v[8], f[8];
+                        unpack8(sv, v);
+                        if (p.rowvec && !rv_fast) {
+                            const float* rv = p.rowvec + (int64_t)((ok ? m : 0) / p.rows_per_vec) * p.rowvec_ld + (ok ? ncol : 0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += ok ? p.alpha * rv[e] : 0.f;
+                        }
+                        const float al = p.alpha;
+                        v[0] += al * (c0.x + rv0[pb].x); v[1] += al * (c0.y + rv0[pb].y);
+                        v[2] += al * (c0.z + rv0[pb].z); v[3] += al * (c0.w + rv0[pb].w);
+                        v[4] += al * (c1.x + rv1[pb].x); v[5] += al * (c1.y + rv1[pb].y);
+                        v[6] += al * (c1.z + rv1[pb].z); v[7] += al * (c1.w + rv1[pb].w);
+                        if (r1) {
+                            unpack8(q1[pb][k], f);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += p.beta1 * f[e];
+                        }
+                        if (r2) {
+                            unpack8(*(const uint4*)(ok ? (const char*)(r2 + (int64_t)m * p.ldr2 + ncol) : zeros), f);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += p.beta2 * f[e];
+                        }
+                        ov = pack8(v);
+                    }
+                    uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + ncol) : dump;
+                    __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
+                    __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+                }
+                wave_lds_sync();
+            };
+            pass(IC<0>{}); pass(IC<1>{}); pass(IC<2>{}); pass(IC<3>{});
+            if (r2 == nullptr) pending_stores = GE ? 4 * ITEMS_G : 4 * ITEMS_P;
+        }
+        t = t_next;
+        q = q_next;
+    }
+}
+
+template <int MODE, bool GE>
+int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
+    static bool attr_set = false;
+    static int num_cu = 256;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) !=
+            hipSuccess) {
+            wiw_set_error("hipFuncSetAttribute(gemm_huge) failed");
+            return WIW_ELAUNCH;
+        }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
+    int64_t grid = num_cu;
+    if (tiles < grid) grid = tiles;   // one tile per block (a grid that is not a multiple of 8 uses contiguous ranges)
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a);
+    return wiw_check_launch("wiw_gemm_bf16(huge)");
+}
+
+}  // namespace
+
+// Shapes the 256x320 tile takes: bf16 output through the staged epilogue, full 320-wide N tiles, enough tiles to give
+// (nearly) every CU one.  Everything else stays on gemm.hip's tiles.
+bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
+    const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
+    if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_OUT_F32)) return false;
+    if (a.N % HN != 0) return false;
+    const int n_valid = ge ? a.n_out : a.N;
+    if (n_valid % 8 || a.ldo % 8) return false;
+    if (a.res1 && a.ldr1 % 8) return false;
+    if (a.res2 && a.ldr2 % 8) return false;
+    if ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) || a.rowvec_ld % 4) return false;
+    // short K (< 10 K tiles): the output tile's epilogue dominates and the smaller tile's finer granularity wins
+    // (measured: K = 320 GEGLU -6 %, plain +-2 %; K >= 640 +4...+28 %)
+    if (a.K < 640 && !getenv("WIW_GEMM_HUGE_ANYK")) return false;
+    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * (a.N / HN);
+    return tiles >= 200;
+}
+
+int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
+    const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
+    switch (a.mode) {
+        case WIW_A_DENSE: return ge ? launch_huge<WIW_A_DENSE, true>(s, a) : launch_huge<WIW_A_DENSE, false>(s, a);
+        case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false>(s, a);
+        case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false>(s, a);
+        case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false>(s, a);
+        case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false>(s, a);
+        default: return launch_huge<WIW_A_CONV_T3, false>(s, a);
+    }
+}
