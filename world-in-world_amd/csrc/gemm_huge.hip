@@ -18,6 +18,9 @@
 //     R(k0: A, W[0:5]) | M | R(k0: W[5:10]) | M | R(k1: A, W[0:5]) | M | R(k1: W[5:10]), confirm next tile | M
 // DMA of K tile kt+1 (9 instructions per wave) is issued 2|2|2|2|1 in slots 0..4 of tile kt.
 #include <stdlib.h>
+#ifndef WIW_ABLATE
+#define WIW_ABLATE 0
+#endif
 
 #include <type_traits>
 
@@ -53,7 +56,7 @@ WIW_DEV void wave_lds_sync() {
 template <int V> using IC = std::integral_constant<int, V>;
 
 template <int MODE, bool GE>
-__global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -99,6 +102,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p) 
     }
     int t = next_tile(q);
     if (t < 0) return;
+    if (stagger > 0) {   // de-phase the blocks (tuning knob WIW_GEMM_STAGGER): see gemm.hip
+        const int phase = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 cycles per iteration
+    }
 
     // ---- loader state
     const int rsub = lane >> 3;
@@ -179,11 +186,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p) 
         constexpr int part = decltype(part_tag)::value;
         char* sA = smem + stage * HSTAGE + wave * 4 * 1024;
         char* sB = smem + stage * HSTAGE + HA_BYTES + wave * 5 * 1024;
-        if (part < 2) {
+        if constexpr (part < 2) {
             glds16(a_src(2 * part, ld_tap, ld_cc), sA + (2 * part) * 1024);
             glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
-        } else if (part < 4) {
-            const int i = 2 * (part - 2);
+        } else if constexpr (part < 4) {
+            constexpr int i = 2 * (part - 2);
             glds16(w_row[i] + (int64_t)ld_kt * (HK * 2), sB + i * 1024);
             glds16(w_row[i + 1] + (int64_t)ld_kt * (HK * 2), sB + (i + 1) * 1024);
         } else {
@@ -425,9 +432,17 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p) 
                         }
                         ov = pack8(v);
                     }
+#if WIW_ABLATE == 21
+                    uint4* dst = dump;
+#else
                     uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + ncol) : dump;
+#endif
+#if WIW_ABLATE == 20
+                    *dst = ov;
+#else
                     __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
                     __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+#endif
                 }
                 wave_lds_sync();
             };
@@ -458,7 +473,9 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
     int64_t grid = num_cu;
     if (tiles < grid) grid = tiles;   // one tile per block (a grid that is not a multiple of 8 uses contiguous ranges)
-    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a);
+    static const char* stg_env = getenv("WIW_GEMM_STAGGER");
+    const int stagger = stg_env ? atoi(stg_env) : 0;
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }
 
