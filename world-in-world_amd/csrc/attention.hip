@@ -57,26 +57,42 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         qf[f][1] = *(const bf16x8*)(src + 32);
     }
 
-    // ---- LDS-DMA sources for this lane
+    // ---- LDS-DMA sources for this lane: per-lane source pointers advance by one KV tile per iteration (64 keys:
+    // 64 rows of QK for K, 128 bytes of a V^T row); only the last tile needs the clamped / zero-filled form.
     const int rsub = lane >> 3, pos = lane & 7;
     const int nkt = (S + KB - 1) / KB;
+    const char* kp[2];
+    const char* vp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 16 + i * 8 + rsub;            // row of the tile (key for K, d for V^T)
+        kp[i] = (const char*)(QK + (row0 + r) * ldqk + k_col_off + h * 64 + (pos ^ (r & 7)) * 8);
+        vp[i] = (const char*)(Vt + (int64_t)(h * 64 + r) * ldvt + row0 + (pos ^ ((r >> 1) & 7)) * 8);
+    }
+    const int64_t kstep = (int64_t)KB * ldqk * 2;
     auto issue = [&](int stage, int kt) {
         char* sK = smem + stage * KV_STAGE + wave * 2 * 1024;
         char* sV = smem + stage * KV_STAGE + 8192 + wave * 2 * 1024;
+        if ((kt + 1) * KB <= S) {   // full tile (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wave * 16 + i * 8 + rsub;            // row of the tile (key for K, d for V^T)
-            // K: chunk swizzle by (r & 7)
-            int key = kt * KB + r;
-            key = key < S ? key : S - 1;
-            const int ck = pos ^ (r & 7);
-            glds16((const char*)(QK + (row0 + key) * ldqk + k_col_off + h * 64 + ck * 8), sK + i * 1024);
-            // V^T: chunk swizzle by ((r >> 1) & 7); chunks past the end of the frame read zeros
-            const int cv = pos ^ ((r >> 1) & 7);
-            const int key0 = kt * KB + cv * 8;
-            const char* vsrc = key0 < S ? (const char*)(Vt + (int64_t)(h * 64 + r) * ldvt + row0 + key0) : zeros;
-            glds16(vsrc, sV + i * 1024);
+            for (int i = 0; i < 2; ++i) {
+                glds16(kp[i], sK + i * 1024);
+                glds16(vp[i], sV + i * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wave * 16 + i * 8 + rsub;
+                // K rows past the end re-read the last key (masked to -inf below); V^T chunks past the end read zeros
+                const int key = kt * KB + r;
+                const char* ksrc = key < S ? kp[i] : kp[i] - (int64_t)(key - (S - 1)) * ldqk * 2;
+                glds16(ksrc, sK + i * 1024);
+                const int key0 = kt * KB + (pos ^ ((r >> 1) & 7)) * 8;
+                glds16(key0 < S ? vp[i] : zeros, sV + i * 1024);
+            }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { kp[i] += kstep; vp[i] += KB * 2; }
     };
 
     f32x4 o[4][2];
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                     for (int r = 0; r < 4; ++r)
                         if (kt * KB + kf * 16 + fq * 4 + r >= S) s[kf][f][r] = -INFINITY;
         }
-        uint32_t pb[2][2][4];   // [query frag][key step][4 dwords] = packed bf16x8 B operands
+        uint32_t pb[2][4][2];   // [query frag][key frag][2 dwords] = packed bf16x4 B operands of the K = 16 MFMAs
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
@@ -129,27 +145,37 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 mx = fmaxf(fmaxf(mx, fmaxf(s[kf][f][0], s[kf][f][1])), fmaxf(s[kf][f][2], s[kf][f][3]));
             mx = xor16_max(mx);
             mx = xor32_max(mx);
+            // Lazy rescale: the running reference m_run only has to bound the exponents, not equal the maximum; it is
+            // raised (and l, O rescaled) when some query of the wave exceeds it by more than 2^8 — after the first
+            // tiles that is rare, so the 32-register rescale and its exp2 leave the steady-state loop.  The result
+            // sum(p v) / sum(p) does not depend on the reference.
             const float m_new = fmaxf(m_run[f], mx * scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
-            m_run[f] = m_new;
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run[f] + 8.0f) != 0) {   // wave-uniform branch
+                const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
+                m_run[f] = m_new;
+                l_run[f] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    o[d][f][0] *= alpha; o[d][f][1] *= alpha; o[d][f][2] *= alpha; o[d][f][3] *= alpha;
+                }
+            }
+            const float m_ref = m_run[f];
             float ps = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][0], scale_log2e, -m_new));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][1], scale_log2e, -m_new));
-                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][2], scale_log2e, -m_new));
-                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][3], scale_log2e, -m_new));
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][0], scale_log2e, -m_ref));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][1], scale_log2e, -m_ref));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][2], scale_log2e, -m_ref));
+                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][3], scale_log2e, -m_ref));
                 ps += (p0 + p1) + (p2 + p3);
-                pb[f][kf >> 1][(kf & 1) * 2 + 0] = pack2bf(p0, p1);
-                pb[f][kf >> 1][(kf & 1) * 2 + 1] = pack2bf(p2, p3);
+                pb[f][kf][0] = pack2bf(p0, p1);
+                pb[f][kf][1] = pack2bf(p2, p3);
             }
-            l_run[f] = l_run[f] * alpha + ps;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                o[d][f][0] *= alpha; o[d][f][1] *= alpha; o[d][f][2] *= alpha; o[d][f][3] *= alpha;
-            }
+            l_run[f] += ps;
         }
-        // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps)
+        // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps).  (K = 16 MFMAs would take the 8-byte LDS
+        // pieces and the packed S^T pairs as they are, without operand assembly moves, but v_mfma_f32_16x16x16_bf16
+        // runs at half the rate of the K = 32 form on gfx950: measured -3 %.)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int drow = d * 16 + fr;
@@ -165,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     union { uint32_t u[4]; bf16x8 v; } pv;
-                    pv.u[0] = pb[f][ks][0]; pv.u[1] = pb[f][ks][1]; pv.u[2] = pb[f][ks][2]; pv.u[3] = pb[f][ks][3];
+                    pv.u[0] = pb[f][2 * ks][0]; pv.u[1] = pb[f][2 * ks][1];
+                    pv.u[2] = pb[f][2 * ks + 1][0]; pv.u[3] = pb[f][2 * ks + 1][1];
                     o[d][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, o[d][f], 0, 0, 0);
                 }
             }
