@@ -101,7 +101,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
         for (int f = 0; f < 2; ++f) o[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY};
-    float l_run[2] = {0.f, 0.f};
+    // Row sums ride on the matrix pipe: O^T gets a 65th "d" row whose V^T entries are all ones, i.e. one extra MFMA per
+    // (key step, query frag) with a constant A operand.  Every register of l_acc[f] then holds sum_k P[k][query fr]
+    // (of the bf16-rounded P the numerator uses), with no VALU adds in the loop and no cross-lane reduction at the end.
+    f32x4 l_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -153,25 +159,22 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             if (__builtin_amdgcn_ballot_w64(m_new > m_run[f] + 8.0f) != 0) {   // wave-uniform branch
                 const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
                 m_run[f] = m_new;
-                l_run[f] *= alpha;
+                l_acc[f][0] *= alpha; l_acc[f][1] *= alpha; l_acc[f][2] *= alpha; l_acc[f][3] *= alpha;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     o[d][f][0] *= alpha; o[d][f][1] *= alpha; o[d][f][2] *= alpha; o[d][f][3] *= alpha;
                 }
             }
             const float m_ref = m_run[f];
-            float ps = 0.f;
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
                 const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][0], scale_log2e, -m_ref));
                 const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][1], scale_log2e, -m_ref));
                 const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][2], scale_log2e, -m_ref));
                 const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][3], scale_log2e, -m_ref));
-                ps += (p0 + p1) + (p2 + p3);
                 pb[f][kf][0] = pack2bf(p0, p1);
                 pb[f][kf][1] = pack2bf(p2, p3);
             }
-            l_run[f] += ps;
         }
         // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps).  (K = 16 MFMAs would take the 8-byte LDS
         // pieces and the packed S^T pairs as they are, without operand assembly moves, but v_mfma_f32_16x16x16_bf16
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                     pv.u[0] = pb[f][2 * ks][0]; pv.u[1] = pb[f][2 * ks][1];
                     pv.u[2] = pb[f][2 * ks + 1][0]; pv.u[3] = pb[f][2 * ks + 1][1];
                     o[d][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, o[d][f], 0, 0, 0);
+                    if (d == 0) l_acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pv.v, l_acc[f], 0, 0, 0);
                 }
             }
         }
@@ -203,10 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
     // ---- normalise and store: lane holds O[query fr][d = dfrag*16 + 4*fq + r]
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
-        float l = l_run[f];
-        l = xor16_sum(l);
-        l = xor32_sum(l);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / l_acc[f][0];
         const int qi = qt * QB + wave * 32 + f * 16 + fr;
         if (qi < S) {
             uint16_t* dst = O + (row0 + qi) * ldo + h * 64 + fq * 4;
