@@ -145,10 +145,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         uint32_t pb[2][4][2];   // [query frag][key frag][2 dwords] = packed bf16x4 B operands of the K = 16 MFMAs
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
-#pragma unroll
-            for (int kf = 1; kf < 4; ++kf)
-                mx = fmaxf(fmaxf(mx, fmaxf(s[kf][f][0], s[kf][f][1])), fmaxf(s[kf][f][2], s[kf][f][3]));
+            float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), s[0][f][2]);   // chains of max(max(a, b), c) -> v_max3_f32
+            mx = fmaxf(fmaxf(mx, s[0][f][3]), s[1][f][0]);
+            mx = fmaxf(fmaxf(mx, s[1][f][1]), s[1][f][2]);
+            mx = fmaxf(fmaxf(mx, s[1][f][3]), s[2][f][0]);
+            mx = fmaxf(fmaxf(mx, s[2][f][1]), s[2][f][2]);
+            mx = fmaxf(fmaxf(mx, s[2][f][3]), s[3][f][0]);
+            mx = fmaxf(fmaxf(mx, s[3][f][1]), s[3][f][2]);
+            mx = fmaxf(mx, s[3][f][3]);
             mx = xor16_max(mx);
             mx = xor32_max(mx);
             // Lazy rescale: the running reference m_run only has to bound the exponents, not equal the maximum; it is

@@ -424,9 +424,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         const bool fast_st = staged && r2 == nullptr;   // counted-wait path (res2 would need loads behind the stores)
         constexpr int ITEMS_P = 6, ITEMS_G = 3;         // row sweeps per 16-row pass: plain (RPS 3) / GEGLU (RPS 6)
         constexpr int CHr = GE ? 10 : 20, RPSr = GE ? 6 : 3;
-        const int lch = lane % CHr, lrow = lane / CHr;
+        // 64 lanes = RPSr rows x CHr chunks + 4 surplus lanes; the surplus lanes (and the row slots past the 16th row of
+        // a pass, below) DUPLICATE a valid lane's work — same address, same data — instead of storing to the dump page:
+        // with streaming stores the dump writes were real HBM traffic (+17 % on the output stream, PMC WRITE_SIZE).
+        const int lrow = lane / CHr < RPSr ? lane / CHr : RPSr - 1;
+        const int lch = lane - (lane / CHr) * CHr;
         const int ncol = (geglu ? tile_n * 80 : n0) + lch * 8;
-        const bool lane_ok = lrow < RPSr && ncol < n_valid;
+        const bool lane_ok = ncol < n_valid;
         const int mw0 = m0 + wave * 32;                  // first row of this wave's 32-row band
         float4 bvf[10];                                   // GEGLU: bias in fragment layout (value | gate)
         float4 c0, c1, rv0[2], rv1[2];                    // plain: bias and the per-frame vector row of each 16-row pass
@@ -443,9 +447,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             constexpr int mi = decltype(mi_tag)::value;
 #pragma unroll
             for (int k = 0; k < ITEMS_P; ++k) {
-                const int rr = lrow + k * 3;
+                const int rr = lrow + k * 3 < 16 ? lrow + k * 3 : 15;
                 const int m = mw0 + mi * 16 + rr;
-                const bool ok = lane_ok && rr < 16 && m < p.M;
+                const bool ok = lane_ok && m < p.M;
                 q1[mi][k] = *(const uint4*)(ok ? (const char*)(r1 + (int64_t)m * p.ldr1 + ncol) : zeros);
             }
         };
@@ -537,9 +541,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                 //     The store is UNCONDITIONAL (invalid lanes hit g_dump) so that exactly ITEMS stores are issued.
 #pragma unroll
                 for (int k = 0; k < ITEMS; ++k) {
-                    const int rr = lrow + k * RPS;
+                    const int rr = lrow + k * RPS < 16 ? lrow + k * RPS : 15;
                     const int m = mrow0 + rr;
-                    const bool ok = lane_ok && rr < 16 && m < p.M;
+                    const bool ok = lane_ok && m < p.M;
                     const uint4 sv = *(const uint4*)(stg + rr * STG_ROWB + lch * 16);   // rr <= 17 stays inside the stage
                     uint4 ov = sv;
                     if (!GE) {

@@ -308,10 +308,14 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         // ---- epilogue, part 1: bias + first pass operands, then the next tile's first K tile, then the 4 passes
         constexpr int ITEMS_P = 6, ITEMS_G = 3;
         constexpr int CHr = GE ? 10 : 20, RPSr = GE ? 6 : 3;
-        const int lch = lane % CHr, lrow = lane / CHr;
+        // 64 lanes = RPSr rows x CHr chunks + 4 surplus lanes; the surplus lanes (and the row slots past the 16th row of
+        // a pass, below) DUPLICATE a valid lane's work — same address, same data — instead of storing to the dump page:
+        // with streaming stores the dump writes were real HBM traffic (+17 % on the output stream, PMC WRITE_SIZE).
+        const int lrow = lane / CHr < RPSr ? lane / CHr : RPSr - 1;
+        const int lch = lane - (lane / CHr) * CHr;
         const int tile_nw = tile_n * 2 + wn;                 // index of this wave's 160-column tile
         const int ncol = (GE ? tile_nw * 80 : tile_nw * 160) + lch * 8;
-        const bool lane_ok = lrow < RPSr && ncol < n_valid;
+        const bool lane_ok = ncol < n_valid;
         const int mw0 = m0 + wm * 64;
         float4 bvf[10];
         float4 c0, c1, rv0[2], rv1[2];
@@ -328,9 +332,9 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             constexpr int mi = decltype(mi_tag)::value;
 #pragma unroll
             for (int k = 0; k < ITEMS_P; ++k) {
-                const int rr = lrow + k * 3;
+                const int rr = lrow + k * 3 < 16 ? lrow + k * 3 : 15;
                 const int m = mw0 + mi * 16 + rr;
-                const bool ok = lane_ok && rr < 16 && m < p.M;
+                const bool ok = lane_ok && m < p.M;
                 q1[mi & 1][k] = *(const uint4*)(ok ? (const char*)(r1 + (int64_t)m * p.ldr1 + ncol) : zeros);
             }
         };
@@ -402,9 +406,9 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 }
 #pragma unroll
                 for (int k = 0; k < ITEMS; ++k) {
-                    const int rr = lrow + k * RPS;
+                    const int rr = lrow + k * RPS < 16 ? lrow + k * RPS : 15;
                     const int m = mrow0 + rr;
-                    const bool ok = lane_ok && rr < 16 && m < p.M;
+                    const bool ok = lane_ok && m < p.M;
                     const uint4 sv = *(const uint4*)(stg + rr * HSTG_ROWB + lch * 16);
                     uint4 ov = sv;
                     if (!GE) {
