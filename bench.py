@@ -186,11 +186,13 @@ def main():
                 sh[0] += e0.elapsed_time(e1) * 1e-3
                 sh[1] += 1
             dom = max(by_mode, key=lambda m: by_mode[m][0])
+            traffic, traffic_src = pmc_traffic(dom)
             tsec, fl, cnt = by_mode[dom]
             ach = fl / tsec / 1e12
             res["roofline"] = {"kernel": MODE_NAMES[dom], "bound": "mfma", "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                               "traffic": None, "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
+                               "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                               "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
                                "share_of_timed_region": round(tsec / dt, 3)}
             res["gemm_kernels"] = {MODE_NAMES[m]: {"launches": v[2], "seconds": round(v[0], 4),
                                                    "tflops": round(v[1] / v[0] / 1e12, 1)} for m, v in sorted(by_mode.items())}
@@ -210,6 +212,33 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(mode: int):
+    """HBM bytes per launch of the GEMM kernels of A-gather mode `mode`, from the committed rocprofv3 PMC summary
+    (FETCH_SIZE and WRITE_SIZE collected in separate passes by tools/pmc_run.sh; KiB -> bytes, FETCH doubled per the
+    gfx950 correction of MI355X_MICROARCH.md): launch-weighted mean over the kernel templates serving that mode.
+    PMC counters cannot be collected from inside this process; None when no summary is present."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.csv")))
+    if not files:
+        return None, None
+    tot = n = 0.0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            m = re.match(r"gemm(_huge)?_kernel<(\d+),", row["kernel"])
+            if not m or int(m.group(2)) != mode:
+                continue
+            try:
+                b = 2.0 * 1024.0 * float(row["FETCH_SIZE_per_launch"]) + 1024.0 * float(row["WRITE_SIZE_per_launch"])
+            except (KeyError, ValueError):
+                continue
+            k = float(row["launches"])
+            tot += b * k
+            n += k
+    return (round(tot / n) if n else None), os.path.basename(files[-1])
 
 
 if __name__ == "__main__":
