@@ -6,6 +6,7 @@ or a standalone TCP server with --port (client protocol of downstream/solver_bas
     python serve_worker.py --unet_path <finetuned>/unet --svd_path <stable-video-diffusion-img2vid-xt> <w_fd>
     python serve_worker.py --unet_path ... --svd_path ... --port 7000
     python serve_worker.py --random_weights --port 7000          # no checkpoints: random-init weights (bring-up)
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 serve_worker.py --port 7000 ...   # one request over 8 GPUs
 
 The denoising loop and the VAE encode / decode run on the hand-written HIP path (libwiwsvd.so; no fallback);
 the CLIP image encoder is the third-party `transformers` module the reference uses, on PyTorch-ROCm.
@@ -86,6 +87,28 @@ def main(argv=None) -> None:
     args = ap.parse_args(list(sys.argv[1:] if argv is None else argv))
     if args.port <= 0 and args.pipe_fd is None:
         ap.error("either --port (standalone TCP server) or the manager's trailing pipe fd is required")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:   # torchrun --nproc-per-node N serve_worker.py --port P ...: one request sharded over N GPUs
+        import torch.distributed as dist
+        from wiw_amd.parallel import ShardedWorker
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        args.device = f"cuda:{local_rank}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(args.device))
+        sharded = ShardedWorker(build_worker(args))
+        if dist.get_rank() == 0:
+            if args.port <= 0:
+                ap.error("multi-GPU serving needs --port (rank 0 runs the TCP server)")
+            print(f"[serve_worker] {world} ranks, listening on {args.host}:{args.port}", file=sys.stderr, flush=True)
+            try:
+                serve_tcp(sharded, host=args.host, port=args.port, batch_size=0)
+            finally:
+                sharded.close()
+        else:
+            sharded.follow()
+        dist.destroy_process_group()
+        return
     worker = build_worker(args)
     if args.port > 0:
         print(f"[serve_worker] listening on {args.host}:{args.port}", file=sys.stderr, flush=True)

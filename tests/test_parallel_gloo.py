@@ -71,3 +71,49 @@ def test_sharded_equals_single_rank_even_and_ragged():
     assert _spawn(4) == 0.0   # 2 + 2
     assert _spawn(3) == 0.0   # 2 + 1 (ragged)
     assert _spawn(1) == 0.0   # 1 + 0 (a rank with no candidate)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ShardedWorker: request dict sharded over ranks, responses concatenated in candidate order
+# ----------------------------------------------------------------------------------------------------------------
+def fake_worker(req):
+    a = np.asarray(req["b_action"])
+    frames = (np.asarray(req["b_image"]).astype(np.int64).sum(axis=(1, 2, 3)) % 251)[:, None] + a
+    return {"save_dirs": list(req["save_dirs"]), "pred_frames": frames.astype(np.uint8)}
+
+
+def _run_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wiw_amd.parallel import ShardedWorker
+    try:
+        sw = ShardedWorker(fake_worker)
+        if rank == 0:
+            errs = []
+            for B in (5, 2, 1):
+                rs = np.random.RandomState(B)
+                req = {"b_action": rs.randint(0, 5, size=(B, 14)), "save_dirs": [f"/tmp/c{i}" for i in range(B)],
+                       "request_model_name": "igen",
+                       "b_image": rs.randint(0, 256, size=(B, 3, 8, 16), dtype=np.uint8), "return_objects": [True] * B}
+                out, ref = sw(req), fake_worker(req)
+                errs.append(out["save_dirs"] == ref["save_dirs"] and np.array_equal(out["pred_frames"], ref["pred_frames"]))
+            sw.close()
+            q.put(all(errs))
+        else:
+            sw.follow()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_worker_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) is True
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0

@@ -71,3 +71,70 @@ def sharded_denoise(denoise_fn: Callable[..., torch.Tensor], device: torch.devic
     if rank != 0:
         return None
     return torch.cat([parts[k][: b - a] for k, (a, b) in enumerate(bounds)])
+
+
+# ------------------------------------------------------------------------------------------------
+# Serving: one request sharded over the ranks, every stage (encode, denoise, decode, PIL post-processing) local
+# ------------------------------------------------------------------------------------------------
+class ShardedWorker:
+    """Rank 0 owns the client connection; a request's candidates are sliced over the ranks exactly as the reference
+    manager slices them over worker processes (every value `v[lo:hi]`, worker_manager.py:448-469), each rank runs the
+    WHOLE worker on its slice — VAE encode, denoise, VAE decode and the CPU-side PIL post-processing all scale with
+    the rank count ("decode-sharded") — and the per-rank response dicts come back to rank 0, where
+    they are concatenated in candidate order.  The two object collectives move the request (1.8 MB / candidate) and
+    the uint8 frames (9.7 MB / candidate); nothing is exchanged inside the loop.
+
+        rank 0:   ShardedWorker(worker)(request) -> response            (e.g. behind server.worker.serve_tcp)
+        rank > 0: ShardedWorker(worker).follow()                        (returns when rank 0 calls close())
+    """
+
+    _STOP = "__wiw_stop__"
+
+    def __init__(self, worker: Callable[[dict], dict]):
+        self.worker = worker
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    @staticmethod
+    def _slice(req: dict, lo: int, hi: int) -> dict:
+        # strings (request_model_name) stay whole: the reference manager slices them too ("igen"[i:i+1]), which its
+        # worker only survives because the name check is dead code there (SURVEY.md §9.5)
+        return {k: (v if isinstance(v, str) else v[lo:hi]) for k, v in req.items()}
+
+    @staticmethod
+    def _concat(parts: List[dict]) -> dict:
+        out: dict = {}
+        for part in parts:
+            for k, v in part.items():
+                out.setdefault(k, []).append(v)
+        res = {}
+        for k, vs in out.items():
+            res[k] = np.concatenate(vs) if isinstance(vs[0], np.ndarray) else [x for v in vs for x in v]
+        return res
+
+    def _step(self, request) -> Optional[dict]:
+        box = [request]
+        dist.broadcast_object_list(box, src=0)
+        req = box[0]
+        if isinstance(req, str) and req == self._STOP:
+            return None
+        n = len(next(v for v in req.values() if not isinstance(v, str)))
+        lo, hi = shard_bounds(n, self.world)[self.rank]
+        mine = self.worker(self._slice(req, lo, hi)) if hi > lo else {}
+        gathered = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if self.rank != 0:
+            return {}
+        return self._concat([g for g in gathered if g])
+
+    def __call__(self, request: dict) -> dict:
+        assert self.rank == 0, "only rank 0 takes client requests"
+        return self._step(request)
+
+    def follow(self) -> None:
+        assert self.rank != 0
+        while self._step(None) is not None:
+            pass
+
+    def close(self) -> None:
+        if self.rank == 0:
+            dist.broadcast_object_list([self._STOP], src=0)
