@@ -19,6 +19,7 @@ for MI355X:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -79,6 +80,7 @@ class RequestCond:
     ehs_bf16: torch.Tensor   # bf16 [Bc, Dctx]
     cross: Dict[str, torch.Tensor]   # attn2 prefix -> fp32 [Bc, C]
     pos_emb: Dict[str, torch.Tensor]  # transformer prefix -> fp32 [Bc*T, C]
+    pos_emb_blend: Dict[str, torch.Tensor]  # -am/(1-am) * pos_emb (AlphaBlender correction, see _transformer)
 
 
 class UNetHIP:
@@ -268,13 +270,16 @@ class UNetHIP:
         # noise-aug embedding (unet:484-486); same value for every CFG row
         nfeat = torch.from_numpy(sinusoid(np.full((Bc,), noise_aug_strength, np.float32), cfg.addition_time_embed_dim))
         noise = self._mlp("add_embedding_noise", nfeat.to(self.device, bf), Bc)
-        cross, pos = {}, {}
+        cross, pos, posb = {}, {}, {}
         for p in self.tr_names:
             for q in (p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"):
                 v = self._linear(ehs, q + ".attn2.to_v", Bc)
                 cross[q] = self._linear(v, q + ".attn2.to_out.0", Bc, out_f32=True)
             pos[p] = self.pos_emb_T[p].repeat(Bc, 1).contiguous()
-        return RequestCond(B=B, Bc=Bc, act_emb=act, noise_emb=noise, ehs_bf16=ehs, cross=cross, pos_emb=pos)
+            am = self.alpha[p]
+            posb[p] = (pos[p] * (-am / (1.0 - am))).contiguous() if abs(1.0 - am) > 1e-4 else pos[p]
+        return RequestCond(B=B, Bc=Bc, act_emb=act, noise_emb=noise, ehs_bf16=ehs, cross=cross, pos_emb=pos,
+                           pos_emb_blend=posb)
 
     # ------------------------------------------------------------------------------------------
     # blocks
@@ -332,26 +337,51 @@ class UNetHIP:
         hip.gemm(w[b + ".attn1.to_v.weight"], a, vt, M=Cn, N=M, K=Cn, C1=Cn)
         o = self._empty(M, Cn)
         hip.attn_spatial(qk, 2 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
-        h = self._linear(o, b + ".attn1.to_out.0", M, res1=h)
-        a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
-                          rows_per_vec=T * S, sum_out=h, out=a)
-        hs = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0)
+        # The adds that follow a GEMM in the reference — the single-key cross-attention output (one vector per CFG item,
+        # attention.py:545-551, 740-743) and the frame-position embedding (transformer_temporal.py:352-353) — ride in that
+        # GEMM's epilogue as its per-row-group vector, so every LayerNorm below is a plain one-read / one-write pass.
+        legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
+        if legacy:
+            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h)
+            a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
+                              rows_per_vec=T * S, sum_out=h, out=a)
+        else:
+            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S)
+            a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
+        am = self.alpha[p]
+        # hs + emb is stored instead of hs; the blend below subtracts am * emb again
+        fold_emb = abs(1.0 - am) > 1e-4 and not legacy
+        if fold_emb:
+            hm = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0, rowvec=cond.pos_emb[p], rowvec_ld=Cn,
+                                rows_per_vec=S)
+            hs = hm                           # = spatial output + emb
+            a = hip.layernorm(hm, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], out=a)
+        else:
+            hs = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0)
+            hm = self._empty(M, Cn)
+            a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
+                              addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
-        hm = self._empty(M, Cn)
-        a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
-                          addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         hm = self._geglu_ff(a, t + ".ff_in", M, Cn, res1=hm, ldr1=Cn, beta1=1.0)
         a = hip.layernorm(hm, M, Cn, w[t + ".norm1.weight"], w[t + ".norm1.bias"], out=a)
         qkv = self._empty(M, 3 * Cn)
         hip.gemm(a, w[t + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
         hip.attn_temporal(qkv, 3 * Cn, o, Cn, batch, T, S, heads, scale)
-        hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm)
-        a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
-                          rows_per_vec=T * S, sum_out=hm, out=a)
-        am = self.alpha[p]
-        # AlphaBlender: am*hs + (1-am)*(hm + ff(a))
-        hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
-                            beta2=am)
+        if legacy:
+            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm)
+            a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
+                              rows_per_vec=T * S, sum_out=hm, out=a)
+        else:
+            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S)
+            a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
+        # AlphaBlender: am*hs + (1-am)*(hm + ff(a)); with hs' = hs + emb stored: am*hs = am*hs' - am*emb, and the
+        # epilogue's vector enters as alpha * rowvec with alpha = 1 - am  ->  rowvec = -am / (1 - am) * emb
+        if fold_emb:
+            hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
+                                beta2=am, rowvec=cond.pos_emb_blend[p], rowvec_ld=Cn, rows_per_vec=S)
+        else:
+            hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
+                                beta2=am)
         return self._linear(hb, p + ".proj_out", M, res1=x)
 
     # ------------------------------------------------------------------------------------------
