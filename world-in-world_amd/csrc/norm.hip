@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 constexpr int LN_MAXCH = 4;
 constexpr int LN_RUN = 8;      // consecutive rows per wave
 
-// NCH = 16-byte chunk passes per row (C <= NCH * 512), R = rows whose loads are in flight together (R * NCH = 4):
+// NCH = 16-byte chunk passes per row (C <= NCH * 512), R = rows whose loads are in flight together (8 at C <= 512:
 // at C = 320 one row is only 640 B, and one row in flight per wave leaves the kernel latency-bound.
 template <int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, int64_t rows, int C,
@@ -361,7 +361,7 @@ extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int
 #define WIW_LN_LAUNCH(NCH, R)                                                                                        \
     hipLaunchKernelGGL((layernorm_kernel<NCH, R>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, \
                        gamma, beta, eps, addvec, addvec_ld, rows_per_vec, (uint16_t*)sum_out, (uint16_t*)out)
-    if (C <= 512) WIW_LN_LAUNCH(1, 4);
+    if (C <= 512) WIW_LN_LAUNCH(1, 8);
     else if (C <= 1024) WIW_LN_LAUNCH(2, 2);
     else WIW_LN_LAUNCH(4, 1);
 #undef WIW_LN_LAUNCH
