@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--dump-shapes", type=str, default="", help="write per-(M,N,K) GEMM timings to this file")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time whole requests (uint8 panorama in -> uint8 frames out: CLIP + VAE encode, denoise, VAE "
+                         "decode, PIL post-processing) through server.worker.SVDWorker; reported as 'end_to_end'")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -202,6 +205,8 @@ def main():
                     for (mode, M, N, K, epi), (sec, cnt) in rows:
                         f.write(f"mode={mode} M={M} N={N} K={K} epi={epi} launches={cnt} total_ms={1e3 * sec:.2f} "
                                 f"avg_us={1e6 * sec / cnt:.1f} tflops={2.0 * M * N * K * cnt / sec / 1e12:.1f}\n")
+        if args.end_to_end and world == 1 and not args.tiny:
+            res["end_to_end"] = end_to_end(den, unet, device, B, args)
         if sd_cpu is not None:
             try:
                 res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, min(os.cpu_count() or 1, 32))
@@ -212,6 +217,40 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(den, unet, device, B, args):
+    """Whole requests through the worker ('also report end-to-end (incl. CLIP/VAE) separately'):
+    random-init VAE / CLIP of the production geometry, B candidates, args.num_inference_steps Euler steps."""
+    import numpy as np
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from wiw_amd import frontend as FE
+    from wiw_amd.server.worker import SVDWorker
+    from wiw_amd.vae import HIPFrontend, VAEHIP
+
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(
+        hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
+        patch_size=14, projection_dim=1024, hidden_act="gelu")).eval()
+    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(1), device, hip=unet.hip), clip)
+
+    def denoise(il, ie, nz, act, **kw):
+        return den.denoise(torch.from_numpy(il), torch.from_numpy(ie), torch.from_numpy(nz), act, **kw).cpu().numpy()
+
+    worker = SVDWorker(denoise, fe, width=args.width, height=args.height, num_inference_steps=args.num_inference_steps)
+    rs = np.random.RandomState(0)
+    req = {"b_action": np.asarray(synth_actions(B, 14), dtype=np.int64), "save_dirs": [f"/tmp/wiw_e2e_{i}" for i in range(B)],
+           "request_model_name": "igen", "b_image": rs.randint(0, 256, size=(B, 3, args.height, args.width), dtype=np.uint8),
+           "return_objects": [True] * B}
+    worker(req)                      # warm-up (CLIP / hipBLASLt first-call costs)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = worker(req)
+    dt = time.perf_counter() - t0
+    assert out["pred_frames"].shape == (B, 14, 3, 480, 480)
+    return {"seconds_per_request": round(dt, 3), "frames_per_s": round(B * 14 / dt, 3), "candidates": B,
+            "includes": "CLIP + VAE encode, denoise loop, VAE decode, PIL resize, uint8 response (random-init weights)"}
 
 
 def pmc_traffic(mode: int):
