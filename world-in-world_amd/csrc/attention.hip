@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 glds16(key0 < S ? vp[i] : zeros, sV + i * 1024);
             }
         }
+#ifndef WIW_ATTN_STATIC_KV   // ablation build: every tile re-reads KV tile 0 (cache-hot operands)
 #pragma unroll
         for (int i = 0; i < 2; ++i) { kp[i] += kstep; vp[i] += KB * 2; }
+#endif
     };
 
     f32x4 o[4][2];
