@@ -480,3 +480,19 @@ def test_gemm_huge_tile_conv_modes(hip):
     check(from_nhwc(o2, 7, h, 2 * w), F.conv2d(xl, wt2, None, stride=2, padding=1), what="huge-tile stride-2 conv")
     hip.gemm(dev_bf(nhwc(xl)), wk2, o2, M=Mo, N=640, K=9 * c, C1=c, mode=H.A_CONV3X3_S2P, H=h, Wd=2 * w)
     check(from_nhwc(o2, 7, h, 2 * w), F.conv2d(F.pad(xl, (0, 1, 0, 1)), wt2, None, stride=2), what="huge-tile stride-2 (0,1,0,1) conv")
+
+
+def test_gemm_huge_tile_partial_n(hip):
+    """N = 512 (one full + one 192-wide 320-column tile): the VAE decoder's channel counts on the 256 x 320 tile."""
+    from wiw_amd import hip as H
+
+    n, c, cout, h, w = 28, 128, 512, 32, 64         # M = 57344 -> 224 x 2 tiles, K = 1152
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(cout, c, 3, 3, seed=2) / math.sqrt(9 * c))
+    b, r1 = rnd(cout, seed=3), bf(rnd(n * h * w, cout, seed=4))
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), dev_bf(wt.permute(0, 2, 3, 1).reshape(cout, -1)), out, M=M, N=cout, K=9 * c, C1=c,
+             mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b), res1=dev_bf(r1), ldr1=cout, beta1=1.0)
+    ref = F.conv2d(x, wt, b, padding=1) + from_nhwc(r1, n, h, w)
+    check(from_nhwc(out, n, h, w), ref, what="huge-tile conv3x3, N = 512 (partial N tile)")

@@ -490,7 +490,9 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
 bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
     if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_OUT_F32)) return false;
-    if (a.N % HN != 0) return false;
+    // partial last N tile (the VAE's 256 / 512-channel layers): only without GEGLU and when 320-wide tiles idle no more
+    // MFMA columns than 160-wide ones would
+    if (a.N % HN != 0 && (ge || ((a.N + HN - 1) / HN) * HN > ((a.N + 159) / 160) * 160)) return false;
     const int n_valid = ge ? a.n_out : a.N;
     if (n_valid % 8 || a.ldo % 8) return false;
     if (a.res1 && a.ldr1 % 8) return false;
@@ -499,7 +501,7 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     // short K (< 10 K tiles): the output tile's epilogue dominates and the smaller tile's finer granularity wins
     // (measured: K = 320 GEGLU -6 %, plain +-2 %; K >= 640 +4...+28 %)
     if (a.K < 640 && !getenv("WIW_GEMM_HUGE_ANYK")) return false;
-    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * (a.N / HN);
+    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
     return tiles >= 200;
 }
 
