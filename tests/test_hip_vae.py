@@ -144,5 +144,16 @@ def test_hip_frontend_protocol(vae_pair):
     x = np.tanh(rs.standard_normal((2, 3, 128, 256))).astype(np.float32)
     lat, emb = fe.encode(x, rs.standard_normal(x.shape).astype(np.float32), 0.02)
     assert lat.shape == (2, 4, 16, 32) and emb.shape == (2, 1, 1024) and lat.dtype == np.float32
-    fr = fe.decode(rs.standard_normal((2, 4, 4, 16, 32)).astype(np.float32))
+    lat = rs.standard_normal((2, 4, 4, 16, 32)).astype(np.float32)
+    fr = fe.decode(lat)
     assert fr.shape == (2, 4, 3, 128, 256) and np.isfinite(fr).all()
+    # device-side quantisation == frames_to_pil on the host, on the SAME decoded frames (two decodes differ in the
+    # last bits: GroupNorm statistics are accumulated with fp32 atomics)
+    from wiw_amd.server import plumbing as P
+    from wiw_amd.vae import frames_to_uint8_device
+    frd = vae.decode(torch.from_numpy(lat))[0]
+    ref = np.stack([np.asarray(im) for im in P.frames_to_pil(frd.cpu().numpy())])
+    assert np.array_equal(frames_to_uint8_device(frd).cpu().numpy(), ref)
+    u8 = fe.decode_uint8(lat)
+    assert u8.shape == (2, 4, 128, 256, 3) and u8.dtype == np.uint8
+    assert np.abs(u8[0].astype(np.int16) - ref.astype(np.int16)).mean() < 0.5

@@ -87,11 +87,26 @@ def frames_to_pil(frames: np.ndarray) -> List[Image.Image]:
 
 def images_to_tensor(pipe_images: Sequence[Sequence[Image.Image]], save_size=(480, 480)) -> np.ndarray:
     """PIL BICUBIC resize to save_size=(W,H) then /255, CHW  ->  float32 (B,T,3,H,W) (api_models/__init__.py:113-166)."""
-    out = []
-    for clip in pipe_images:
-        fr = [np.transpose(np.asarray(im.resize(save_size, Image.BICUBIC), dtype=np.float32) / 255.0, (2, 0, 1)) for im in clip]
-        out.append(np.stack(fr))
-    return np.stack(out)
+    def one(im):
+        return np.transpose(np.asarray(im.resize(save_size, Image.BICUBIC), dtype=np.float32) / 255.0, (2, 0, 1))
+
+    flat = [im for clip in pipe_images for im in clip]
+    # PIL's resize releases the GIL: the frames of a request are resized on a small thread pool (same result per
+    # frame; 14 x B frames of 576x1024 cost 0.16 s x B on one thread, next to 0.17 s x B of VAE decode on the GPU)
+    fr = list(_pool().map(one, flat)) if len(flat) > 1 else [one(im) for im in flat]
+    it = iter(fr)
+    return np.stack([np.stack([next(it) for _ in clip]) for clip in pipe_images])
+
+
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1)))
+    return _POOL
 
 
 def save_predict(video: np.ndarray, b_action, save_dirs: Sequence[str]) -> None:

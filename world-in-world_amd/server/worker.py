@@ -73,8 +73,12 @@ class SVDWorker:
         latents = self.denoise_fn(image_latents, image_embeddings, lat_noise, b_action,
                                   num_steps=self.num_inference_steps, fps=7, motion_bucket_id=127,
                                   noise_aug_strength=0.02)
-        frames = self.frontend.decode(np.asarray(latents, dtype=np.float32))  # (B,T,3,H,W) in [-1,1]
-        clips = [P.frames_to_pil(f) for f in frames]
+        lat = np.asarray(latents, dtype=np.float32)
+        if hasattr(self.frontend, "decode_uint8"):    # frame quantisation on the device (same arithmetic, same bytes)
+            clips = [[P.Image.fromarray(f) for f in clip] for clip in self.frontend.decode_uint8(lat)]
+        else:
+            frames = self.frontend.decode(lat)         # (B,T,3,H,W) in [-1,1]
+            clips = [P.frames_to_pil(f) for f in frames]
         video = P.images_to_tensor(clips, save_size=self.out_size)
         out = P.build_response(video, b_action, list(save_dirs), return_objects)
         P.check_outputdict(out)
