@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 1
+#define WIW_ABI_VERSION 2   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment) */
 
 int wiw_abi_version(void);
 const char* wiw_last_error(void);
@@ -55,6 +55,9 @@ int wiw_device_check(int dev, char* name, int name_len);
  *        dp/models/embeddings.py:804-816 (TimestepEmbedding), resnet.py:343-350 (time_emb_proj).
  * mode WIW_A_CONV3X3   : 3x3, stride 1, zero pad 1 over (H, Wd)                   (K = 9 * C1)
  *        dp/models/resnet.py:269,285 (ResnetBlock2D.conv1/conv2), unet:130-135, 255-260.
+ *        With C2 > 0 a tenth, dense K segment concat(A2[m][0:C2], A3[m][0:C3]) follows the nine taps
+ *        (K = 9 * C1 + C2 + C3): ResnetBlock2D's 1x1 `conv_shortcut` over the skip concat (resnet.py:311-318,
+ *        unet_3d_blocks.py:1612) accumulated inside conv2 — the shortcut tensor is never written.
  * mode WIW_A_CONV3X3_S2: 3x3, stride 2, pad 1; input is (2H, 2Wd)                 (K = 9 * C1)
  *        dp/models/downsampling.py:132-150 (Downsample2D).
  * mode WIW_A_CONV3X3_S2P: 3x3, stride 2, zero pad (0,1,0,1) = bottom / right only; input is (2H, 2Wd)
@@ -63,7 +66,8 @@ int wiw_device_check(int dev, char* name, int name_len);
  *        dp/models/upsampling.py:142-186 (Upsample2D).
  * mode WIW_A_CONV_T3   : (3,1,1) temporal conv, zero pad 1 over T; S = H*Wd       (K = 3 * C1)
  *        dp/models/resnet.py:570-592 (TemporalResnetBlock.conv1/conv2).
- * Constraints: C1 % 64 == 0, C2 % 64 == 0, K = taps * (C1 + C2); A2 only with WIW_A_DENSE.
+ * Constraints: C1, C2, C3 % 64 == 0; K = C1 + C2 (dense), taps * C1 (conv) or 9 * C1 + C2 + C3 (conv3x3 + shortcut);
+ * A2 only with WIW_A_DENSE / WIW_A_CONV3X3, A3 only with WIW_A_CONV3X3.
  * ---------------------------------------------------------------------------------------------- */
 enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_UP = 3, WIW_A_CONV_T3 = 4,
        WIW_A_CONV3X3_S2P = 5 };
@@ -79,8 +83,9 @@ typedef struct WiwGemmArgs {
     const void* res1;    /* bf16 [M][ldr1] or NULL */
     const void* res2;    /* bf16 [M][ldr2] or NULL */
     const void* zeros;   /* >= 16 bytes of device zeros (source of padding taps) */
+    const void* A3;      /* bf16 [rows_in][C3] or NULL (second half of the fused shortcut segment, CONV3X3 only) */
     int32_t M, N, K;
-    int32_t C1, C2;
+    int32_t C1, C2, C3;
     int32_t mode;
     int32_t H, Wd, T;    /* OUTPUT geometry of the conv modes */
     int32_t ldo, ldr1, ldr2;

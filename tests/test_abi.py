@@ -34,15 +34,15 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported"
     lib.wiw_abi_version.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 1
+    assert lib.wiw_abi_version() == 2
 
 
 def test_gemm_args_struct_layout():
     from wiw_amd.hip import WiwGemmArgs
 
-    # 9 pointers + 19 x 4-byte fields, natural alignment (matches the C struct in wiw_svd.h)
-    assert ctypes.sizeof(WiwGemmArgs) == 9 * 8 + 19 * 4 + 4
-    assert WiwGemmArgs.M.offset == 72 and WiwGemmArgs.epilogue.offset == 72 + 18 * 4
+    # 10 pointers + 20 x 4-byte fields, natural alignment (matches the C struct in wiw_svd.h)
+    assert ctypes.sizeof(WiwGemmArgs) == 10 * 8 + 20 * 4
+    assert WiwGemmArgs.M.offset == 80 and WiwGemmArgs.epilogue.offset == 80 + 19 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

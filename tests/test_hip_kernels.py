@@ -496,3 +496,26 @@ def test_gemm_huge_tile_partial_n(hip):
              mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b), res1=dev_bf(r1), ldr1=cout, beta1=1.0)
     ref = F.conv2d(x, wt, b, padding=1) + from_nhwc(r1, n, h, w)
     check(from_nhwc(out, n, h, w), ref, what="huge-tile conv3x3, N = 512 (partial N tile)")
+
+
+@pytest.mark.parametrize("n,c,c2,c3,cout,h,w", [(3, 64, 64, 0, 96, 8, 16),          # small tile, single-source shortcut
+                                                 (24, 64, 128, 64, 320, 32, 64),    # 256 x 160 tile, concat shortcut
+                                                 (28, 128, 64, 192, 320, 32, 64)])  # 256 x 320 tile (K = 1408)
+def test_conv3x3_with_fused_shortcut(hip, n, c, c2, c3, cout, h, w):
+    """conv2 + the 1x1 conv_shortcut over the skip concat (resnet.py:311-318) as ONE implicit GEMM: K = 9*C1 + C2 + C3."""
+    from wiw_amd import hip as H
+
+    x = bf(rnd(n, c, h, w, seed=1))
+    s1 = bf(rnd(n, c2, h, w, seed=2))
+    s2 = bf(rnd(n, c3, h, w, seed=3)) if c3 else None
+    wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+    wsc = bf(rnd(cout, c2 + c3, 1, 1, seed=5) / math.sqrt(c2 + c3))
+    b = rnd(cout, seed=6)
+    wk = dev_bf(torch.cat([wt.permute(0, 2, 3, 1).reshape(cout, -1), wsc[:, :, 0, 0]], dim=1))
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=cout, K=9 * c + c2 + c3, C1=c, mode=H.A_CONV3X3, H=h, Wd=w,
+             A2=dev_bf(nhwc(s1)), C2=c2, A3=dev_bf(nhwc(s2)) if c3 else None, C3=c3, bias=dev_f(b))
+    skip = torch.cat([s1, s2], dim=1) if c3 else s1
+    ref = F.conv2d(x, wt, b, padding=1) + F.conv2d(skip, wsc)
+    check(from_nhwc(out, n, h, w), ref, what=f"conv3x3 + fused shortcut {c}|{c2}+{c3}->{cout}")

@@ -142,9 +142,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     const int chunk = (lane & 7) ^ (rsub & 7);        // logical 16-B chunk fetched into position lane&7
     const char* const Ab = (const char*)p.A;
     const char* const A2b = (const char*)p.A2;
+    const char* const A3b = (const char*)p.A3;
     const char* const zeros = (const char*)p.zeros;
     const int HW = p.H * p.Wd;
-    const int Ctot = p.C1 + p.C2;
+    const int Ctot = MODE == WIW_A_DENSE ? p.C1 + p.C2 : p.C1;   // channels per tap (the shortcut segment is tap 9)
     const int nk = p.K / BK;
 
     int a_m[4];
@@ -197,6 +198,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             if (!a_ok[i] || (unsigned)tt >= (unsigned)p.T) return zeros;
             return Ab + (((int64_t)a_m[i] + (int64_t)(tap - 1) * HW) * p.C1 + cc + chunk * 8) * 2;
         } else {
+            if (MODE == WIW_A_CONV3X3 && tap == 9) {   // fused 1x1 shortcut: dense segment concat(A2, A3) after the taps
+                if (!a_ok[i]) return zeros;
+                if (cc < p.C2) return A2b + ((int64_t)a_m[i] * p.C2 + cc + chunk * 8) * 2;
+                return A3b + ((int64_t)a_m[i] * p.C3 + (cc - p.C2) + chunk * 8) * 2;
+            }
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             int row;
             bool ok;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         }
         ++ld_kt;
         ld_cc += BK;
-        if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
+        if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
     };
 
     // BIG: the 7 DMA instructions of a K tile are spread 2|2|2|1 over the four slots of the previous tile's
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             }
             ++ld_kt;
             ld_cc += BK;
-            if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
+            if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
         }
     };
 
@@ -706,12 +712,16 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     const WiwGemmArgs& a = *args;
     WIW_REQUIRE(a.A && a.W && a.out && a.zeros, "gemm: null A/W/out/zeros pointer");
     WIW_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: M, N, K must be positive");
-    WIW_REQUIRE(a.C1 > 0 && a.C1 % 64 == 0 && a.C2 >= 0 && a.C2 % 64 == 0, "gemm: C1/C2 must be multiples of 64");
+    WIW_REQUIRE(a.C1 > 0 && a.C1 % 64 == 0 && a.C2 >= 0 && a.C2 % 64 == 0 && a.C3 >= 0 && a.C3 % 64 == 0,
+                "gemm: C1/C2/C3 must be multiples of 64");
     WIW_REQUIRE((a.C2 == 0) == (a.A2 == nullptr), "gemm: A2 must be given iff C2 > 0");
+    WIW_REQUIRE((a.C3 == 0) == (a.A3 == nullptr), "gemm: A3 must be given iff C3 > 0");
+    WIW_REQUIRE(a.C3 == 0 || (a.mode == WIW_A_CONV3X3 && a.C2 > 0), "gemm: A3 only as the second half of a conv3x3 shortcut segment");
     WIW_REQUIRE(a.mode >= WIW_A_DENSE && a.mode <= WIW_A_CONV3X3_S2P, "gemm: unknown mode");
     const int taps = a.mode == WIW_A_DENSE ? 1 : (a.mode == WIW_A_CONV_T3 ? 3 : 9);
-    WIW_REQUIRE(a.mode == WIW_A_DENSE || a.C2 == 0, "gemm: concat input only in dense mode");
-    WIW_REQUIRE(a.K == taps * (a.C1 + a.C2), "gemm: K != taps * (C1 + C2)");
+    WIW_REQUIRE(a.mode == WIW_A_DENSE || a.mode == WIW_A_CONV3X3 || a.C2 == 0, "gemm: A2 only in dense / conv3x3 mode");
+    if (a.mode == WIW_A_DENSE) WIW_REQUIRE(a.K == a.C1 + a.C2, "gemm: K != C1 + C2");
+    else WIW_REQUIRE(a.K == taps * a.C1 + a.C2 + a.C3, "gemm: K != taps * C1 (+ C2 + C3 shortcut segment)");
     if (a.mode != WIW_A_DENSE) {
         WIW_REQUIRE(a.H > 0 && a.Wd > 0, "gemm: conv geometry missing");
         WIW_REQUIRE(a.M % (a.H * a.Wd) == 0, "gemm: M must be a multiple of H*W in conv modes");

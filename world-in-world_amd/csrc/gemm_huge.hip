@@ -112,9 +112,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const int chunk = (lane & 7) ^ (rsub & 7);
     const char* const Ab = (const char*)p.A;
     const char* const A2b = (const char*)p.A2;
+    const char* const A3b = (const char*)p.A3;
     const char* const zeros = (const char*)p.zeros;
     const int HW = p.H * p.Wd;
-    const int Ctot = p.C1 + p.C2;
+    const int Ctot = MODE == WIW_A_DENSE ? p.C1 + p.C2 : p.C1;   // channels per tap (the shortcut segment is tap 9)
     const int nk = p.K / HK;
 
     int a_m[4];
@@ -159,6 +160,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             if (!a_ok[i] || (unsigned)tt >= (unsigned)p.T) return zeros;
             return Ab + (((int64_t)a_m[i] + (int64_t)(tap - 1) * HW) * p.C1 + cc + chunk * 8) * 2;
         } else {
+            if (MODE == WIW_A_CONV3X3 && tap == 9) {   // fused 1x1 shortcut: dense segment concat(A2, A3) after the taps
+                if (!a_ok[i]) return zeros;
+                if (cc < p.C2) return A2b + ((int64_t)a_m[i] * p.C2 + cc + chunk * 8) * 2;
+                return A3b + ((int64_t)a_m[i] * p.C3 + (cc - p.C2) + chunk * 8) * 2;
+            }
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
             int row;
             bool ok;
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             glds16(w_row[4] + (int64_t)ld_kt * (HK * 2), sB + 4 * 1024);
             ++ld_kt;
             ld_cc += HK;
-            if (ld_cc == Ctot) { ld_cc = 0; ++ld_tap; }
+            if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
         }
     };
     auto issue_all = [&](int stage) {

@@ -23,9 +23,9 @@ class WiwGemmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("out", C.c_void_p),
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p),
-        ("zeros", C.c_void_p),
+        ("zeros", C.c_void_p), ("A3", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
-        ("C1", C.c_int32), ("C2", C.c_int32), ("mode", C.c_int32),
+        ("C1", C.c_int32), ("C2", C.c_int32), ("C3", C.c_int32), ("mode", C.c_int32),
         ("H", C.c_int32), ("Wd", C.c_int32), ("T", C.c_int32),
         ("ldo", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("n_out", C.c_int32),
         ("rowvec_ld", C.c_int32), ("rows_per_vec", C.c_int32),
@@ -91,7 +91,7 @@ class Hip:
 
     def __init__(self, device: torch.device):
         self.lib = load_library()
-        if self.lib.wiw_abi_version() != 1:
+        if self.lib.wiw_abi_version() != 2:
             raise RuntimeError("libwiwsvd.so ABI version mismatch")
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -115,14 +115,15 @@ class Hip:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.wiw_last_error().decode()}")
 
     # ---- operators
-    def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
+    def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, A3=None, C3=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
              rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,
              ldo=None, epilogue=0, n_out=0):
         a = WiwGemmArgs()
         a.A, a.A2, a.W, a.out = _p(A), _p(A2), _p(W), _p(out)
         a.bias, a.rowvec, a.res1, a.res2 = _p(bias), _p(rowvec), _p(res1), _p(res2)
         a.zeros = self.zeros.data_ptr()
-        a.M, a.N, a.K, a.C1, a.C2, a.mode = M, N, K, C1, C2, mode
+        a.A3 = _p(A3)
+        a.M, a.N, a.K, a.C1, a.C2, a.C3, a.mode = M, N, K, C1, C2, C3, mode
         a.H, a.Wd, a.T = H, Wd, T
         a.ldo = ldo if ldo is not None else (n_out if epilogue & EPI_GEGLU else N)
         a.ldr1, a.ldr2, a.n_out = ldr1, ldr2, n_out

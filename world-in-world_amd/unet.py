@@ -135,10 +135,18 @@ class UNetHIP:
             nonlocal off
             s, t = p + ".spatial_res_block", p + ".temporal_res_block"
             norm(s + ".norm1"); conv3(s + ".conv1"); norm(s + ".norm2"); conv3(s + ".conv2")
-            if s + ".conv_shortcut.weight" in sd:
+            if s + ".conv_shortcut.weight" in sd and os.environ.get("WIW_UNFUSED_SHORTCUT"):   # A/B knob
                 x = self._t(sd, s + ".conv_shortcut.weight")[:, :, 0, 0]
                 w[s + ".conv_shortcut.weight"] = x.to(bf).contiguous()
                 w[s + ".conv_shortcut.bias"] = self._t(sd, s + ".conv_shortcut.bias").contiguous()
+            elif s + ".conv_shortcut.weight" in sd:
+                # the 1x1 shortcut over the (skip-concatenated) block input is a tenth K segment of conv2's implicit
+                # GEMM: W = [conv2 (9*Cout) | shortcut (Cin)], bias = b2 + b_sc — the shortcut tensor is never written
+                x = self._t(sd, s + ".conv_shortcut.weight")[:, :, 0, 0]
+                w2 = self._t(sd, s + ".conv2.weight").permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+                w[s + ".conv2sc.weight"] = torch.cat([w2, x], dim=1).to(bf).contiguous()
+                w[s + ".conv2sc.bias"] = (self._t(sd, s + ".conv2.bias") + self._t(sd, s + ".conv_shortcut.bias")).contiguous()
+                del w[s + ".conv2.weight"], w[s + ".conv2.bias"]
             norm(t + ".norm1"); convt(t + ".conv1"); norm(t + ".norm2"); convt(t + ".conv2")
             for q in (s, t):  # all time_emb_proj layers are evaluated by ONE batched GEMM per step
                 tw = self._t(sd, q + ".time_emb_proj.weight")
@@ -296,16 +304,20 @@ class UNetHIP:
                  bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
                  rows_per_vec=S)
         hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
-        if s + ".conv_shortcut.weight" in w:
-            sc = self._empty(M, Cout)
-            hip.gemm(x1, w[s + ".conv_shortcut.weight"], sc, M=M, N=Cout, K=Cin, C1=C1, A2=x2, C2=C2,
-                     bias=w[s + ".conv_shortcut.bias"])
-        else:
-            assert x2 is None
-            sc = x1
         xs = self._empty(M, Cout)
-        hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                 bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0)
+        if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
+            hip.gemm(hn, w[s + ".conv2sc.weight"], xs, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
+                     A2=x1, C2=C1, A3=x2, C3=C2, bias=w[s + ".conv2sc.bias"])
+        else:
+            if s + ".conv_shortcut.weight" in w:   # unfused A/B path: separate 1x1 GEMM, then residual
+                sc = self._empty(M, Cout)
+                hip.gemm(x1, w[s + ".conv_shortcut.weight"], sc, M=M, N=Cout, K=Cin, C1=C1, A2=x2, C2=C2,
+                         bias=w[s + ".conv_shortcut.bias"])
+            else:
+                assert x2 is None
+                sc = x1
+            hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
+                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0)
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
         xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
