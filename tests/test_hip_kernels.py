@@ -519,3 +519,17 @@ def test_conv3x3_with_fused_shortcut(hip, n, c, c2, c3, cout, h, w):
     skip = torch.cat([s1, s2], dim=1) if c3 else s1
     ref = F.conv2d(x, wt, b, padding=1) + F.conv2d(skip, wsc)
     check(from_nhwc(out, n, h, w), ref, what=f"conv3x3 + fused shortcut {c}|{c2}+{c3}->{cout}")
+
+
+def test_attn_spatial_long_sequence_many_blocks(hip):
+    """A level-1-sized problem: 36 KV tiles per block (lazy rescale in steady state), 1152 blocks over the XCD remap."""
+    frames, S, heads = 8, 2304, 8
+    C = heads * 64
+    qkv = bf(rnd(frames * S, 3 * C, seed=21))
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    qk = dev_bf(torch.cat([q, k], dim=1))
+    vt = dev_bf(v.t().contiguous())
+    o = torch.empty(frames * S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads, 0.125)
+    ref = sdpa(q.reshape(frames, S, C), k.reshape(frames, S, C), v.reshape(frames, S, C), heads).reshape(frames * S, C)
+    check(o, ref, what="attn_spatial 8 x 2304 x 8 heads")
