@@ -207,3 +207,19 @@ def test_cli_accepts_the_reference_launcher_arguments():
         "--task_type navigation --action_strategy micro_cond --action_input_channel 14 --device cuda:0 "
         "--unet_path /x/unet --svd_path /y --log_dir logs --exp_id e1".split())
     assert args.num_frames == 14 and args.action_input_channel == 14
+
+
+def test_launcher_cli_takes_the_manager_command_line():
+    """serve_worker.py is started by the reference manager as `<python> <script> <args...> <w_fd>`
+    (worker_manager.py:324-334): the reference launcher's arguments plus the trailing result-pipe fd must parse,
+    and the standalone forms (--port, --random_weights) too.  No GPU: only the parser is exercised."""
+    import serve_worker
+
+    ap = serve_worker.arg_parser()
+    argv = ("--width 1024 --height 576 --out_width 480 --out_height 480 --num_frames 14 --num_past_obs 1 "
+            "--task_type navigation --action_strategy micro_cond --action_input_channel 14 --device cuda:3 "
+            "--unet_path /ckpt/unet --svd_path /ckpt/svd --log_dir logs --exp_id e1 17").split()
+    a = ap.parse_args(argv)
+    assert a.pipe_fd == 17 and a.port == 0 and a.device == "cuda:3" and a.frontend == "hip" and not a.random_weights
+    b = ap.parse_args(["--random_weights", "--port", "7000", "--batch_size", "1", "--frontend", "torch"])
+    assert b.pipe_fd is None and b.port == 7000 and b.random_weights and b.frontend == "torch"
