@@ -126,17 +126,21 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  * dp/models/transformers/transformer_temporal.py:324, unet:565-566.  `rows_per_unit` = H*W for the
  * per-frame 2D norms and T*H*W for the 5D norms of TemporalResnetBlock (statistics over T too).
  * The input may be the channel concat of two tensors (skip connections, unet_3d_blocks.py:1612).
- *   stats : fp32 [units][32][2] (sum, sum of squares) — MUST be zeroed by the caller (wiw_fill_f32);
+ *   stats : fp32 [units][32][2] (sum, sum of squares), fully overwritten;
+ *   scratch : fp32, >= wiw_groupnorm_scratch_floats(rows, rows_per_unit, rows_per_block) elements (per-block partial
+ *             sums).  The reduction is deterministic: fixed-order sums, no atomics (two launches: partials, then a
+ *             block-order reduce).  rows_per_block (0 = default by unit size) fixes the summation order of a unit
+ *             independently of how many units the call covers — a candidate's bits do not depend on its batch;
  *   ab    : fp32 [units][2][C]  per-channel scale a = rstd*gamma and shift b = beta - mean*a.
  * ---------------------------------------------------------------------------------------------- */
+int64_t wiw_groupnorm_scratch_floats(int64_t rows, int rows_per_unit, int rows_per_block);
 int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
-                        int rows_per_unit, float* stats);
+                        int rows_per_unit, int rows_per_block, float* stats, float* scratch);
 int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta, int units,
                            int C, int rows_per_unit, float eps, float* ab);
 int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
                         int rows_per_unit, const float* ab, int silu, void* out);
-/* finalize + apply in one launch: scale / shift are derived from the raw `stats` inside the kernel.  With a pool of
- * statistics buffers zeroed by ONE wiw_fill_f32 per forward this removes two tiny launches per GroupNorm. */
+/* finalize + apply in one launch: scale / shift are derived from the raw `stats` inside the kernel. */
 int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
                               int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
                               int silu, void* out);
@@ -203,7 +207,7 @@ int wiw_vae_time_conv_out(void* stream, const float* Y, int ldy, const float* we
 int wiw_nchw_f32_to_nhwc_bf16(void* stream, const float* X, int frames, int Cin, int HW, float scale, int Cpad,
                               void* out);
 
-/* Utility: fill fp32 buffer (used to zero GroupNorm statistics inside captured graphs). */
+/* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);
 
 #ifdef __cplusplus

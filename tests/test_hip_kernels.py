@@ -266,17 +266,13 @@ def test_groupnorm(hip, n, c1, c2, h, w, unit_frames):
         check(from_nhwc(out4, n, h, w), ref, what=f"groupnorm (4 entry points) C={c1}+{c2} silu={silu}")
 
 
-def test_groupnorm_stats_pool_refill(hip):
-    """More GroupNorms than pool slots: statistics slots are re-zeroed in bulk and never reused dirty."""
-    n, C, h, w = 2, 64, 4, 8
-    x = bf(rnd(n, C, h, w, seed=4))
-    gamma, beta = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
-    x1 = dev_bf(nhwc(x))
-    ref = F.group_norm(x, 32, gamma, beta, 1e-5)
-    g, b = dev_f(gamma), dev_f(beta)
-    outs = [hip.groupnorm(x1, C, None, 0, n * h * w, h * w, g, b, 1e-5, False) for _ in range(hip.STATS_POOL + 40)]
-    for i in (0, hip.STATS_POOL - 1, hip.STATS_POOL, len(outs) - 1):
-        check(from_nhwc(outs[i], n, h, w), ref, what=f"groupnorm call {i}")
+def test_groupnorm_is_deterministic(hip):
+    """No atomics in the statistics: the same call gives the same BYTES every time (and so does the whole pipeline)."""
+    n, C, h, w = 6, 320, 24, 32
+    x1 = dev_bf(nhwc(bf(rnd(n, C, h, w, seed=4) * 3 + 0.7)))
+    g, b = dev_f(1 + 0.1 * rnd(C, seed=5)), dev_f(0.1 * rnd(C, seed=6))
+    outs = [hip.groupnorm(x1, C, None, 0, n * h * w, h * w * u, g, b, 1e-5, True) for u in (1, 1, 1, 3, 3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[3], outs[4])
 
 
 @pytest.mark.parametrize("rows,C", [(100, 64), (777, 320), (64, 1280), (50, 2048)])

@@ -42,13 +42,15 @@ def main():
         us = timeit(lambda: hip.layernorm(x, M, C, g, b, addvec=av, addvec_ld=C, rows_per_vec=S, sum_out=sm, out=out))
         print(f"layernorm+sum    M={M} C={C}: {us:8.1f} us  {3 * byts / us / 1e6:6.2f} TB/s")
         stats = torch.zeros(frames * 64, device=dev)
+        scratch = torch.empty(max(int(hip.lib.wiw_groupnorm_scratch_floats(M, S, hip.gn_rows_per_block(S, False))), int(hip.lib.wiw_groupnorm_scratch_floats(M, 14 * S, hip.gn_rows_per_block(14 * S, True)))),
+                              device=dev)
         ab = torch.randn(frames * 2 * C, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, S, stats.data_ptr()))
+        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, S, hip.gn_rows_per_block(S, False), stats.data_ptr(), scratch.data_ptr()))
         print(f"gn_stats         M={M} C={C}: {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s")
         us = timeit(lambda: hip.lib.wiw_groupnorm_apply(s, x.data_ptr(), C, None, 0, M, S, ab.data_ptr(), 1, out.data_ptr()))
         print(f"gn_apply(silu)   M={M} C={C}: {us:8.1f} us  {2 * byts / us / 1e6:6.2f} TB/s")
-        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, 14 * S, stats.data_ptr()))
+        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, 14 * S, hip.gn_rows_per_block(14 * S, True), stats.data_ptr(), scratch.data_ptr()))
         print(f"gn_stats (T*S)   M={M} C={C}: {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s")
 
 

@@ -1,6 +1,7 @@
 // GroupNorm(32) in NHWC (statistics / finalize / fused apply + SiLU) and LayerNorm with fused
 // pre-add.  HBM-bound kernels: every global access is 16 B per lane on channel-contiguous rows,
-// reductions use wave shuffles + LDS atomics, statistics are fp32.
+// reductions are deterministic (fixed-order sums through LDS / a block-order second stage; DPP and permlane
+// swaps inside a wave), statistics are fp32.
 #include "common.h"
 
 namespace {
@@ -11,14 +12,20 @@ constexpr int GROUPS = 32;
 // statistics: grid = (row_splits, units).  A block reduces rows [r0, r1) of one unit for ALL channels.
 // Threads are laid out (channel chunk, row lane); a thread keeps per-channel partial sums of its
 // 8 channels in registers, so the inner loop has no group arithmetic.
+// DETERMINISTIC: no atomics anywhere — row lanes are summed in lane order through LDS, channels are folded
+// into groups in channel order, every block writes its 64 partial sums to `partials[unit][block][64]`, and
+// gn_reduce_kernel adds the blocks in block order.  (With fp32 atomics the same request differed by 1.6e-2
+// relative rms between two runs after two Euler steps at full size: a random-init network amplifies last-bit
+// differences; the reference's GroupNorm is deterministic.)
 // ---------------------------------------------------------------------------------------------
+constexpr int GN_MAXC = 4096;
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X1, int C1,
                                                         const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
-                                                        int rows_per_block, float* stats) {
-    __shared__ float bins[GROUPS * 2];
+                                                        int rows_per_block, float* __restrict__ partials) {
+    __shared__ float red[256][17];          // per-thread (sum[8], sumsq[8]); 17: skewed banks
+    __shared__ float chan[2][GN_MAXC];      // per-channel block totals
     const int tid = threadIdx.x;
-    if (tid < GROUPS * 2) bins[tid] = 0.f;
-    __syncthreads();
     const int C = C1 + C2;
     const int cg = C / GROUPS;
     const int chunks = C >> 3;
@@ -30,17 +37,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
     int r1 = r0 + rows_per_block;
     if (r1 > rows_per_unit) r1 = rows_per_unit;
     const int64_t base_row = (int64_t)unit * rows_per_unit;
-    if (rl < rp) {
-        for (int cbase = 0; cbase < chunks; cbase += cpb) {
-            const int chunk = cbase + ci;
-            if (chunk >= chunks) break;
-            const int c0 = chunk * 8;
+    for (int cbase = 0; cbase < chunks; cbase += cpb) {      // uniform trip count: the barriers below are reached by all
+        const int chunk = cbase + ci;
+        const bool active = rl < rp && chunk < chunks;
+        const int c0 = chunk * 8;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (active) {
             const uint16_t* src;
             int ld, coff;
             if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
-            float s[8], q[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
             int r = r0 + rl;
             for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent 16-byte loads in flight per thread
                 uint4 raw[4];
@@ -60,25 +67,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
             }
-            // fold channels of the same group before touching LDS
-            int g_prev = c0 / cg;
-            float gs = 0.f, gq = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int g = (c0 + e) / cg;
-                if (g != g_prev) {
-                    atomicAdd(&bins[g_prev * 2], gs);
-                    atomicAdd(&bins[g_prev * 2 + 1], gq);
-                    gs = 0.f; gq = 0.f; g_prev = g;
-                }
-                gs += s[e]; gq += q[e];
-            }
-            atomicAdd(&bins[g_prev * 2], gs);
-            atomicAdd(&bins[g_prev * 2 + 1], gq);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid][e] = s[e]; red[tid][8 + e] = q[e]; }
+        __syncthreads();
+        if (tid < cpb && chunk < chunks) {   // row lane 0 of every chunk column: add the row lanes in lane order
+            float ts[8], tq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ts[e] = 0.f; tq[e] = 0.f; }
+            for (int j = 0; j < rp; ++j) {
+                const float* rr = red[j * cpb + ci];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ts[e] += rr[e]; tq[e] += rr[8 + e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { chan[0][c0 + e] = ts[e]; chan[1][c0 + e] = tq[e]; }
+        }
+        __syncthreads();
     }
+    if (tid < GROUPS * 2) {   // channels of a group in channel order
+        const int g = tid >> 1, which = tid & 1;
+        float a = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) a += chan[which][c];
+        partials[((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + tid] = a;
+    }
+}
+
+// stats[unit][g][which] = sum over the unit's blocks in a FIXED order: 16 waves each add a contiguous 1/16 of the blocks
+// in block order, wave 0 adds the 16 partial sums in wave order.
+constexpr int GN_RED_PARTS = 16;
+
+__global__ __launch_bounds__(64 * GN_RED_PARTS) void gn_reduce_kernel(const float* __restrict__ partials, int splits,
+                                                                       float* __restrict__ stats) {
+    __shared__ float part[GN_RED_PARTS][GROUPS * 2];
+    const int unit = blockIdx.x, t = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (splits + GN_RED_PARTS - 1) / GN_RED_PARTS;
+    const int b0 = w * per, b1 = b0 + per < splits ? b0 + per : splits;
+    const float* p = partials + (int64_t)unit * splits * (GROUPS * 2) + t;
+    float a = 0.f;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(b + u) * (GROUPS * 2)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+    }
+    for (; b < b1; ++b) a += p[(int64_t)b * (GROUPS * 2)];
+    part[w][t] = a;
     __syncthreads();
-    if (tid < GROUPS * 2) atomicAdd(&stats[(int64_t)unit * GROUPS * 2 + tid], bins[tid]);
+    if (w == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < GN_RED_PARTS; ++k) s += part[k][t];
+        stats[(int64_t)unit * (GROUPS * 2) + t] = s;
+    }
 }
 
 // ab[unit][0][c] = rstd*gamma[c];  ab[unit][1][c] = beta[c] - mean*rstd*gamma[c]
@@ -310,25 +353,38 @@ inline int grid_for(int64_t total, int block, int cap) {
 
 }  // namespace
 
+namespace {
+// Rows per block are chosen by the caller (or default to a function of the unit size) and NEVER depend on the number
+// of units: the summation order of a unit — and with it every bit of a candidate's result — is then the same whether
+// the candidate is evaluated alone or in a batch.
+inline void gn_stats_geometry(int64_t rows, int rows_per_unit, int rows_per_block_in, int* units, int* splits, int* rows_per_block) {
+    *units = (int)(rows / rows_per_unit);
+    *rows_per_block = rows_per_block_in > 0 ? rows_per_block_in : (rows_per_unit <= 16384 ? 128 : 256);
+    *splits = (rows_per_unit + *rows_per_block - 1) / *rows_per_block;
+}
+}  // namespace
+
+extern "C" int64_t wiw_groupnorm_scratch_floats(int64_t rows, int rows_per_unit, int rows_per_block) {
+    if (rows <= 0 || rows_per_unit <= 0 || rows % rows_per_unit != 0 || rows_per_block < 0) return 0;
+    int units, splits, rpb;
+    gn_stats_geometry(rows, rows_per_unit, rows_per_block, &units, &splits, &rpb);
+    return (int64_t)units * splits * (GROUPS * 2);
+}
+
 extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
-                                   int rows_per_unit, float* stats) {
-    WIW_REQUIRE(X1 && stats, "groupnorm_stats: null pointer");
+                                   int rows_per_unit, int rows_per_block_in, float* stats, float* scratch) {
+    WIW_REQUIRE(X1 && stats && scratch, "groupnorm_stats: null pointer");
+    WIW_REQUIRE(rows_per_block_in >= 0, "groupnorm_stats: rows_per_block must be >= 0 (0 = default)");
     WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_stats: X2 iff C2 > 0");
     const int C = C1 + C2;
-    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0, "groupnorm_stats: channels must be %8 and C %32");
+    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0 && C <= GN_MAXC,
+                "groupnorm_stats: channels must be %8, C %32 and C <= 4096");
     WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats: bad rows");
-    const int units = (int)(rows / rows_per_unit);
-    // enough blocks to fill the chip, each reducing >= 64 rows
-    // blocks: every block ends with 64 atomics on its unit's statistics, so few units (the per-clip norms of
-    // TemporalResnetBlock) take half as many blocks: 2.9 -> 4.7 TB/s at C = 320, units = 2
-    int splits = ((units <= 4 ? 1024 : 2048) + units - 1) / units;
-    const int max_splits = (rows_per_unit + 63) / 64;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    const int rows_per_block = (rows_per_unit + splits - 1) / splits;
-    splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    int units, splits, rows_per_block;
+    gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
-                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, stats);
+                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, scratch);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits, stats);
     return wiw_check_launch("wiw_groupnorm_stats");
 }
 

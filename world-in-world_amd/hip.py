@@ -43,8 +43,9 @@ EXPORTS = {
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "wiw_attn_temporal_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_float]),
-    "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
-                                      C.c_void_p]),
+    "wiw_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
     "wiw_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_void_p]),
     "wiw_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
@@ -150,55 +151,55 @@ class Hip:
                  "wiw_attn_temporal_bf16")
         return O
 
-    # GroupNorm statistics come from a pool that is zeroed by ONE fill per `STATS_POOL` norms (instead of a fill
-    # launch per norm); every slot is used once between refills, so in-flight kernels never share a slot.
-    STATS_POOL = 256           # slots
-    STATS_SLOT = 64 * 64       # floats per slot: up to 64 units x 32 groups x (sum, sumsq)
+    @staticmethod
+    def gn_rows_per_block(rows_per_unit: int, clip: bool) -> int:
+        """Block size of the statistics pass — a function of the unit size and the KIND of norm only (never of the
+        batch): per-frame norms (28+ units per request) use large blocks, per-clip norms (one unit per CFG item:
+        TemporalResnetBlock) split a unit into ~500 blocks."""
+        if not clip:
+            return 128 if rows_per_unit >= 8192 else (64 if rows_per_unit >= 2048 else (32 if rows_per_unit >= 512 else 16))
+        rpb = 16
+        while rpb < 256 and rpb * 2 * 448 <= rows_per_unit:
+            rpb *= 2
+        return rpb
 
-    def _stats_slot(self, units: int) -> torch.Tensor:
-        need = units * 64
-        if need > self.STATS_SLOT:   # rare (many units): private zeroed buffer
-            return torch.zeros(need, dtype=torch.float32, device=self.device)
-        if getattr(self, "_stats_pool", None) is None or self._stats_next >= self.STATS_POOL:
-            # a fresh pool per refill: kernels still queued on the stream keep using the old one (torch's caching
-            # allocator does not hand the block out again before the stream has passed its last use)
-            self._stats_pool = torch.empty(self.STATS_POOL * self.STATS_SLOT, dtype=torch.float32, device=self.device)
-            self._ck(self.lib.wiw_fill_f32(self._stream(), self._stats_pool.data_ptr(), self._stats_pool.numel(), 0.0),
-                     "wiw_fill_f32")
-            self._stats_next = 0
-        i = self._stats_next
-        self._stats_next += 1
-        return self._stats_pool[i * self.STATS_SLOT: i * self.STATS_SLOT + need]
-
-    def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None):
-        """statistics -> fused finalize + apply; returns the normalised (and SiLU'd) bf16 tensor [rows, C1+C2]."""
-        if os.environ.get("WIW_GN_UNFUSED"):   # A/B knob for profiling
-            return self.groupnorm_unfused(X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out)
-        Ct = C1 + C2
+    def _gn_buffers(self, rows, rows_per_unit, rpb):
+        """(stats [units*64], scratch) — both fully written by wiw_groupnorm_stats (deterministic two-stage reduction)."""
         units = rows // rows_per_unit
-        stats = self._stats_slot(units)
+        n = int(self.lib.wiw_groupnorm_scratch_floats(rows, rows_per_unit, rpb))
+        buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
+        return buf[: units * 64], buf[units * 64:]
+
+    def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False):
+        """statistics (deterministic, no atomics) -> fused finalize + apply; returns the normalised (and SiLU'd) bf16
+        tensor [rows, C1+C2].  clip=True: the unit is a whole clip (T frames), see gn_rows_per_block."""
+        if os.environ.get("WIW_GN_UNFUSED"):   # A/B knob for profiling
+            return self.groupnorm_unfused(X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out, clip)
+        Ct = C1 + C2
+        rpb = self.gn_rows_per_block(rows_per_unit, clip)
+        stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
         if out is None:
             out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
         s = self._stream()
-        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr()),
-                 "wiw_groupnorm_stats")
+        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
+                                              scratch.data_ptr()), "wiw_groupnorm_stats")
         self._ck(self.lib.wiw_groupnorm_apply_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
                                                     _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr()),
                  "wiw_groupnorm_apply_stats")
         return out
 
-    def groupnorm_unfused(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None):
-        """fill -> stats -> finalize -> apply through the four separate entry points (kept for the ABI tests)."""
+    def groupnorm_unfused(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False):
+        """stats -> finalize -> apply through the three separate entry points (kept for the ABI tests)."""
         Ct = C1 + C2
         units = rows // rows_per_unit
-        stats = torch.empty(units * 64, dtype=torch.float32, device=self.device)
+        rpb = self.gn_rows_per_block(rows_per_unit, clip)
+        stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
         ab = torch.empty(units * 2 * Ct, dtype=torch.float32, device=self.device)
         if out is None:
             out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
         s = self._stream()
-        self._ck(self.lib.wiw_fill_f32(s, stats.data_ptr(), units * 64, 0.0), "wiw_fill_f32")
-        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr()),
-                 "wiw_groupnorm_stats")
+        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
+                                              scratch.data_ptr()), "wiw_groupnorm_stats")
         self._ck(self.lib.wiw_groupnorm_finalize(s, stats.data_ptr(), _p(gamma), _p(beta), units, Ct, rows_per_unit,
                                                  eps, ab.data_ptr()), "wiw_groupnorm_finalize")
         self._ck(self.lib.wiw_groupnorm_apply(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, ab.data_ptr(),

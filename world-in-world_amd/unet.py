@@ -319,11 +319,11 @@ class UNetHIP:
             hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
                      bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0)
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
-        xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True)
+        xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True, clip=True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
                  bias=w[t + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[t]:], rowvec_ld=self.temb_total,
                  rows_per_vec=S)
-        hn = hip.groupnorm(h, Cout, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], eps, True, out=hn)
+        hn = hip.groupnorm(h, Cout, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], eps, True, out=hn, clip=True)
         a = self.alpha[p]
         out = self._empty(M, Cout)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2(h) + b) = xs + (1-a)*(acc + b)   (resnet.py:784-797)

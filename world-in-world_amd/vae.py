@@ -173,11 +173,11 @@ class VAEHIP:
         S = H * W
         xs, C = self._res2d(p + ".spatial_res_block", x, Cin, M, H, W, 1e-6)
         t = p + ".temporal_res_block"
-        xn = hip.groupnorm(xs, C, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], 1e-5, True)
+        xn = hip.groupnorm(xs, C, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], 1e-5, True, clip=True)
         h = self._empty(M, C)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=C, K=3 * C, C1=C, mode=A_CONV_T3, H=H, Wd=W, T=T,
                  bias=w[t + ".conv1.bias"])
-        hn = hip.groupnorm(h, C, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], 1e-5, True, out=xn)
+        hn = hip.groupnorm(h, C, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], 1e-5, True, out=xn, clip=True)
         # (1-s)*xs + s*(xs + conv2(hn) + b) = xs + s*(acc + b)
         hip.gemm(hn, w[t + ".conv2.weight"], h, M=M, N=C, K=3 * C, C1=C, mode=A_CONV_T3, H=H, Wd=W, T=T,
                  bias=w[t + ".conv2.bias"], alpha=self.mix[p], res1=xs, ldr1=C, beta1=1.0)
