@@ -185,7 +185,7 @@ int wiw_cfg_euler_step(void* stream, const float* V, int ldv, float* latents, in
                        float sigma_next, float gmin, float gmax);
 
 /* ------------------------------------------------------------------------------------------------
- * Temporal VAE (SURVEY.md §8 rows a5 / a20 — the callers either side of the denoising loop).  The VAE
+ * Temporal VAE (SURVEY.md §8 rows a6 / a20 — the callers either side of the denoising loop).  The VAE
  * reuses wiw_gemm_bf16 (3x3 / stride-2 / upsample / temporal convolutions, 1x1 shortcuts, attention
  * projections) and the GroupNorm entry points; three operators exist only for it:
  *

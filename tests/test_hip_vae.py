@@ -1,4 +1,4 @@
-"""Temporal VAE on the HIP kernels (SURVEY.md §8 rows a5 / a20) against the fp32 functional restatement in
+"""Temporal VAE on the HIP kernels (SURVEY.md §8 rows a6 / a20) against the fp32 functional restatement in
 frontend.py, which tests/test_frontend.py pins to the reference VAE through tests/golden/frontend_tiny.npz.
 
 Tolerances: the HIP path keeps activations in bf16 between layers (as the reference does under its bf16

@@ -1,4 +1,4 @@
-// Kernels that exist only for the temporal VAE (SURVEY.md §8 rows a5 / a20, the "next" rows f1 / f4):
+// Kernels that exist only for the temporal VAE (SURVEY.md §8 rows a6 / a20, the "next" rows f1 / f4):
 //   * row softmax fp32 -> bf16 for the single-head, head_dim = C (512) attention of the VAE mid blocks, which is
 //     evaluated as two MFMA GEMMs (scores = Q.K^T, out = P.V) around this kernel — a 512-wide head does not fit the
 //     register budget of the flash kernel in attention.hip, and this attention is ~2 % of a decode;

@@ -1,5 +1,5 @@
 """Temporal VAE (AutoencoderKLTemporalDecoder) on the hand-written gfx950 kernels: the callers either side of
-the denoising loop (SURVEY.md §8 rows a5 `_encode_vae_image`, a20 `decode_latents`; "next" rows f1 / f4).
+the denoising loop (SURVEY.md §8 rows a6 `_encode_vae_image`, a20 `decode_latents`; "next" rows f1 / f4).
 
 Why it is not left to PyTorch-ROCm: on a fresh MI355X box the MIOpen convolutions behind `F.conv2d` / `F.conv3d`
 need > 6 minutes for ONE 576x1024x14 decode (measured) against ~3 s for the 25-step denoise; the
