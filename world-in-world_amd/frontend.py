@@ -216,12 +216,19 @@ def resize_with_antialiasing(x: torch.Tensor, size=(224, 224)) -> torch.Tensor:
     sig = (max((fac[0] - 1.0) / 2.0, 0.001), max((fac[1] - 1.0) / 2.0, 0.001))
     ks = [int(max(2.0 * 2 * s, 3)) for s in sig]
     ks = [k + 1 if k % 2 == 0 else k for k in ks]
-    b, c = x.shape[:2]
-    kx = _gaussian(ks[1], sig[1], x.dtype).to(x.device).reshape(1, 1, 1, -1).expand(c, 1, 1, -1)
-    ky = _gaussian(ks[0], sig[0], x.dtype).to(x.device).reshape(1, 1, -1, 1).expand(c, 1, -1, 1)
+    kx = _gaussian(ks[1], sig[1], x.dtype).tolist()
+    ky = _gaussian(ks[0], sig[0], x.dtype).tolist()
     px, py = ks[1] - 1, ks[0] - 1
-    out = F.conv2d(F.pad(x, (px // 2, px - px // 2, 0, 0), mode="reflect"), kx, groups=c)
-    out = F.conv2d(F.pad(out, (0, 0, py // 2, py - py // 2), mode="reflect"), ky, groups=c)
+    # the separable depthwise blur as explicit tap sums (3-7 taps): on ROCm the grouped fp32 F.conv2d of the reference
+    # falls to MIOpen's naive kernel (2.3 ms per call at 576x1024, 18 ms per request); same taps, same order
+    xp = F.pad(x, (px // 2, px - px // 2, 0, 0), mode="reflect")
+    out = kx[0] * xp[..., 0:w]
+    for k in range(1, ks[1]):
+        out = out + kx[k] * xp[..., k:k + w]
+    yp = F.pad(out, (0, 0, py // 2, py - py // 2), mode="reflect")
+    out = ky[0] * yp[..., 0:h, :]
+    for k in range(1, ks[0]):
+        out = out + ky[k] * yp[..., k:k + h, :]
     return F.interpolate(out, size=size, mode="bicubic", align_corners=True)
 
 
