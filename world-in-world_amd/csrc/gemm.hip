@@ -31,6 +31,7 @@
 #define WIW_ABLATE 0
 #endif
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -664,19 +665,20 @@ template <int MODE, int NW, int STAGES, bool GE>
 int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     constexpr int BM = NW * 32;
     constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES);
-    static bool attr_set = false;
+    // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
+    static std::once_flag once;
+    static bool attr_ok = false;
     static int num_cu = 256;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM) != hipSuccess) {
-            wiw_set_error("hipFuncSetAttribute(gemm) failed");
-            return WIW_ELAUNCH;
-        }
+    std::call_once(once, [] {
+        attr_ok = hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             num_cu = prop.multiProcessorCount;
-        attr_set = true;
+    });
+    if (!attr_ok) {
+        wiw_set_error("hipFuncSetAttribute(gemm) failed");
+        return WIW_ELAUNCH;
     }
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     int64_t grid = (int64_t)num_cu * blocks_per_cu;   // persistent: every CU slot gets one block

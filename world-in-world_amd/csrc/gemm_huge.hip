@@ -22,6 +22,7 @@
 #define WIW_ABLATE 0
 #endif
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -466,19 +467,20 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 
 template <int MODE, bool GE>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
-    static bool attr_set = false;
+    // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
+    static std::once_flag once;
+    static bool attr_ok = false;
     static int num_cu = 256;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) !=
-            hipSuccess) {
-            wiw_set_error("hipFuncSetAttribute(gemm_huge) failed");
-            return WIW_ELAUNCH;
-        }
+    std::call_once(once, [] {
+        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             num_cu = prop.multiProcessorCount;
-        attr_set = true;
+    });
+    if (!attr_ok) {
+        wiw_set_error("hipFuncSetAttribute(gemm_huge) failed");
+        return WIW_ELAUNCH;
     }
     const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
     int64_t grid = num_cu;
