@@ -51,7 +51,6 @@ def arg_parser():
     ap = build_arg_parser()
     ap.add_argument("--random_weights", action="store_true", help="random-init UNet / VAE / CLIP (no checkpoints)")
     ap.add_argument("--host", type=str, default="127.0.0.1")
-    ap.add_argument("--frontend", choices=["hip", "torch"], default="hip", help="VAE encode/decode implementation")
     ap.add_argument("pipe_fd", nargs="?", type=int, default=None, help="result-pipe fd appended by the manager")
     return ap
 
@@ -68,10 +67,9 @@ def build_worker(args) -> SVDWorker:
     den = SVDDenoiser(unet)
     dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}[args.weight_dtype]
     clip = _clip(args.svd_path, args.random_weights)
-    if args.frontend == "hip":     # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module
-        fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip), clip, dtype=dtype)
-    else:                          # everything around the denoiser through PyTorch-ROCm / MIOpen
-        fe = FE.TorchFrontend(vae_sd, clip, device=args.device, dtype=dtype)
+    # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module.  There is no PyTorch / MIOpen VAE
+    # route in the product (it needed > 6 minutes per decode on a fresh box); the fp32 PyTorch chain lives in oracle/.
+    fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip), clip, dtype=dtype)
 
     def denoise(image_latents, image_embeddings, noise, actions, **kw) -> np.ndarray:
         return den.denoise(torch.from_numpy(image_latents), torch.from_numpy(image_embeddings),

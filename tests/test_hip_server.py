@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import svd_oracle as O
+import vae_oracle as VO
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +32,7 @@ def test_worker_end_to_end_matches_oracle_chain(tmp_path):
                                                           num_attention_heads=2, image_size=224, patch_size=32,
                                                           projection_dim=1024)).eval()
     den = SVDDenoiser(UNetHIP(cfg, sd, "cuda:0"))
-    fe_gpu = FE.TorchFrontend(vsd, clip, device="cuda:0", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
+    fe_gpu = VO.TorchFrontend(vsd, clip, device="cuda:0", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
 
     def denoise(il, ie, nz, act, **kw):
         return den.denoise(torch.from_numpy(il), torch.from_numpy(ie), torch.from_numpy(nz), act, **kw).cpu().numpy()
@@ -54,7 +55,7 @@ def test_worker_end_to_end_matches_oracle_chain(tmp_path):
     assert pf.shape == (2, T, 3, 48, 64) and pf.dtype == np.uint8
 
     # the same chain on the CPU: fp32 frontend + oracle loop, same draws
-    fe_cpu = FE.TorchFrontend(vsd, clip, device="cpu", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
+    fe_cpu = VO.TorchFrontend(vsd, clip, device="cpu", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
     _, _, _, images = P.parse_request(req)
     x = np.stack([P.preprocess_image(im, W, H) for im in images])
     il, ie = fe_cpu.encode(x, draws[0], 0.02)

@@ -1,5 +1,5 @@
 """Temporal VAE on the HIP kernels against the fp32 functional restatement in
-frontend.py, which tests/test_frontend.py pins to the reference VAE through tests/golden/frontend_tiny.npz.
+oracle/vae_oracle.py, which tests/test_frontend.py pins to the reference VAE through tests/golden/frontend_tiny.npz.
 
 Tolerances: the HIP path keeps activations in bf16 between layers (as the reference does under its bf16
 `weight_dtype`); against the fp32 chain the accumulated rounding of ~60 layers is gated at 3e-2 relative rms
@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+import vae_oracle as VO
 
 pytestmark = pytest.mark.gpu
 
@@ -105,7 +107,7 @@ def test_vae_decode_matches_fp32_chain(vae_pair):
     T, h, w = 4, 16, 32
     z = rnd(T, 4, h, w, seed=7) * 3.0
     out = vae.decode_frames(z)
-    ref = FE.vae_decode(sd, z, T, len(VCFG["block_out_channels"]), VCFG["layers_per_block"])
+    ref = VO.vae_decode(sd, z, T, len(VCFG["block_out_channels"]), VCFG["layers_per_block"])
     mx, rms = rel(out, ref)
     print(f"[parity] VAE decode {T}x{8 * h}x{8 * w}: max_rel={mx:.3e} rms_rel={rms:.3e}")
     assert out.shape == (T, 3, 8 * h, 8 * w) and rms <= 3e-2
@@ -122,7 +124,7 @@ def test_vae_encode_matches_fp32_chain(vae_pair):
     vae, sd = vae_pair
     x = torch.tanh(rnd(2, 3, 128, 256, seed=9))
     out = vae.encode_mode(x)
-    ref = FE.vae_encode_mode(sd, x, len(VCFG["block_out_channels"]), VCFG["layers_per_block"])
+    ref = VO.vae_encode_mode(sd, x, len(VCFG["block_out_channels"]), VCFG["layers_per_block"])
     mx, rms = rel(out, ref)
     print(f"[parity] VAE encode 2x128x256: max_rel={mx:.3e} rms_rel={rms:.3e}")
     assert out.shape == (2, 4, 16, 32) and rms <= 3e-2

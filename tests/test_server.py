@@ -220,6 +220,6 @@ def test_launcher_cli_takes_the_manager_command_line():
             "--task_type navigation --action_strategy micro_cond --action_input_channel 14 --device cuda:3 "
             "--unet_path /ckpt/unet --svd_path /ckpt/svd --log_dir logs --exp_id e1 17").split()
     a = ap.parse_args(argv)
-    assert a.pipe_fd == 17 and a.port == 0 and a.device == "cuda:3" and a.frontend == "hip" and not a.random_weights
-    b = ap.parse_args(["--random_weights", "--port", "7000", "--batch_size", "1", "--frontend", "torch"])
-    assert b.pipe_fd is None and b.port == 7000 and b.random_weights and b.frontend == "torch"
+    assert a.pipe_fd == 17 and a.port == 0 and a.device == "cuda:3" and not a.random_weights
+    b = ap.parse_args(["--random_weights", "--port", "7000", "--batch_size", "1"])
+    assert b.pipe_fd is None and b.port == 7000 and b.random_weights

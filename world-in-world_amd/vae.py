@@ -16,7 +16,7 @@ Reference modules restated (dp/ = FTsvd/diffusers-private/diffusers/):
   * the single-head (head_dim = C) self-attention of both mid blocks (legacy `AttnProcessor`).
 Layout: token-major NHWC bf16 rows m = (frame*H + y)*W + x, fp32 accumulation and statistics; the reference runs
 these modules in bf16 (`weight_dtype`), see pipeline:525-531, 615-620.  The parity checker is the fp32 functional
-restatement in frontend.py (itself pinned to the reference by tests/golden/frontend_tiny.npz).
+restatement in oracle/vae_oracle.py (itself pinned to the reference by tests/golden/frontend_tiny.npz).
 """
 from __future__ import annotations
 
