@@ -112,3 +112,31 @@ def test_noise_rotation_is_a_roll_chain(acts, seed):
             assert fwd or torch.equal(out[0, i], torch.roll(out[0, i - 1], -shift, dims=-1))
         else:
             assert torch.equal(out[0, i], noise[0, i])
+
+
+@settings(max_examples=50, deadline=None)
+@given(st.integers(2, 80))
+def test_scheduler_tables_for_any_step_count(n):
+    """Karras rho=7 table (scheduler:476-499): product host code == oracle bit for bit, strictly decreasing from 700 to
+    0.002, terminal 0; continuous timesteps t = 0.25 ln sigma; init_noise_sigma = sqrt(sigma_max^2 + 1)."""
+    s, so = PL.karras_sigmas(n), O.karras_sigmas(n)
+    assert s.dtype == np.float32 and np.array_equal(s, so) and len(s) == n + 1
+    assert s[0] == np.float32(700.0) and abs(float(s[-2]) - 0.002) < 1e-6 and s[-1] == 0.0
+    assert (np.diff(s) < 0).all()
+    assert np.array_equal(PL.sigma_to_timestep(s), O.sigma_to_timestep(so))
+    assert PL.init_noise_sigma(s) == O.init_noise_sigma(so) == float((700.0 ** 2 + 1) ** 0.5)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.floats(0.01, 700.0), st.floats(0.0, 1.0), st.integers(0, 10 ** 6))
+def test_euler_step_is_affine_in_latents_and_prediction(sigma, frac, seed):
+    """EulerDiscreteScheduler.step with v-prediction (scheduler:635-673) is affine: step(a v1 + b v2, a x1 + b x2) =
+    a step(v1, x1) + b step(v2, x2) for a + b = 1 — and sigma_next = sigma is the identity."""
+    g = torch.Generator().manual_seed(seed)
+    v1, v2, x1, x2 = (torch.randn(2, 3, 4, generator=g, dtype=torch.float64) for _ in range(4))
+    sn = sigma * frac
+    a, b = 0.3, 0.7
+    lhs = O.euler_step(a * v1 + b * v2, a * x1 + b * x2, sigma, sn)
+    rhs = a * O.euler_step(v1, x1, sigma, sn) + b * O.euler_step(v2, x2, sigma, sn)
+    assert torch.allclose(lhs.double(), rhs.double(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(O.euler_step(v1, x1, sigma, sigma).double(), x1, rtol=1e-5, atol=1e-5)
