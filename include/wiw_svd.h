@@ -126,10 +126,12 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  * dp/models/transformers/transformer_temporal.py:324, unet:565-566.  `rows_per_unit` = H*W for the
  * per-frame 2D norms and T*H*W for the 5D norms of TemporalResnetBlock (statistics over T too).
  * The input may be the channel concat of two tensors (skip connections, unet_3d_blocks.py:1612).
- *   stats : fp32 [units][32][2] (sum, sum of squares), fully overwritten;
- *   scratch : fp32, >= wiw_groupnorm_scratch_floats(rows, rows_per_unit, rows_per_block) elements (per-block partial
- *             sums).  The reduction is deterministic: fixed-order sums, no atomics (two launches: partials, then a
- *             block-order reduce).  rows_per_block (0 = default by unit size) fixes the summation order of a unit
+ *   stats : fp32 [units][32][2] (mean, biased variance) per group, fully overwritten.  Numerically stable: shifted
+ *           sums per thread, then Chan merges of (count, mean, M2) — no E[x^2] - mean^2 cancellation (ABI v3;
+ *           v2 stored raw (sum, sum of squares));
+ *   scratch : fp32, >= wiw_groupnorm_scratch_floats(rows, rows_per_unit, rows_per_block) elements (per-block
+ *             (mean, M2) pairs).  The reduction is deterministic: fixed merge order, no atomics (two launches:
+ *             partials, then a block-order merge).  rows_per_block (0 = default by unit size) fixes the summation order of a unit
  *             independently of how many units the call covers — a candidate's bits do not depend on its batch;
  *   ab    : fp32 [units][2][C]  per-channel scale a = rstd*gamma and shift b = beta - mean*a.
  * ---------------------------------------------------------------------------------------------- */

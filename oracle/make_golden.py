@@ -19,6 +19,9 @@ Fixtures written (all fp32 unless noted):
   blocks_tiny.npz          inputs/outputs of one SpatioTemporalResBlock (with shortcut) and one
                            TransformerSpatioTemporalModel captured by forward hooks
   frontend_tiny.npz        AutoencoderKLTemporalDecoder encode-mode / decode and `_resize_with_antialiasing` (tiny random VAE)
+  unet_full_16x32.npz      FULL-WIDTH UNet (320/640/1280/1280, 5/10/20/20 heads, T = 14 — the served architecture) forward
+                           at latent 16x32, B=1 with CFG: fp32 reference output, the reference's own bf16 run, and the
+                           reference run in fp32 with bf16-ROUNDED WEIGHTS (the error floor of any bf16-weight evaluation)
   pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
 """
@@ -183,6 +186,29 @@ def gen_unet(ns):
          out_contract=contract.numpy())
 
 
+def gen_unet_full(ns):
+    """The served architecture at a latent the CPU finishes in seconds (full-width parity)."""
+    cfg = UNetConfig()
+    h, w = 16, 32
+    t = 0.68666  # t_12 of the 25-step table (sigma 15.59)
+    sample, ehs, tids, acts = unet_inputs(cfg, 1, h, w, seed=21)
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    m = ref_unet(ns, cfg, seed=4)
+    args = (torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids))
+    with torch.no_grad():
+        out = m(*args, return_dict=False, added_action_ids=aid)[0]
+        # fp32 arithmetic, bf16-rounded weights: what ANY implementation holding bf16 weights starts from
+        for prm in m.parameters():
+            prm.data = prm.data.to(torch.bfloat16).to(torch.float32)
+        out_w = m(*args, return_dict=False, added_action_ids=aid)[0]
+        m = m.to(torch.bfloat16)
+        out_bf16 = m(args[0].bfloat16(), args[1], args[2].bfloat16(), args[3].bfloat16(), return_dict=False,
+                     added_action_ids=aid.bfloat16())[0]
+    save("unet_full_16x32.npz", weight_seed=np.array(4), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
+         added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(),
+         out_ref_bf16_weights_fp32_math=out_w.numpy(), out_ref_bf16=out_bf16.float().numpy())
+
+
 def gen_pipeline(ns):
     from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
     from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
@@ -303,12 +329,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
-    gen_scheduler(ns)
-    gen_action_ids(ns)
-    gen_noise_rotation(ns)
-    gen_unet(ns)
-    gen_pipeline(ns)
-    gen_frontend(ns)
+    gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
+                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full)
+    only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
+    for name, fn in gens.items():
+        if not only or name in only:
+            fn(ns)
 
 
 if __name__ == "__main__":

@@ -12,19 +12,33 @@ constexpr int GROUPS = 32;
 // statistics: grid = (row_splits, units).  A block reduces rows [r0, r1) of one unit for ALL channels.
 // Threads are laid out (channel chunk, row lane); a thread keeps per-channel partial sums of its
 // 8 channels in registers, so the inner loop has no group arithmetic.
-// DETERMINISTIC: no atomics anywhere — row lanes are summed in lane order through LDS, channels are folded
-// into groups in channel order, every block writes its 64 partial sums to `partials[unit][block][64]`, and
-// gn_reduce_kernel adds the blocks in block order.  (With fp32 atomics the same request differed by 1.6e-2
-// relative rms between two runs after two Euler steps at full size: a random-init network amplifies last-bit
-// differences; the reference's GroupNorm is deterministic.)
+// NUMERICALLY STABLE: a thread accumulates SHIFTED sums  sum(x - p), sum((x - p)^2)  around a per-channel pivot p (the
+// first row it sees), turns them into (mean, M2 = sum (x - mean)^2) and every later stage MERGES (count, mean, M2)
+// triples with Chan's pairwise formula — row lanes in lane order, channels of a group in channel order, blocks in block
+// order.  The single-pass E[x^2] - mean^2 of round 1 lost the variance for |mean| >> std (torch uses Welford; trained
+// SVD activations have outlier channels).
+// DETERMINISTIC: no atomics anywhere — every merge order is fixed; every block writes its 32 (mean, M2) pairs to
+// `partials[unit][block][32][2]`, and gn_reduce_kernel merges the blocks in block order.  (With fp32 atomics the same
+// request differed by 1.6e-2 relative rms between two runs after two Euler steps at full size: a random-init network
+// amplifies last-bit differences; the reference's GroupNorm is deterministic.)
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_MAXC = 4096;
+
+// (na, ma, Ma) <- merge with (nb, mb, Mb);  counts are exact small integers held in fp32
+WIW_DEV void chan_merge(float& na, float& ma, float& Ma, float nb, float mb, float Mb) {
+    if (nb <= 0.f) return;
+    if (na <= 0.f) { na = nb; ma = mb; Ma = Mb; return; }
+    const float n = na + nb, d = mb - ma, f = nb / n;
+    ma = __builtin_fmaf(d, f, ma);
+    Ma = Ma + Mb + d * d * na * f;
+    na = n;
+}
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X1, int C1,
                                                         const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
                                                         int rows_per_block, float* __restrict__ partials) {
-    __shared__ float red[256][17];          // per-thread (sum[8], sumsq[8]); 17: skewed banks
-    __shared__ float chan[2][GN_MAXC];      // per-channel block totals
+    __shared__ float red[256][17];          // per-thread (mean[8], M2[8]); 17: skewed banks
+    __shared__ float chan[2][GN_MAXC];      // per-channel block (mean, M2)
     const int tid = threadIdx.x;
     const int C = C1 + C2;
     const int cg = C / GROUPS;
@@ -39,16 +53,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
     const int64_t base_row = (int64_t)unit * rows_per_unit;
     for (int cbase = 0; cbase < chunks; cbase += cpb) {      // uniform trip count: the barriers below are reached by all
         const int chunk = cbase + ci;
-        const bool active = rl < rp && chunk < chunks;
+        const bool active = rl < rp && chunk < chunks && r0 + rl < r1;
         const int c0 = chunk * 8;
-        float s[8], q[8];
+        float s[8], q[8], pv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; pv[e] = 0.f; }
+        int cnt = 0;
         if (active) {
             const uint16_t* src;
             int ld, coff;
             if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
             int r = r0 + rl;
+            unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), pv);   // pivot = first row (re-read below: L1 hit)
             for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent 16-byte loads in flight per thread
                 uint4 raw[4];
 #pragma unroll
@@ -58,69 +74,84 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
                     float f[8];
                     unpack8(raw[u], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                    for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = __builtin_fmaf(d, d, q[e]); }
                 }
+                cnt += 4;
             }
             for (; r < r1; r += rp) {
                 float f[8];
                 unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = __builtin_fmaf(d, d, q[e]); }
+                ++cnt;
             }
         }
+        {
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { red[tid][e] = s[e]; red[tid][8 + e] = q[e]; }
+            for (int e = 0; e < 8; ++e) {
+                const float ms = s[e] * inv;                       // mean of the shifted values
+                red[tid][e] = pv[e] + ms;
+                red[tid][8 + e] = fmaxf(q[e] - s[e] * ms, 0.f);    // M2 around the thread's own mean
+            }
+        }
         __syncthreads();
-        if (tid < cpb && chunk < chunks) {   // row lane 0 of every chunk column: add the row lanes in lane order
-            float ts[8], tq[8];
+        if (tid < cpb && chunk < chunks) {   // row lane 0 of every chunk column: merge the row lanes in lane order
+            float tn[8], tm[8], tM[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ts[e] = 0.f; tq[e] = 0.f; }
+            for (int e = 0; e < 8; ++e) { tn[e] = 0.f; tm[e] = 0.f; tM[e] = 0.f; }
             for (int j = 0; j < rp; ++j) {
+                const int left = r1 - r0 - j;
+                const float nj = left > 0 ? (float)((left + rp - 1) / rp) : 0.f;   // rows row-lane j walked
                 const float* rr = red[j * cpb + ci];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { ts[e] += rr[e]; tq[e] += rr[8 + e]; }
+                for (int e = 0; e < 8; ++e) chan_merge(tn[e], tm[e], tM[e], nj, rr[e], rr[8 + e]);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { chan[0][c0 + e] = ts[e]; chan[1][c0 + e] = tq[e]; }
+            for (int e = 0; e < 8; ++e) { chan[0][c0 + e] = tm[e]; chan[1][c0 + e] = tM[e]; }
         }
         __syncthreads();
     }
-    if (tid < GROUPS * 2) {   // channels of a group in channel order
-        const int g = tid >> 1, which = tid & 1;
-        float a = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) a += chan[which][c];
-        partials[((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + tid] = a;
+    if (tid < GROUPS) {   // channels of a group in channel order; every channel carries (r1 - r0) rows
+        const int g = tid;
+        const float nr = (float)(r1 - r0);
+        float n = 0.f, m = 0.f, M2 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) chan_merge(n, m, M2, nr, chan[0][c], chan[1][c]);
+        float* dst = partials + ((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + 2 * g;
+        dst[0] = m;
+        dst[1] = M2;
     }
 }
 
-// stats[unit][g][which] = sum over the unit's blocks in a FIXED order: 16 waves each add a contiguous 1/16 of the blocks
-// in block order, wave 0 adds the 16 partial sums in wave order.
+// stats[unit][g] = (mean, biased variance) of the whole unit: the blocks' (count, mean, M2) triples are merged in a
+// FIXED order: 16 waves each merge a contiguous 1/16 of the blocks in block order (lane = group), wave 0 merges the 16
+// results in wave order.  Block b of a unit holds min(rows_per_block, rows_per_unit - b*rows_per_block) * cg elements.
 constexpr int GN_RED_PARTS = 16;
 
 __global__ __launch_bounds__(64 * GN_RED_PARTS) void gn_reduce_kernel(const float* __restrict__ partials, int splits,
+                                                                       int rows_per_unit, int rows_per_block, int cg,
                                                                        float* __restrict__ stats) {
-    __shared__ float part[GN_RED_PARTS][GROUPS * 2];
+    __shared__ float part[GN_RED_PARTS][GROUPS][3];
     const int unit = blockIdx.x, t = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (splits + GN_RED_PARTS - 1) / GN_RED_PARTS;
     const int b0 = w * per, b1 = b0 + per < splits ? b0 + per : splits;
-    const float* p = partials + (int64_t)unit * splits * (GROUPS * 2) + t;
-    float a = 0.f;
-    int b = b0;
-    for (; b + 4 <= b1; b += 4) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = p[(int64_t)(b + u) * (GROUPS * 2)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a += v[u];
+    if (t < GROUPS) {
+        const float2* p = (const float2*)(partials + (int64_t)unit * splits * (GROUPS * 2)) + t;
+        float n = 0.f, m = 0.f, M2 = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            const int rows = rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
+            const float2 v = p[(int64_t)b * GROUPS];
+            chan_merge(n, m, M2, (float)rows * (float)cg, v.x, v.y);
+        }
+        part[w][t][0] = n; part[w][t][1] = m; part[w][t][2] = M2;
     }
-    for (; b < b1; ++b) a += p[(int64_t)b * (GROUPS * 2)];
-    part[w][t] = a;
     __syncthreads();
-    if (w == 0) {
-        float s = 0.f;
+    if (w == 0 && t < GROUPS) {
+        float n = 0.f, m = 0.f, M2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < GN_RED_PARTS; ++k) s += part[k][t];
-        stats[(int64_t)unit * (GROUPS * 2) + t] = s;
+        for (int k = 0; k < GN_RED_PARTS; ++k) chan_merge(n, m, M2, part[k][t][0], part[k][t][1], part[k][t][2]);
+        stats[(int64_t)unit * (GROUPS * 2) + 2 * t] = m;
+        stats[(int64_t)unit * (GROUPS * 2) + 2 * t + 1] = n > 0.f ? M2 / n : 0.f;
     }
 }
 
@@ -133,9 +164,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ stats, const float*
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int u = idx / C, c = idx - u * C;
         const int g = c / cg;
-        const float mean = stats[(u * GROUPS + g) * 2] * inv_count;
-        float var = stats[(u * GROUPS + g) * 2 + 1] * inv_count - mean * mean;
-        var = var < 0.f ? 0.f : var;
+        const float mean = stats[(u * GROUPS + g) * 2];
+        const float var = stats[(u * GROUPS + g) * 2 + 1];
         const float rstd = rsqrtf(var + eps);
         const float a = rstd * gamma[c];
         ab[((int64_t)u * 2) * C + c] = a;
@@ -178,9 +208,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c0 + e, g = c / cg;
-                const float mean = ab[((int64_t)unit * GROUPS + g) * 2] * inv_count;
-                float var = ab[((int64_t)unit * GROUPS + g) * 2 + 1] * inv_count - mean * mean;
-                var = var < 0.f ? 0.f : var;
+                const float mean = ab[((int64_t)unit * GROUPS + g) * 2];
+                const float var = ab[((int64_t)unit * GROUPS + g) * 2 + 1];
                 av[e] = rsqrtf(var + eps) * gamma[c];
                 bv[e] = beta[c] - mean * av[e];
             }
@@ -384,7 +413,8 @@ extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const v
     gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
                        (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, scratch);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits, stats);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits,
+                       rows_per_unit, rows_per_block, C / GROUPS, stats);
     return wiw_check_launch("wiw_groupnorm_stats");
 }
 
