@@ -31,7 +31,8 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 2   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment) */
+#define WIW_ABI_VERSION 3   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+                             3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance) */
 
 int wiw_abi_version(void);
 const char* wiw_last_error(void);
@@ -119,6 +120,23 @@ int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off,
  * ---------------------------------------------------------------------------------------------- */
 int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, int ldo, int batch, int T, int S,
                            int heads, float scale);
+
+/* ------------------------------------------------------------------------------------------------
+ * FUSED temporal attention block: LayerNorm -> Q/K/V projection -> softmax(Q K^T) V over the T (<= 14) frames of every
+ * spatial site, ONE kernel; the 3C-wide QKV tensor of wiw_attn_temporal_bf16 never exists.  Replaces
+ * TemporalBasicTransformerBlock.norm1 + attn1 up to (not including) its out-projection
+ * (dp/models/attention.py:735-737; to_q/to_k/to_v of dp/models/attention_processor.py:2358-2366 — no bias;
+ * nn.LayerNorm of attention.py:659-694), rows m = (b*T + t)*S + s as above.
+ *   X    : bf16 [batch*T*S][C]  the residual stream BEFORE norm1 (C = heads*64)
+ *   Wqkv : bf16 [heads*192][C]  rows of head h = [to_q rows h*64.. | to_k rows | to_v rows], each row multiplied by the
+ *          LayerNorm weight gamma (W' = W * gamma, rounded to bf16): the kernel runs its MFMAs on the raw rows of X
+ *   fold : fp32 [heads][512]    per head: s[192] = sum_k W'[n][k] (of the bf16-rounded W'), t[192] = sum_k W[n][k]*beta[k],
+ *          128 floats of padding;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd
+ *          of each row are accumulated inside the kernel from the operand fragments, eps as given)
+ *   O    : bf16 [batch*T*S][ldo], columns h*64 + d.   1 <= T <= 14; all pointers 16-byte aligned; ldo % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_temporal_attn_block_bf16(void* stream, const void* X, const void* Wqkv, const float* fold, void* O, int ldo,
+                                 int batch, int T, int S, int heads, float eps, float scale, const void* zeros);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) in NHWC, split into statistics + fused normalise/affine/SiLU.

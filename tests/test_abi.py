@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported"
     lib.wiw_abi_version.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 2
+    assert lib.wiw_abi_version() == 3
 
 
 def test_gemm_args_struct_layout():

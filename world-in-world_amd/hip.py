@@ -43,6 +43,8 @@ EXPORTS = {
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "wiw_attn_temporal_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_float]),
+    "wiw_temporal_attn_block_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "wiw_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
@@ -92,7 +94,7 @@ class Hip:
 
     def __init__(self, device: torch.device):
         self.lib = load_library()
-        if self.lib.wiw_abi_version() != 2:
+        if self.lib.wiw_abi_version() != 3:
             raise RuntimeError("libwiwsvd.so ABI version mismatch")
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -149,6 +151,13 @@ class Hip:
     def attn_temporal(self, QKV, ldqkv, O, ldo, batch, T, S, heads, scale):
         self._ck(self.lib.wiw_attn_temporal_bf16(self._stream(), _p(QKV), ldqkv, _p(O), ldo, batch, T, S, heads, scale),
                  "wiw_attn_temporal_bf16")
+        return O
+
+    def temporal_attn_block(self, X, Wqkv, fold, O, ldo, batch, T, S, heads, eps, scale):
+        """LayerNorm (folded) + per-head QKV projection + temporal attention in one kernel (temporal.hip)."""
+        self._ck(self.lib.wiw_temporal_attn_block_bf16(self._stream(), _p(X), _p(Wqkv), _p(fold), _p(O), ldo, batch, T, S,
+                                                       heads, eps, scale, self.zeros.data_ptr()),
+                 "wiw_temporal_attn_block_bf16")
         return O
 
     @staticmethod

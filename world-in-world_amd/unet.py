@@ -70,6 +70,21 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     return wp.contiguous(), bp.contiguous(), n_half
 
 
+def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
+    weight folded in (W' = bf16(W * gamma)), and per head the fold vectors s = sum_k W'[n][k] (of the ROUNDED weights,
+    so the fold is exact for what the MFMAs multiply), t = sum_k W[n][k] * beta[k]:
+        LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n."""
+    C = wq.shape[1]
+    heads = C // 64
+    wp = torch.stack([m.float().reshape(heads, 64, C) for m in (wq, wk, wv)], dim=1).reshape(heads * 192, C)
+    wg = (wp * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    fold = torch.zeros(heads, 512, dtype=torch.float32, device=wp.device)
+    fold[:, :192] = wg.float().sum(dim=1).reshape(heads, 192)
+    fold[:, 192:384] = (wp @ beta.float()).reshape(heads, 192)
+    return wg, fold.contiguous()
+
+
 @dataclass
 class RequestCond:
     """Step-invariant conditioning of one request (everything but time_embedding(t))."""
@@ -92,6 +107,7 @@ class UNetHIP:
         validate_state_dict(cfg, state_dict)
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
+        self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         self._prepare(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -173,6 +189,9 @@ class UNetHIP:
                                                        self._t(sd, t + ".attn1.to_k.weight"),
                                                        self._t(sd, t + ".attn1.to_v.weight")]).to(bf).contiguous()
             lin(t + ".attn1.to_out.0")
+            w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"] = pack_temporal_qkv(
+                self._t(sd, t + ".attn1.to_q.weight"), self._t(sd, t + ".attn1.to_k.weight"),
+                self._t(sd, t + ".attn1.to_v.weight"), self._t(sd, t + ".norm1.weight"), self._t(sd, t + ".norm1.bias"))
             for q in (b, t):  # single-key cross-attention: only to_v and to_out matter (§9.3)
                 lin(q + ".attn2.to_v", bias=False); lin(q + ".attn2.to_out.0")
             ff(b + ".ff"); ff(t + ".ff_in"); ff(t + ".ff")
@@ -375,10 +394,16 @@ class UNetHIP:
                               addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
         hm = self._geglu_ff(a, t + ".ff_in", M, Cn, res1=hm, ldr1=Cn, beta1=1.0)
-        a = hip.layernorm(hm, M, Cn, w[t + ".norm1.weight"], w[t + ".norm1.bias"], out=a)
-        qkv = self._empty(M, 3 * Cn)
-        hip.gemm(a, w[t + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
-        hip.attn_temporal(qkv, 3 * Cn, o, Cn, batch, T, S, heads, scale)
+        if T <= 14 and not self.temporal_unfused:
+            # norm1 + to_q/k/v + the 14x14 attention in ONE kernel (temporal.hip): LayerNorm folded into the projection,
+            # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor
+            hip.temporal_attn_block(hm, w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"], o, Cn, batch, T, S,
+                                    heads, 1e-5, scale)
+        else:
+            a = hip.layernorm(hm, M, Cn, w[t + ".norm1.weight"], w[t + ".norm1.bias"], out=a)
+            qkv = self._empty(M, 3 * Cn)
+            hip.gemm(a, w[t + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
+            hip.attn_temporal(qkv, 3 * Cn, o, Cn, batch, T, S, heads, scale)
         if legacy:
             hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm)
             a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
