@@ -457,6 +457,7 @@ extern "C" int wiw_temporal_attn_block_bf16(void* stream, const void* X, const v
     a.tiles_per_batch = (S + 15) / 16;
     const int64_t items = (int64_t)batch * a.tiles_per_batch * heads;
     WIW_REQUIRE(items < (1ll << 31), "temporal_attn_block: too many work items");
+    WIW_REQUIRE((int64_t)batch * T * S * heads * 64 * 2 < (1ll << 32), "temporal_attn_block: X must be < 4 GiB (32-bit source offsets)");
     a.items = (int)items;
     a.eps = eps; a.scale_log2e = scale * LOG2E; a.inv_c = 1.0f / (float)a.C;
     hipStream_t s = (hipStream_t)stream;

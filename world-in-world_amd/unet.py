@@ -394,7 +394,7 @@ class UNetHIP:
                               addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
         hm = self._geglu_ff(a, t + ".ff_in", M, Cn, res1=hm, ldr1=Cn, beta1=1.0)
-        if T <= 14 and not self.temporal_unfused:
+        if T <= 14 and not self.temporal_unfused and M * Cn * 2 < (1 << 32):
             # norm1 + to_q/k/v + the 14x14 attention in ONE kernel (temporal.hip): LayerNorm folded into the projection,
             # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor
             hip.temporal_attn_block(hm, w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"], o, Cn, batch, T, S,
