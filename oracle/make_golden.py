@@ -19,6 +19,7 @@ Fixtures written (all fp32 unless noted):
   blocks_tiny.npz          inputs/outputs of one SpatioTemporalResBlock (with shortcut) and one
                            TransformerSpatioTemporalModel captured by forward hooks
   frontend_tiny.npz        AutoencoderKLTemporalDecoder encode-mode / decode and `_resize_with_antialiasing` (tiny random VAE)
+  unet_schema.json         names + shapes of the served UNet's 1 438 state-dict tensors (reference class, meta device)
   unet_full_16x32.npz      FULL-WIDTH UNet (320/640/1280/1280, 5/10/20/20 heads, T = 14 — the served architecture) forward
                            at latent 16x32, B=1 with CFG: fp32 reference output, the reference's own bf16 run, and the
                            reference run in fp32 with bf16-ROUNDED WEIGHTS (the error floor of any bf16-weight evaluation)
@@ -209,6 +210,25 @@ def gen_unet_full(ns):
          out_ref_bf16_weights_fp32_math=out_w.numpy(), out_ref_bf16=out_bf16.float().numpy())
 
 
+def gen_schema(ns):
+    """Names and shapes of the served UNet's state dict, from the reference class on the meta device (no weights):
+    the on-disk schema of `unet/diffusion_pytorch_model[.fp16].safetensors`."""
+    import json
+
+    cfg = UNetConfig()
+    with torch.device("meta"):
+        m = ns.UNet(block_out_channels=cfg.block_out_channels, num_attention_heads=cfg.num_attention_heads,
+                    num_frames=cfg.num_frames, action_strategy="micro_cond", task_type="navigation",
+                    action_input_channel=cfg.action_input_channel)
+    sd = m.state_dict()
+    schema = {k: list(v.shape) for k, v in sd.items()}
+    path = os.path.join(OUT, "unet_schema.json")
+    with open(path, "w") as f:
+        json.dump({"n_tensors": len(schema), "n_params": int(sum(int(np.prod(v)) for v in schema.values())),
+                   "tensors": schema}, f, separators=(",", ":"))
+    print(f"wrote {path}: {len(schema)} tensors")
+
+
 def gen_pipeline(ns):
     from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
     from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
@@ -330,7 +350,7 @@ def main():
     ns = import_reference()
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
-                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full)
+                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

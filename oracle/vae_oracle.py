@@ -138,9 +138,15 @@ class TorchFrontend:
         self.nb, self.lpb = len(block_out_channels), layers_per_block
 
     @torch.no_grad()
-    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float):
+    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float, clip_images=None):
         x = torch.from_numpy(np.ascontiguousarray(images)).to(self.device, torch.float32)
-        emb = self.image_encoder(_product_frontend().clip_preprocess(x).to(self.dtype)).image_embeds[:, None].float()   # (B,1,D)
+        fe = _product_frontend()
+        if clip_images is None:
+            pix = fe.clip_preprocess(x)
+        else:   # the CLIP branch runs on the un-resized images (pipeline:192-199)
+            pix = torch.cat([fe.clip_preprocess(torch.from_numpy(np.ascontiguousarray(c))[None].to(self.device, torch.float32))
+                             for c in clip_images])
+        emb = self.image_encoder(pix.to(self.dtype)).image_embeds[:, None].float()   # (B,1,D)
         xn = x + noise_aug_strength * torch.from_numpy(np.ascontiguousarray(image_noise)).to(self.device, torch.float32)
         lat = vae_encode_mode(self.sd_enc, xn.to(self.vae_dtype), self.nb, self.lpb).float()
         return lat.cpu().numpy(), emb.cpu().numpy()

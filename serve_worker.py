@@ -3,7 +3,7 @@
 FTsvd/eval_inference.py (downstream/utils/worker_manager.py:324-334 spawns `<python> <script> <args...> <w_fd>`),
 or a standalone TCP server with --port (client protocol of downstream/solver_base.py:645-688).
 
-    python serve_worker.py --unet_path <finetuned>/unet --svd_path <stable-video-diffusion-img2vid-xt> <w_fd>
+    python serve_worker.py --unet_path <finetuned checkpoint dir (holds unet/)> --svd_path <stable-video-diffusion-img2vid-xt> <w_fd>
     python serve_worker.py --unet_path ... --svd_path ... --port 7000
     python serve_worker.py --random_weights --port 7000          # no checkpoints: random-init weights (bring-up)
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 serve_worker.py --port 7000 ...   # one request over 8 GPUs
@@ -29,12 +29,29 @@ from wiw_amd.vae import HIPFrontend, VAEHIP
 from wiw_amd.weights import load_safetensors, random_state_dict
 
 
-def _find_safetensors(folder: str) -> str:
-    for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"):
-        p = os.path.join(folder, name)
-        if os.path.isfile(p):
-            return p
-    raise FileNotFoundError(f"no diffusion_pytorch_model[.fp16].safetensors under {folder}")
+WEIGHT_FILES = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors")
+
+
+def _find_safetensors(*folders: str) -> str:
+    """First `diffusion_pytorch_model[.fp16].safetensors` found in `folders` (searched in order)."""
+    for folder in folders:
+        for name in WEIGHT_FILES:
+            p = os.path.join(folder, name)
+            if os.path.isfile(p):
+                return p
+    raise FileNotFoundError(f"no diffusion_pytorch_model[.fp16].safetensors under any of {list(folders)}")
+
+
+def resolve_unet_weights(unet_path: str, svd_path: str) -> str:
+    """Where the reference finds the UNet: `from_pretrained(unet_path, subfolder='unet')` (eval_inference.py:115-131) —
+    the manager passes `--unet_path=.../checkpoint-6000` (workers_cfg.py:26), so the file is `<unet_path>/unet/...`;
+    a path that already IS the unet folder is accepted too.  A non-empty --unet_path that does not exist is an ERROR
+    (no silent fallback to the stock model); an empty one means the stock `<svd_path>/unet`."""
+    if unet_path:
+        if not os.path.isdir(unet_path):
+            raise FileNotFoundError(f"--unet_path {unet_path!r} is not a directory")
+        return _find_safetensors(os.path.join(unet_path, "unet"), unet_path)
+    return _find_safetensors(os.path.join(svd_path, "unet"))
 
 
 def _clip(svd_path: str, random_weights: bool):
@@ -44,7 +61,13 @@ def _clip(svd_path: str, random_weights: bool):
         return CLIPVisionModelWithProjection(CLIPVisionConfig(
             hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
             patch_size=14, projection_dim=1024, hidden_act="gelu")).eval()
-    return CLIPVisionModelWithProjection.from_pretrained(svd_path, subfolder="image_encoder").eval()
+    enc = os.path.join(svd_path, "image_encoder")
+    # the reference pipeline loads with variant='fp16' and local_files_only (eval_inference.py:134-141): an fp16-only
+    # snapshot carries model.fp16.safetensors and no plain file
+    variant = "fp16" if (not os.path.isfile(os.path.join(enc, "model.safetensors")) and
+                         os.path.isfile(os.path.join(enc, "model.fp16.safetensors"))) else None
+    return CLIPVisionModelWithProjection.from_pretrained(svd_path, subfolder="image_encoder", variant=variant,
+                                                         local_files_only=True).eval()
 
 
 def arg_parser():
@@ -55,21 +78,23 @@ def arg_parser():
     return ap
 
 
-def build_worker(args) -> SVDWorker:
-    cfg = UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel)
+def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) -> SVDWorker:
+    """cfg / vae_cfg / clip: overrides for tests (reduced-width checkpoints); the served geometry by default."""
+    cfg = cfg or UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel)
+    vae_cfg = vae_cfg or {}
     if args.random_weights:
-        unet_sd, vae_sd = random_state_dict(cfg, 0), FE.vae_random_state_dict(1)
+        unet_sd, vae_sd = random_state_dict(cfg, 0), FE.vae_random_state_dict(1, **vae_cfg)
     else:
-        unet_dir = args.unet_path if os.path.isdir(args.unet_path) else os.path.join(args.svd_path, "unet")
-        unet_sd = load_safetensors(_find_safetensors(unet_dir))
+        unet_sd = load_safetensors(resolve_unet_weights(args.unet_path, args.svd_path))
         vae_sd = load_safetensors(_find_safetensors(os.path.join(args.svd_path, "vae")))
+    torch.cuda.set_device(torch.device(args.device))   # the C ABI sizes its grids from the CURRENT device
     unet = UNetHIP(cfg, unet_sd, args.device)
     den = SVDDenoiser(unet)
     dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}[args.weight_dtype]
-    clip = _clip(args.svd_path, args.random_weights)
+    clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)
     # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module.  There is no PyTorch / MIOpen VAE
     # route in the product (it needed > 6 minutes per decode on a fresh box); the fp32 PyTorch chain lives in oracle/.
-    fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip), clip, dtype=dtype)
+    fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip, **vae_cfg), clip, dtype=dtype)
 
     def denoise(image_latents, image_embeddings, noise, actions, **kw) -> np.ndarray:
         return den.denoise(torch.from_numpy(image_latents), torch.from_numpy(image_embeddings),

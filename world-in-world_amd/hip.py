@@ -108,10 +108,23 @@ class Hip:
         # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
+        # ... and this one for the non-GEMM kernels: (start_event, end_event, family, algorithmic_flops, algorithmic_bytes)
+        self.kernel_profile = None
 
     # ---- helpers
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _timed(self, family: str, flops: float, nbytes: float, fn):
+        """Run `fn` (one or more launches of one kernel family) between two HIP events when bench.py profiles."""
+        if self.kernel_profile is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.kernel_profile.append((e0, e1, family, float(flops), float(nbytes)))
+        return r
 
     def _ck(self, rc: int, what: str):
         if rc != 0:
@@ -144,20 +157,28 @@ class Hip:
         return out
 
     def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale):
-        self._ck(self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
-                                                frames, S, heads, scale, self.zeros.data_ptr()), "wiw_attn_spatial_bf16")
+        # algorithmic work: Q.K^T and P.V, 2*S*S*64 each per (frame, head); bytes: Q, K, V read + O written (bf16)
+        self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
+            self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
+                                           frames, S, heads, scale, self.zeros.data_ptr()), "wiw_attn_spatial_bf16"))
         return O
 
     def attn_temporal(self, QKV, ldqkv, O, ldo, batch, T, S, heads, scale):
-        self._ck(self.lib.wiw_attn_temporal_bf16(self._stream(), _p(QKV), ldqkv, _p(O), ldo, batch, T, S, heads, scale),
-                 "wiw_attn_temporal_bf16")
+        self._timed("attn_temporal", 4.0 * batch * S * heads * T * T * 64, 8.0 * batch * T * S * heads * 64, lambda: self._ck(
+            self.lib.wiw_attn_temporal_bf16(self._stream(), _p(QKV), ldqkv, _p(O), ldo, batch, T, S, heads, scale),
+            "wiw_attn_temporal_bf16"))
         return O
 
     def temporal_attn_block(self, X, Wqkv, fold, O, ldo, batch, T, S, heads, eps, scale):
         """LayerNorm (folded) + per-head QKV projection + temporal attention in one kernel (temporal.hip)."""
-        self._ck(self.lib.wiw_temporal_attn_block_bf16(self._stream(), _p(X), _p(Wqkv), _p(fold), _p(O), ldo, batch, T, S,
-                                                       heads, eps, scale, self.zeros.data_ptr()),
-                 "wiw_temporal_attn_block_bf16")
+        Cn, M = heads * 64, batch * T * S
+        # algorithmic work: the Q/K/V projection (2*M*3C*C) + the attention core at the real T; bytes: X read once,
+        # O written, weights once (bf16)
+        self._timed("temporal_block", 2.0 * M * 3 * Cn * Cn + 4.0 * batch * S * heads * T * T * 64,
+                    2.0 * (2 * M * Cn + 3 * Cn * Cn), lambda: self._ck(
+            self.lib.wiw_temporal_attn_block_bf16(self._stream(), _p(X), _p(Wqkv), _p(fold), _p(O), ldo, batch, T, S,
+                                                  heads, eps, scale, self.zeros.data_ptr()),
+            "wiw_temporal_attn_block_bf16"))
         return O
 
     @staticmethod
@@ -190,11 +211,16 @@ class Hip:
         if out is None:
             out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
         s = self._stream()
-        self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
-                                              scratch.data_ptr()), "wiw_groupnorm_stats")
-        self._ck(self.lib.wiw_groupnorm_apply_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
-                                                    _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr()),
-                 "wiw_groupnorm_apply_stats")
+
+        def launch():
+            self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
+                                                  scratch.data_ptr()), "wiw_groupnorm_stats")
+            self._ck(self.lib.wiw_groupnorm_apply_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
+                                                        _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr()),
+                     "wiw_groupnorm_apply_stats")
+
+        # algorithmic bytes: the input is read twice (statistics, apply) and the output written once (bf16)
+        self._timed("groupnorm", 0.0, 6.0 * rows * Ct, launch)
         return out
 
     def groupnorm_unfused(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False):
@@ -219,8 +245,9 @@ class Hip:
                   out=None):
         if out is None:
             out = torch.empty((rows, Cn), dtype=torch.bfloat16, device=self.device)
-        self._ck(self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
-                                             addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16")
+        self._timed("layernorm", 0.0, (6.0 if sum_out is not None else 4.0) * rows * Cn, lambda: self._ck(
+            self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
+                                        addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16"))
         return out
 
     def emb_combine(self, time, act, noise, Bc, B, T, E, out):

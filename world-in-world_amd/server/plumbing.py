@@ -78,6 +78,13 @@ def preprocess_image(img: Image.Image, width: int, height: int) -> np.ndarray:
     return np.transpose(2.0 * x - 1.0, (2, 0, 1))
 
 
+def image_to_array(img: Image.Image) -> np.ndarray:
+    """pil_to_numpy + numpy_to_pt + `* 2 - 1` of `_encode_image` (pipeline:192-199): float32 (3, H0, W0) in [-1,1] at the
+    image's OWN size (no resize)."""
+    x = np.asarray(img.convert("RGB"), dtype=np.float32) / 255.0
+    return np.transpose(2.0 * x - 1.0, (2, 0, 1))
+
+
 def frames_to_pil(frames: np.ndarray) -> List[Image.Image]:
     """decoded frames (T,3,H,W) in [-1,1] -> PIL list: denormalise, clamp, (x*255).round() (image_processor.py:147)."""
     x = np.clip(frames / 2.0 + 0.5, 0.0, 1.0)

@@ -7,9 +7,9 @@ persistent seeded generator semantics (one generator for the worker's lifetime, 
 image-noise then latent-noise).
 
 The denoising loop runs on the HIP kernels (`SVDDenoiser`).  Image conditioning (CLIP embed + VAE
-encode) and latent decoding (temporal VAE) are PyTorch modules supplied through `frontend`
-(north_star: "PyTorch-ROCm only for tensor plumbing and the VAE encode/decode"); they are the
-"next" rows of SURVEY.md §8(f) and are injected so that the worker is testable without checkpoints.
+encode) and latent decoding (temporal VAE) come through `frontend` — in the product `vae.HIPFrontend`,
+whose VAE encode / temporal decode run on the same HIP kernels; it is injected so that the worker is
+testable without checkpoints (and with the fp32 PyTorch checker of oracle/vae_oracle.py).
 
 Two transports:
   * `serve_tcp`   — speaks the client protocol directly (what `Solver.send_batch_to_server` expects,
@@ -36,8 +36,11 @@ from .protocol import DONE, read_framed, read_pickled, write_framed, write_pickl
 class Frontend(Protocol):
     """PyTorch side of the worker (CLIP + VAE)."""
 
-    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float):
-        """images (B,3,H,W) in [-1,1]; returns (image_latents (B,4,h,w), image_embeddings (B,1,D)) float32."""
+    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float, clip_images=None):
+        """images (B,3,H,W) in [-1,1] (LANCZOS-resized to the model size: the VAE branch, pipeline:521);
+        clip_images: optional list of B arrays (3,H0,W0) in [-1,1] at the ORIGINAL size — what the reference's
+        `_encode_image` sees (pipeline:192-199 runs on the un-resized PIL image); None = same as `images`.
+        Returns (image_latents (B,4,h,w), image_embeddings (B,1,D)) float32."""
 
     def decode(self, latents: np.ndarray) -> np.ndarray:
         """latents (B,T,4,h,w) -> frames (B,T,3,H,W) in [-1,1] float32 (decode_latents, pipeline:282-309)."""
@@ -66,8 +69,15 @@ class SVDWorker:
             raise AssertionError(f"navigation b_action must be (b, {self.num_frames}), got {b_action.shape}")
         B = len(images)
         x = np.stack([P.preprocess_image(im, self.width, self.height) for im in images])
+        # CLIP sees the image at its ORIGINAL size (pipeline:192-199); only the VAE branch is resized (pipeline:521)
+        clip_images = None
+        if any(im.size != (self.width, self.height) for im in images):
+            clip_images = [P.image_to_array(im) for im in images]
         img_noise = self.noise_fn(x.shape)                                   # draw 1 (pipeline:522)
-        image_latents, image_embeddings = self.frontend.encode(x, img_noise, 0.02)
+        if clip_images is None:
+            image_latents, image_embeddings = self.frontend.encode(x, img_noise, 0.02)
+        else:
+            image_latents, image_embeddings = self.frontend.encode(x, img_noise, 0.02, clip_images=clip_images)
         h, w = image_latents.shape[-2:]
         lat_noise = self.noise_fn((B, self.num_frames, 4, h, w))             # draw 2 (pipeline:765)
         latents = self.denoise_fn(image_latents, image_embeddings, lat_noise, b_action,

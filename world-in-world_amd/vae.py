@@ -296,9 +296,14 @@ class HIPFrontend:
         self.image_encoder = image_encoder.to(self.device, dtype).eval() if image_encoder is not None else None
 
     @torch.no_grad()
-    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float):
+    def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float, clip_images=None):
         x = torch.from_numpy(np.ascontiguousarray(images)).to(self.device, torch.float32)
-        emb = self.image_encoder(self._clip_preprocess(x).to(self.dtype)).image_embeds[:, None].float()
+        if clip_images is None:
+            pix = self._clip_preprocess(x)
+        else:   # CLIP branch on the un-resized images (pipeline:192-199); sizes may differ between candidates
+            pix = torch.cat([self._clip_preprocess(torch.from_numpy(np.ascontiguousarray(c))[None].to(self.device, torch.float32))
+                             for c in clip_images])
+        emb = self.image_encoder(pix.to(self.dtype)).image_embeds[:, None].float()
         xn = x + noise_aug_strength * torch.from_numpy(np.ascontiguousarray(image_noise)).to(self.device, torch.float32)
         lat = self.vae.encode_mode(xn)
         return lat.cpu().numpy(), emb.cpu().numpy()
