@@ -119,7 +119,8 @@ def main(argv=None) -> None:
         args.device = f"cuda:{local_rank}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(args.device))
-        sharded = ShardedWorker(build_worker(args))
+        from wiw_amd.server import plumbing as P
+        sharded = ShardedWorker(build_worker(args), validate=lambda r: P.validate_request(r, args.num_frames))
         if dist.get_rank() == 0:
             if args.port <= 0:
                 ap.error("multi-GPU serving needs --port (rank 0 runs the TCP server)")

@@ -106,6 +106,70 @@ def _run_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _poisoned_worker(req):
+    if any("poison" in d for d in req["save_dirs"]):
+        raise ValueError("bad candidate")
+    return fake_worker(req)
+
+
+def _run_worker_errors(rank, world, port, q):
+    """A slice that raises must not desynchronise the group: rank 0 gets ShardedWorkerError, the NEXT request works."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wiw_amd.parallel import ShardedWorker, ShardedWorkerError
+    from wiw_amd.server import plumbing as P
+    try:
+        sw = ShardedWorker(_poisoned_worker, validate=lambda r: P.validate_request(r, 14))
+        if rank == 0:
+            rs = np.random.RandomState(0)
+
+            def mk(B, poison=None):
+                dirs = [f"/tmp/c{i}" for i in range(B)]
+                if poison is not None:
+                    dirs[poison] = "/tmp/poison"
+                return {"b_action": rs.randint(0, 5, size=(B, 14)), "save_dirs": dirs, "request_model_name": "igen",
+                        "b_image": rs.randint(0, 256, size=(B, 3, 8, 16), dtype=np.uint8), "return_objects": [True] * B}
+
+            res = []
+            for poison in (3, 0):            # the failing candidate lands on rank 1, then on rank 0
+                try:
+                    sw(mk(4, poison))
+                    res.append("no error")
+                except ShardedWorkerError as e:
+                    res.append("bad candidate" in str(e))
+            # malformed request: rejected on rank 0 before any collective (b_action with 13 columns)
+            bad = mk(2)
+            bad["b_action"] = bad["b_action"][:, :13]
+            try:
+                sw(bad)
+                res.append("no error")
+            except AssertionError:
+                res.append(True)
+            good = mk(3)
+            out, ref = sw(good), fake_worker(good)
+            res.append(out["save_dirs"] == ref["save_dirs"] and np.array_equal(out["pred_frames"], ref["pred_frames"]))
+            sw.close()
+            q.put(res)
+        else:
+            sw.follow()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_worker_survives_a_failing_slice():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_worker_errors, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120) == [True, True, True, True]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+
 def test_sharded_worker_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

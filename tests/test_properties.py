@@ -76,9 +76,15 @@ def test_sharded_worker_concat_is_order_preserving(b, parts, seed):
     rs = np.random.RandomState(seed)
     frames = rs.randint(0, 255, size=(b, 2, 3), dtype=np.uint8)
     dirs = [f"c{i}" for i in range(b)]
-    pieces = [{"save_dirs": dirs[lo:hi], "pred_frames": frames[lo:hi]} for lo, hi in shard_bounds(b, parts) if hi > lo]
-    out = ShardedWorker._concat(pieces)
-    assert out["save_dirs"] == dirs and np.array_equal(out["pred_frames"], frames)
+    import torch
+
+    from wiw_amd.parallel import pad_slices, unpad_concat
+    bounds = shard_bounds(b, parts)
+    width = max(hi - lo for lo, hi in bounds)
+    padded = pad_slices(torch.from_numpy(frames), bounds, width)      # what scatter sends / gather receives
+    assert len(padded) == parts and all(p.shape == (width, 2, 3) for p in padded)
+    assert np.array_equal(unpad_concat(padded, bounds).numpy(), frames)
+    assert [d for lo, hi in bounds for d in dirs[lo:hi]] == dirs
     sl = ShardedWorker._slice({"request_model_name": "igen", "save_dirs": dirs, "b_image": frames}, 0, 1)
     assert sl["request_model_name"] == "igen" and sl["save_dirs"] == dirs[:1] and sl["b_image"].shape[0] == 1
 

@@ -2,15 +2,20 @@
 
 The reference scales by running N independent worker processes behind a manager that splits every
 request into batch-1 tasks over pipes (downstream/utils/worker_manager.py:448-469, 555-570).  Here the
-candidates of ONE request are sharded across ranks: rank 0 owns the request, broadcasts the (small)
-conditioning tensors, every rank denoises its contiguous slice with a full weight replica, and the
-latents are gathered back on rank 0.  There is no exchange inside the loop (candidates are
-independent); the two collectives move ~1 MB per candidate.
+candidates of ONE request are sharded across ranks: rank 0 owns the request, SCATTERS each rank's slice of the
+(small) conditioning tensors, every rank denoises its contiguous slice with a full weight replica, and the
+results are GATHERED on rank 0.  There is no exchange inside the loop (candidates are independent,
+SURVEY.md §8e); the two collectives move ~1 MB per candidate (latents) or 9.7 MB per candidate (uint8 frames).
+
+xGMI is point-to-point (7 links per GPU): scatter / gather from rank 0 use rank 0's 7 links in parallel, one slice
+per link — nothing is relayed through a ring, and no rank receives bytes it does not need (a whole-request
+broadcast would push N times the data over the same links).
 
 `backend="nccl"` is RCCL on ROCm; tests run the same code with `gloo` on CPU tensors.
 """
 from __future__ import annotations
 
+import traceback
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
@@ -29,13 +34,44 @@ def shard_bounds(n_items: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def _bcast(t: Optional[torch.Tensor], shape, dtype, device, src=0) -> torch.Tensor:
-    if t is None:
-        t = torch.empty(shape, dtype=dtype, device=device)
-    else:
-        t = t.to(device=device, dtype=dtype).contiguous()
-    dist.broadcast(t, src=src)
-    return t
+def pad_slices(t: torch.Tensor, bounds, width: int) -> List[torch.Tensor]:
+    """Rows [lo, hi) of `t` for every rank, each zero-padded to `width` rows (collectives need equal shapes)."""
+    parts = []
+    for lo, hi in bounds:
+        p = torch.zeros((width, *t.shape[1:]), dtype=t.dtype, device=t.device)
+        p[: hi - lo] = t[lo:hi]
+        parts.append(p)
+    return parts
+
+
+def unpad_concat(parts: List[torch.Tensor], bounds) -> torch.Tensor:
+    """Inverse of `pad_slices`: candidate order is rank order."""
+    return torch.cat([parts[k][: b - a] for k, (a, b) in enumerate(bounds)])
+
+
+def _scatter_slices(t: Optional[torch.Tensor], item_shape, dtype, device, bounds, width: int) -> torch.Tensor:
+    """Rank 0 holds `t` (B, *item_shape); every rank receives its rows [lo, hi) in a (width, *item_shape) buffer
+    (zero-padded: scatter needs equal shapes)."""
+    rank = dist.get_rank()
+    mine = torch.empty((width, *item_shape), dtype=dtype, device=device)
+    parts = None
+    if rank == 0:
+        parts = pad_slices(t.to(device=device, dtype=dtype), bounds, width)
+    dist.scatter(mine, parts, src=0)
+    return mine
+
+
+def _gather_slices(mine: torch.Tensor, bounds, width: int) -> Optional[torch.Tensor]:
+    """Inverse of `_scatter_slices`: rank r contributes rows [lo_r, hi_r); rank 0 returns their concatenation."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = bounds[rank]
+    pad = torch.zeros((width, *mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    pad[: hi - lo] = mine
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, parts, dst=0)
+    if rank != 0:
+        return None
+    return unpad_concat(parts, bounds)
 
 
 def sharded_denoise(denoise_fn: Callable[..., torch.Tensor], device: torch.device, image_latents: Optional[torch.Tensor],
@@ -51,38 +87,43 @@ def sharded_denoise(denoise_fn: Callable[..., torch.Tensor], device: torch.devic
         meta[:6] = torch.tensor([B, T, h, w, image_embeddings.shape[-1], image_embeddings.shape[-2]])
     dist.broadcast(meta, src=0)
     B, T, h, w, D, L = (int(v) for v in meta[:6].tolist())
-    il = _bcast(image_latents, (B, 4, h, w), torch.float32, device)
-    ie = _bcast(image_embeddings, (B, L, D), torch.float32, device)
-    nz = _bcast(noise, (B, T, 4, h, w), torch.float32, device)
-    ac = _bcast(None if actions is None else torch.as_tensor(np.asarray(actions), dtype=torch.int64), (B, T),
-                torch.int64, device)
     bounds = shard_bounds(B, world)
+    width = max(b - a for a, b in bounds)
     lo, hi = bounds[rank]
-    if hi > lo:
-        mine = denoise_fn(il[lo:hi], ie[lo:hi], nz[lo:hi], ac[lo:hi].cpu().numpy(), **kw).to(torch.float32).contiguous()
+    n = hi - lo
+    il = _scatter_slices(image_latents, (4, h, w), torch.float32, device, bounds, width)[:n]
+    ie = _scatter_slices(image_embeddings, (L, D), torch.float32, device, bounds, width)[:n]
+    nz = _scatter_slices(noise, (T, 4, h, w), torch.float32, device, bounds, width)[:n]
+    ac = _scatter_slices(None if actions is None else torch.as_tensor(np.asarray(actions), dtype=torch.int64), (T,),
+                         torch.int64, device, bounds, width)[:n]
+    if n > 0:
+        mine = denoise_fn(il, ie, nz, ac.cpu().numpy(), **kw).to(torch.float32).contiguous()
     else:
         mine = torch.empty((0, T, 4, h, w), dtype=torch.float32, device=device)
-    # ragged gather as a padded all_gather (available on both RCCL and gloo)
-    width = max(b - a for a, b in bounds)
-    pad = torch.zeros((width, T, 4, h, w), dtype=torch.float32, device=device)
-    pad[: hi - lo] = mine
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
-    if rank != 0:
-        return None
-    return torch.cat([parts[k][: b - a] for k, (a, b) in enumerate(bounds)])
+    return _gather_slices(mine, bounds, width)
 
 
 # ------------------------------------------------------------------------------------------------
 # Serving: one request sharded over the ranks, every stage (encode, denoise, decode, PIL post-processing) local
 # ------------------------------------------------------------------------------------------------
+class ShardedWorkerError(RuntimeError):
+    """A rank failed on its slice of a request; the process group stayed in step (every rank reached the gather)."""
+
+
 class ShardedWorker:
     """Rank 0 owns the client connection; a request's candidates are sliced over the ranks exactly as the reference
     manager slices them over worker processes (every value `v[lo:hi]`, worker_manager.py:448-469), each rank runs the
     WHOLE worker on its slice — VAE encode, denoise, VAE decode and the CPU-side PIL post-processing all scale with
-    the rank count ("decode-sharded") — and the per-rank response dicts come back to rank 0, where
-    they are concatenated in candidate order.  The two object collectives move the request (1.8 MB / candidate) and
-    the uint8 frames (9.7 MB / candidate); nothing is exchanged inside the loop.
+    the rank count ("decode-sharded") — and the responses come back to rank 0 in candidate order.
+
+    Data movement per request: each rank receives ONLY its slice (`scatter_object_list`: 1.8 MB / candidate of uint8
+    panorama); the uint8 frames come back as ONE padded tensor gather (9.7 MB / candidate, no pickling of the bulk
+    data; on RCCL the gather runs device to device over xGMI); the small rest (save_dirs, status) is a gathered object.
+
+    Failure containment (the reference lets a failing worker process die and the client hang, worker_manager.py:369-379):
+    rank 0 validates the request BEFORE any collective; every rank catches exceptions of its slice and still takes
+    part in both gathers, so one malformed request cannot desynchronise or kill the group — rank 0 raises
+    `ShardedWorkerError` for that request and serves the next one.
 
         rank 0:   ShardedWorker(worker)(request) -> response            (e.g. behind server.worker.serve_tcp)
         rank > 0: ShardedWorker(worker).follow()                        (returns when rank 0 calls close())
@@ -90,9 +131,15 @@ class ShardedWorker:
 
     _STOP = "__wiw_stop__"
 
-    def __init__(self, worker: Callable[[dict], dict]):
+    def __init__(self, worker: Callable[[dict], dict], device: Optional[torch.device] = None,
+                 validate: Optional[Callable[[dict], None]] = None):
         self.worker = worker
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        # tensors of a collective live where the backend wants them: the GPU for RCCL, the host for gloo
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        self.device = device
+        self.validate = validate
 
     @staticmethod
     def _slice(req: dict, lo: int, hi: int) -> dict:
@@ -100,34 +147,70 @@ class ShardedWorker:
         # worker only survives because the name check is dead code there
         return {k: (v if isinstance(v, str) else v[lo:hi]) for k, v in req.items()}
 
-    @staticmethod
-    def _concat(parts: List[dict]) -> dict:
-        out: dict = {}
-        for part in parts:
-            for k, v in part.items():
-                out.setdefault(k, []).append(v)
-        res = {}
-        for k, vs in out.items():
-            res[k] = np.concatenate(vs) if isinstance(vs[0], np.ndarray) else [x for v in vs for x in v]
-        return res
-
     def _step(self, request) -> Optional[dict]:
-        box = [request]
-        dist.broadcast_object_list(box, src=0)
-        req = box[0]
-        if isinstance(req, str) and req == self._STOP:
+        # ---- scatter: rank k receives (n_candidates, its slice of the request) — or the stop token
+        if self.rank == 0:
+            if isinstance(request, str):
+                objs = [request] * self.world
+            else:
+                n = len(next(v for v in request.values() if not isinstance(v, str)))
+                bounds = shard_bounds(n, self.world)
+                objs = [(n, self._slice(request, lo, hi)) for lo, hi in bounds]
+        else:
+            objs = None
+        box = [None]
+        dist.scatter_object_list(box, objs, src=0)
+        if isinstance(box[0], str) and box[0] == self._STOP:
             return None
-        n = len(next(v for v in req.values() if not isinstance(v, str)))
-        lo, hi = shard_bounds(n, self.world)[self.rank]
-        mine = self.worker(self._slice(req, lo, hi)) if hi > lo else {}
+        n, sub = box[0]
+        bounds = shard_bounds(n, self.world)
+        lo, hi = bounds[self.rank]
+        width = max(b - a for a, b in bounds)
+        # ---- run the slice; an exception becomes a status object, never a missed collective
+        mine, err = {}, None
+        if hi > lo:
+            try:
+                mine = self.worker(sub)
+            except BaseException as e:  # noqa: BLE001 — the group must stay in step whatever the slice raised
+                err = f"rank {self.rank}, candidates [{lo}, {hi}): {type(e).__name__}: {e}\n{traceback.format_exc(limit=6)}"
+                mine = {}
+        frames = mine.get("pred_frames") if isinstance(mine, dict) else None
+        small = {k: v for k, v in mine.items() if k != "pred_frames"} if isinstance(mine, dict) else {}
+        status = dict(err=err, small=small, frame_shape=None if frames is None else tuple(np.asarray(frames).shape[1:]))
         gathered = [None] * self.world if self.rank == 0 else None
-        dist.gather_object(mine, gathered, dst=0)
+        dist.gather_object(status, gathered, dst=0)
+        # ---- every rank learns whether (and in which per-candidate shape) frames travel: one small broadcast
+        plan = [None]
+        if self.rank == 0:
+            shapes = {g["frame_shape"] for g in gathered if g["frame_shape"] is not None}
+            ok = all(g["err"] is None for g in gathered) and len(shapes) == 1 and \
+                all(g["frame_shape"] is not None for g, (a, b) in zip(gathered, bounds) if b > a)
+            plan = [shapes.pop() if ok else None]
+        dist.broadcast_object_list(plan, src=0)
+        out_frames = None
+        if plan[0] is not None:
+            t = torch.zeros((hi - lo, *plan[0]), dtype=torch.uint8, device=self.device)
+            if hi > lo:
+                t.copy_(torch.as_tensor(np.ascontiguousarray(frames)))
+            out_frames = _gather_slices(t, bounds, width)
         if self.rank != 0:
             return {}
-        return self._concat([g for g in gathered if g])
+        errs = [g["err"] for g in gathered if g["err"]]
+        if errs:
+            raise ShardedWorkerError("request failed on %d rank(s):\n%s" % (len(errs), "\n".join(errs)))
+        res: dict = {}
+        for g, (a, b) in zip(gathered, bounds):
+            if b > a:
+                for k, v in g["small"].items():
+                    res.setdefault(k, []).extend(v)
+        if out_frames is not None:
+            res["pred_frames"] = out_frames.cpu().numpy()
+        return res
 
     def __call__(self, request: dict) -> dict:
         assert self.rank == 0, "only rank 0 takes client requests"
+        if self.validate is not None:
+            self.validate(request)      # raises BEFORE any collective: followers never see a malformed request
         return self._step(request)
 
     def follow(self) -> None:
@@ -137,4 +220,4 @@ class ShardedWorker:
 
     def close(self) -> None:
         if self.rank == 0:
-            dist.broadcast_object_list([self._STOP], src=0)
+            self._step(self._STOP)

@@ -40,6 +40,27 @@ def check_inputdict(d: dict) -> None:
             assert isinstance(v, list) and all(isinstance(s, bool) for s in v), "return_objects should be list[bool]"
 
 
+def validate_request(d: dict, num_frames: int) -> None:
+    """Everything the worker would trip over, checked BEFORE compute is committed (a multi-GPU server must not hand a
+    malformed request to its ranks): the reference's `check_inputdict` plus the shape facts its worker assumes
+    (b_action (b, num_frames) for navigation, eval_inference.py:313-349; one save_dir / image per candidate;
+    b_image uint8 (b, C>=3, H, W); `<save_dir>/cond_rgb.png` present when no b_image travels)."""
+    check_inputdict(d)
+    b_action = np.asarray(d["b_action"])
+    assert b_action.ndim == 2 and b_action.shape[1] == num_frames, \
+        f"navigation b_action must be (b, {num_frames}), got {b_action.shape}"
+    b = b_action.shape[0]
+    assert b > 0 and len(d["save_dirs"]) == b, "one save_dir per candidate"
+    if "return_objects" in d:
+        assert len(d["return_objects"]) == b, "one return_objects flag per candidate"
+    img = d.get("b_image")
+    if img is not None:
+        assert img.ndim == 4 and img.shape[0] == b and img.shape[1] >= 3, f"b_image should be uint8 (b, 3, H, W), got {img.shape}"
+    else:
+        missing = [s for s in d["save_dirs"] if not os.path.isfile(os.path.join(s, "cond_rgb.png"))]
+        assert not missing, f"no b_image and no cond_rgb.png under {missing[:3]}"
+
+
 def check_outputdict(d: dict) -> None:
     pf = d.get("pred_frames")
     assert pf is None or (isinstance(pf, np.ndarray) and pf.dtype == np.uint8)
