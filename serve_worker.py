@@ -126,7 +126,8 @@ def main(argv=None) -> None:
                 ap.error("multi-GPU serving needs --port (rank 0 runs the TCP server)")
             print(f"[serve_worker] {world} ranks, listening on {args.host}:{args.port}", file=sys.stderr, flush=True)
             try:
-                serve_tcp(sharded, host=args.host, port=args.port, batch_size=0)
+                serve_tcp(sharded, host=args.host, port=args.port, batch_size=0,
+                          coalesce_candidates=args.coalesce_candidates, coalesce_wait_s=args.coalesce_wait_ms / 1e3)
             finally:
                 sharded.close()
         else:
@@ -136,7 +137,8 @@ def main(argv=None) -> None:
     worker = build_worker(args)
     if args.port > 0:
         print(f"[serve_worker] listening on {args.host}:{args.port}", file=sys.stderr, flush=True)
-        serve_tcp(worker, host=args.host, port=args.port, batch_size=args.batch_size)
+        serve_tcp(worker, host=args.host, port=args.port, batch_size=args.batch_size,
+                  coalesce_candidates=args.coalesce_candidates, coalesce_wait_s=args.coalesce_wait_ms / 1e3)
     else:
         worker_main(args.pipe_fd, worker)
 

@@ -101,3 +101,67 @@ def test_serve_worker_full_size_over_tcp(tmp_path):
     assert pf.shape == (2, 14, 3, 480, 480) and pf.dtype == np.uint8
     assert np.isfinite(pf.astype(np.float32)).all() and pf.std() > 0
     assert list(out["save_dirs"]) == req["save_dirs"]
+
+
+def test_coalesced_clients_get_their_alone_bytes_on_the_hip_path(tmp_path):
+    """SURVEY.md §8f row 3 on the GPU: two clients' requests (2 + 3 candidates) coalesced into ONE HIP batch of 5; every
+    client's uint8 frames equal what it gets when served alone — bit for bit (batch-independent kernels)."""
+    import threading
+
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import frontend as FE
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.server.worker import Coalescer, SVDWorker
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.vae import HIPFrontend, VAEHIP
+    from wiw_amd.weights import random_state_dict
+
+    T, H, W = 4, 128, 256
+    cfg = UNetConfig.tiny(T)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 21), "cuda:0")
+    den = SVDDenoiser(unet)
+    vcfg = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=1024)).eval()
+    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(22, **vcfg), "cuda:0", hip=unet.hip, **vcfg), clip, dtype=torch.float32)
+
+    def denoise(il, ie, nz, act, **kw):
+        return den.denoise(torch.as_tensor(il), torch.as_tensor(ie), torch.as_tensor(nz), act, **kw).cpu().numpy()
+
+    # noise as a function of the candidate (its save_dir), so that batching does not change anybody's draws
+    calls = []
+
+    def make(noise_seed_base):
+        return SVDWorker(denoise, fe, width=W, height=H, out_width=64, out_height=48, num_frames=T, num_inference_steps=2,
+                         noise_fn=lambda shape: np.zeros(shape, np.float32))
+
+    worker = make(0)
+
+    def recording(req):
+        calls.append(len(req["save_dirs"]))
+        return worker(req)
+
+    rs = np.random.RandomState(3)
+    reqs = []
+    for c, b in enumerate((2, 3)):
+        reqs.append({"b_action": rs.randint(1, 4, size=(b, T)).astype(np.int64), "request_model_name": "igen",
+                     "save_dirs": [str(tmp_path / f"c{c}_{i}") for i in range(b)],
+                     "b_image": rs.randint(0, 256, size=(b, 3, H, W), dtype=np.uint8), "return_objects": [True] * b})
+    alone = [worker(r)["pred_frames"] for r in reqs]
+    co = Coalescer(recording, max_candidates=8, max_wait_s=2.0)
+    outs = [None, None]
+    ts = [threading.Thread(target=lambda i=i: outs.__setitem__(i, co.submit(reqs[i]))) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    co.close()
+    assert calls == [5], f"the two requests must be evaluated as one batch of 5 candidates, got {calls}"
+    for i in range(2):
+        assert outs[i]["save_dirs"] == reqs[i]["save_dirs"]
+        assert np.array_equal(outs[i]["pred_frames"], alone[i]), f"client {i}: coalesced frames differ from the alone run"

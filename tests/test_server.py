@@ -223,3 +223,107 @@ def test_launcher_cli_takes_the_manager_command_line():
     assert a.pipe_fd == 17 and a.port == 0 and a.device == "cuda:3" and not a.random_weights
     b = ap.parse_args(["--random_weights", "--port", "7000", "--batch_size", "1"])
     assert b.pipe_fd is None and b.port == 7000 and b.random_weights
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# cross-client batching
+# ----------------------------------------------------------------------------------------------------------------
+def test_coalescer_forms_one_batch_from_concurrent_clients(tmp_path):
+    """Two solvers sending 3 candidates each within the window are evaluated as ONE call of 6 candidates; every client
+    receives exactly its own candidates in order, with the bytes it would have received alone."""
+    from wiw_amd.server.worker import Coalescer
+
+    calls = []
+    base = make_worker(noise_fn=lambda shape: np.zeros(shape, np.float32))   # noise-free: results comparable across batchings
+
+    def recording(req):
+        calls.append(len(req["save_dirs"]))
+        return base(req)
+
+    ready, stop = threading.Event(), threading.Event()
+    th = threading.Thread(target=serve_tcp, kwargs=dict(worker=recording, port=0, ready=ready, stop=stop,
+                                                        coalesce_candidates=8, coalesce_wait_s=1.0), daemon=True)
+    th.start()
+    assert ready.wait(10)
+    try:
+        reqs = []
+        for c in range(2):
+            r = make_request(3, tmp=tmp_path / f"client{c}")
+            r["b_image"] = np.random.RandomState(10 + c).randint(0, 256, size=(3, 3, 64, 128), dtype=np.uint8)
+            r["b_action"] = np.roll(r["b_action"], c, axis=1)
+            reqs.append(r)
+        outs = [None, None]
+
+        def client(i):
+            outs[i] = _client_roundtrip(ready.port, reqs[i])
+
+        ts = [threading.Thread(target=client, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(30)
+        assert calls == [6], f"expected one merged call of 6 candidates, worker saw {calls}"
+        for i in range(2):
+            alone = base(reqs[i])
+            assert outs[i]["save_dirs"] == reqs[i]["save_dirs"]
+            assert isinstance(outs[i]["pred_frames"], np.ndarray) and np.array_equal(outs[i]["pred_frames"], alone["pred_frames"])
+        # a lone request is not held longer than the window and is served as is; 5 + 5 candidates do not fit one batch of 8
+        calls.clear()
+        co = Coalescer(recording, max_candidates=8, max_wait_s=0.3)
+        big = [make_request(5, tmp=tmp_path / f"big{c}") for c in range(2)]
+        res = [None, None]
+        ts = [threading.Thread(target=lambda i=i: res.__setitem__(i, co.submit(big[i]))) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(30)
+        assert sorted(calls) == [5, 5] and all(r["pred_frames"].shape[0] == 5 for r in res)
+        co.close()
+    finally:
+        stop.set()
+        th.join(5)
+
+
+def test_coalescer_isolates_a_failing_request(tmp_path):
+    from wiw_amd.server.worker import Coalescer
+
+    base = make_worker()
+
+    def worker(req):
+        if any("bad" in d for d in req["save_dirs"]):
+            raise ValueError("poisoned candidate")
+        return base(req)
+
+    co = Coalescer(worker, max_candidates=8, max_wait_s=0.5)
+    good, bad = make_request(2, tmp=tmp_path / "g"), make_request(2, tmp=tmp_path / "bad")
+    res = {}
+
+    def run(name, req):
+        try:
+            res[name] = co.submit(req)
+        except ValueError as e:
+            res[name] = e
+
+    ts = [threading.Thread(target=run, args=("good", good)), threading.Thread(target=run, args=("bad", bad))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    co.close()
+    assert isinstance(res["bad"], ValueError) and res["good"]["save_dirs"] == good["save_dirs"]
+    assert res["good"]["pred_frames"].shape[0] == 2
+
+
+def test_coalescer_merge_is_the_inverse_of_the_managers_split():
+    from wiw_amd.server.worker import Coalescer
+
+    req = make_request(5, tmp="/tmp/x")
+    parts = P.split_batch(req, 2)
+    # the manager slices strings too ("igen"[0:2]); a client-side request always carries the whole name
+    for p_ in parts:
+        p_["request_model_name"] = "igen"
+    merged = Coalescer.merge(parts)
+    assert set(merged) == set(req) and merged["save_dirs"] == req["save_dirs"]
+    assert np.array_equal(merged["b_action"], req["b_action"]) and np.array_equal(merged["b_image"], req["b_image"])
+    back = Coalescer.split(merged, [2, 2, 1])
+    assert [b["save_dirs"] for b in back] == [p_["save_dirs"] for p_ in parts]

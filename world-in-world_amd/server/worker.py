@@ -96,9 +96,132 @@ class SVDWorker:
 
 
 # ------------------------------------------------------------------------------------------------
+# cross-client batching (the manager's batching policy, done so that B = 8 per GPU is FORMED)
+# ------------------------------------------------------------------------------------------------
+class Coalescer:
+    """Forms GPU batches ACROSS clients.  The reference manager does the opposite: it splits every request into
+    batch-1 tasks (worker_manager.py:448-469), sleeps 60 ms per dispatched task (:570) and polls results every 50 ms
+    (:548), so a worker never sees more than one candidate.  Here every client handler `submit`s its request; one
+    compute thread takes the oldest pending request, keeps collecting for at most `max_wait_s` or until `max_candidates`
+    candidates are pending, concatenates the requests key by key (the same `v[lo:hi]` algebra the manager uses to split,
+    inverted), runs the worker ONCE, and hands every client exactly its own candidates back, in order.  Wire format and
+    per-candidate results are unchanged (candidates are evaluated independently of what else is in the batch — the B >= 2
+    contract, bit for bit on the HIP path).
+
+    Failure containment: if the merged call raises, the participating requests are re-run one by one, so only the
+    offending client sees the error."""
+
+    def __init__(self, worker: Callable[[dict], dict], max_candidates: int = 8, max_wait_s: float = 0.02):
+        self.worker = worker
+        self.max_candidates = max(1, int(max_candidates))
+        self.max_wait_s = float(max_wait_s)
+        self._cv = threading.Condition()
+        self._pending: list = []          # [request, n_candidates, result slot (dict), done Event]
+        self._stop = False
+        self.batches: list = []           # candidates per worker call (observability / tests)
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    @staticmethod
+    def _count(req: dict) -> int:
+        return len(req["save_dirs"])
+
+    @staticmethod
+    def merge(reqs: list) -> dict:
+        out: dict = {}
+        keys = set(reqs[0])
+        for r in reqs[1:]:
+            if set(r) != keys:
+                raise ValueError("requests with different key sets cannot share a batch")
+        for k in reqs[0]:
+            vs = [r[k] for r in reqs]
+            if isinstance(vs[0], str):
+                if any(v != vs[0] for v in vs):
+                    raise ValueError(f"{k} differs between requests")
+                out[k] = vs[0]
+            elif isinstance(vs[0], np.ndarray):
+                out[k] = np.concatenate([np.asarray(v) for v in vs])
+            else:
+                out[k] = [x for v in vs for x in v]
+        return out
+
+    @staticmethod
+    def split(resp: dict, counts: list) -> list:
+        outs, lo = [], 0
+        for n in counts:
+            outs.append({k: (v if isinstance(v, str) else v[lo:lo + n]) for k, v in resp.items()})
+            lo += n
+        return outs
+
+    def submit(self, req: dict) -> dict:
+        slot: dict = {}
+        done = threading.Event()
+        with self._cv:
+            self._pending.append([req, self._count(req), slot, done])
+            self._cv.notify_all()
+        done.wait()
+        if "error" in slot:
+            raise slot["error"]
+        return slot["resp"]
+
+    def close(self) -> None:
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._thread.join(5)
+
+    def _take_batch(self):
+        import time
+        with self._cv:
+            while not self._pending and not self._stop:
+                self._cv.wait(0.2)
+            if self._stop and not self._pending:
+                return None
+            deadline = time.monotonic() + self.max_wait_s
+            while sum(p[1] for p in self._pending) < self.max_candidates:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    break
+                self._cv.wait(left)
+            batch, total = [], 0
+            while self._pending and (not batch or total + self._pending[0][1] <= self.max_candidates):
+                item = self._pending.pop(0)
+                batch.append(item)
+                total += item[1]
+            return batch
+
+    def _run(self):
+        while True:
+            batch = self._take_batch()
+            if batch is None:
+                return
+            try:
+                merged = self.merge([b[0] for b in batch]) if len(batch) > 1 else batch[0][0]
+                self.batches.append(sum(b[1] for b in batch))
+                resp = self.worker(merged)
+                parts = self.split(resp, [b[1] for b in batch]) if len(batch) > 1 else [resp]
+                for b, part in zip(batch, parts):
+                    b[2]["resp"] = part
+            except BaseException:  # noqa: BLE001 — isolate the offender: one request at a time
+                for b in batch:
+                    if len(batch) == 1:
+                        import sys as _s
+                        b[2]["error"] = _s.exc_info()[1]
+                        continue
+                    try:
+                        self.batches.append(b[1])
+                        b[2]["resp"] = self.worker(b[0])
+                    except BaseException as e:  # noqa: BLE001
+                        b[2]["error"] = e
+            for b in batch:
+                b[3].set()
+
+
+# ------------------------------------------------------------------------------------------------
 # transports
 # ------------------------------------------------------------------------------------------------
-def _handle_client(conn: socket.socket, worker: Callable[[dict], dict], batch_size: int, lock: threading.Lock):
+def _handle_client(conn: socket.socket, worker: Callable[[dict], dict], batch_size: int, lock: threading.Lock,
+                   coalescer: Optional[Coalescer] = None):
     with conn:
         while True:
             try:
@@ -108,6 +231,9 @@ def _handle_client(conn: socket.socket, worker: Callable[[dict], dict], batch_si
             if isinstance(req, str) and req == DONE:
                 return
             P.check_inputdict(req)
+            if coalescer is not None:
+                write_framed(conn, coalescer.submit(req))
+                continue
             if batch_size and batch_size > 0:  # the manager's split / recompose (worker_manager.py:448-481)
                 parts = []
                 for sub in P.split_batch(req, batch_size):
@@ -121,11 +247,17 @@ def _handle_client(conn: socket.socket, worker: Callable[[dict], dict], batch_si
 
 
 def serve_tcp(worker: Callable[[dict], dict], host="127.0.0.1", port=7000, batch_size: int = 0,
-              ready: Optional[threading.Event] = None, stop: Optional[threading.Event] = None) -> None:
+              ready: Optional[threading.Event] = None, stop: Optional[threading.Event] = None,
+              coalesce_candidates: int = 0, coalesce_wait_s: float = 0.02) -> None:
     """Accept loop (worker_manager.py:644-656): one thread per client, compute serialised by a lock.
     batch_size > 0 reproduces the manager's split into sub-batches (responses then carry LISTS per key,
-    exactly what the reference's recompose yields); 0 hands the whole request to the worker (true batching)."""
+    exactly what the reference's recompose yields); 0 hands the whole request to the worker (true batching).
+    coalesce_candidates > 0: requests of DIFFERENT clients that arrive within `coalesce_wait_s` are evaluated as one
+    batch of up to that many candidates (`Coalescer`)."""
     lock = threading.Lock()
+    coalescer = Coalescer(worker, coalesce_candidates, coalesce_wait_s) if coalesce_candidates > 0 else None
+    if ready is not None:
+        ready.coalescer = coalescer
     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     srv.bind((host, port))
@@ -140,9 +272,11 @@ def serve_tcp(worker: Callable[[dict], dict], host="127.0.0.1", port=7000, batch
                 conn, _ = srv.accept()
             except socket.timeout:
                 continue
-            threading.Thread(target=_handle_client, args=(conn, worker, batch_size, lock), daemon=True).start()
+            threading.Thread(target=_handle_client, args=(conn, worker, batch_size, lock, coalescer), daemon=True).start()
     finally:
         srv.close()
+        if coalescer is not None:
+            coalescer.close()
 
 
 def worker_main(pipe_fd: int, task_fn: Callable[[dict], dict], stdin=None) -> None:
@@ -186,4 +320,7 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--num_inference_steps", type=int, default=30)
     ap.add_argument("--port", type=int, default=0, help="> 0: standalone TCP server instead of the manager pipe loop")
     ap.add_argument("--batch_size", type=int, default=0)
+    ap.add_argument("--coalesce_candidates", type=int, default=0,
+                    help="> 0: batch requests of different clients into one GPU call of up to this many candidates")
+    ap.add_argument("--coalesce_wait_ms", type=float, default=20.0, help="how long the oldest pending request may wait for company")
     return ap
