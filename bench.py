@@ -282,10 +282,10 @@ def end_to_end(den, unet, device, B, args):
     clip = CLIPVisionModelWithProjection(CLIPVisionConfig(
         hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
         patch_size=14, projection_dim=1024, hidden_act="gelu")).eval()
-    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(1), device, hip=unet.hip), clip)
+    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(1), device, hip=unet.hip), clip, device_io=True)
 
-    def denoise(il, ie, nz, act, **kw):
-        return den.denoise(torch.from_numpy(il), torch.from_numpy(ie), torch.from_numpy(nz), act, **kw).cpu().numpy()
+    def denoise(il, ie, nz, act, **kw):   # as serve_worker.build_worker: latents stay on the device
+        return den.denoise(torch.as_tensor(il), torch.as_tensor(ie), torch.as_tensor(nz), act, **kw)
 
     worker = SVDWorker(denoise, fe, width=args.width, height=args.height, num_inference_steps=args.num_inference_steps)
     rs = np.random.RandomState(0)

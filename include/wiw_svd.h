@@ -43,7 +43,7 @@ int wiw_device_check(int dev, char* name, int name_len);
  * GEMM / implicit-GEMM convolution on bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
  *
  *   acc[m][n]  = sum_k Agather[m][k] * W[n][k]
- *   y          = alpha * (acc + bias[n] + rowvec[m / rows_per_vec][n]) (optionally SiLU)
+ *   y          = alpha * (acc + bias[n] + rowvec[m / rows_per_vec][n]) (optionally SiLU / GELU / quick-GELU)
  *   out[m][n]  = y + beta1 * res1[m][n] + beta2 * res2[m][n]
  *   GEGLU      : W rows are stored in tiles of 160 = [80 value | 80 gate] (see weights.py
  *                `pack_geglu`); out[m][j] = (v + bias_v) * gelu_erf(g + bias_g), N counts packed rows.
@@ -72,7 +72,9 @@ int wiw_device_check(int dev, char* name, int name_len);
  * ---------------------------------------------------------------------------------------------- */
 enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_UP = 3, WIW_A_CONV_T3 = 4,
        WIW_A_CONV3X3_S2P = 5 };
-enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4 };
+enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
+       WIW_EPI_GELU = 8,        /* y = gelu_erf(y)           (CLIP ViT-H MLP, transformers `gelu`) */
+       WIW_EPI_QUICK_GELU = 16  /* y = y * sigmoid(1.702 y)  (OpenAI CLIP `quick_gelu`) */ };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -226,6 +228,33 @@ int wiw_vae_time_conv_out(void* stream, const float* Y, int ldy, const float* we
                           int T, int HW, float* out);
 int wiw_nchw_f32_to_nhwc_bf16(void* stream, const float* X, int frames, int Cin, int HW, float scale, int Cpad,
                               void* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * CLIP image encoder: `_encode_image` of
+ * dp/pipelines/stable_video_diffusion/pipeline_stable_video_diffusion.py:183-229.  The transformer's linear layers,
+ * LayerNorms and residual adds are wiw_gemm_bf16 (with WIW_EPI_GELU / WIW_EPI_QUICK_GELU for the MLP) and
+ * wiw_layernorm_bf16; two operators exist only for it:
+ *
+ * wiw_clip_preprocess: `_resize_with_antialiasing` (pipeline:643-669: Gaussian blur, reflect padding, then bicubic
+ *   interpolation with align_corners=True) to out_size x out_size + `(x + 1) / 2` + (x - mean) / std (pipeline:199-208) +
+ *   the im2col of the stride-`patch` patch-embedding convolution (transformers CLIPVisionEmbeddings), written as bf16
+ *   operand rows of the patch GEMM:
+ *     img  fp32 DEVICE [B][3][H0][W0] in [-1, 1];  tmp fp32 DEVICE scratch [B*3*H0*out_size];
+ *     A    bf16 DEVICE [B*rows_per_image][ldA]: pixel (c, y, x) of image b -> row b*rows_per_image + 1 + (y/patch)*(out_size/patch)
+ *          + x/patch, column c*patch*patch + (y%patch)*patch + x%patch  (row 0 of an image is the class token's, left untouched,
+ *          as are the padding rows / columns: the caller zeroes the buffer once);
+ *     taps_x / taps_y (odd counts <= 31), mean[3], inv_std[3]: small HOST arrays (they become kernel arguments).
+ * wiw_attn_small_bf16: softmax(Q K^T * scale) V for short sequences and head_dim = any multiple of 16 up to 128
+ *   (ViT-H/14: S = 257, 16 heads of 80; F.scaled_dot_product_attention in transformers' CLIPAttention):
+ *     QK bf16 [seqs*Sp][ldqk] (Q at column h*head_dim, K at k_col_off + h*head_dim), Vt bf16 [heads*head_dim][ldvt]
+ *     (V TRANSPOSED, token index = seq*Sp + s), O bf16 [seqs*Sp][ldo]; Sp = row stride of a sequence, multiple of 16,
+ *     >= S; keys >= S are masked, query rows >= S are not written.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_clip_preprocess(void* stream, const float* img, int B, int H0, int W0, int out_size, int patch,
+                        const float* taps_x, int ntx, const float* taps_y, int nty, const float* mean, const float* inv_std,
+                        float* tmp, void* A, int rows_per_image, int ldA);
+int wiw_attn_small_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O,
+                        int ldo, int seqs, int S, int Sp, int heads, int head_dim, float scale);
 
 /* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);

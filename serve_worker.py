@@ -94,11 +94,12 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)
     # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module.  There is no PyTorch / MIOpen VAE
     # route in the product (it needed > 6 minutes per decode on a fresh box); the fp32 PyTorch chain lives in oracle/.
-    fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip, **vae_cfg), clip, dtype=dtype)
+    fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip, **vae_cfg), clip, dtype=dtype, device_io=True)
 
-    def denoise(image_latents, image_embeddings, noise, actions, **kw) -> np.ndarray:
-        return den.denoise(torch.from_numpy(image_latents), torch.from_numpy(image_embeddings),
-                           torch.from_numpy(noise), actions, **kw).cpu().numpy()
+    def denoise(image_latents, image_embeddings, noise, actions, **kw):
+        # device tensors in (HIPFrontend.encode, device_io) and out (decode_uint8 takes them): no host bounce of latents
+        return den.denoise(torch.as_tensor(image_latents), torch.as_tensor(image_embeddings), torch.as_tensor(noise),
+                           actions, **kw)
 
     return SVDWorker(denoise, fe, width=args.width, height=args.height, out_width=args.out_width,
                      out_height=args.out_height, num_frames=args.num_frames,

@@ -125,10 +125,11 @@ def test_coalesced_clients_get_their_alone_bytes_on_the_hip_path(tmp_path):
     den = SVDDenoiser(unet)
     vcfg = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
     torch.manual_seed(0)
-    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                                                           num_attention_heads=2, image_size=224, patch_size=32,
-                                                          projection_dim=1024)).eval()
-    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(22, **vcfg), "cuda:0", hip=unet.hip, **vcfg), clip, dtype=torch.float32)
+                                                          projection_dim=1024, hidden_act="gelu")).eval()
+    # VAE and CLIP both on the HIP kernels: every stage of the request is batch-independent bit for bit
+    fe = HIPFrontend(VAEHIP(FE.vae_random_state_dict(22, **vcfg), "cuda:0", hip=unet.hip, **vcfg), clip, clip="hip")
 
     def denoise(il, ie, nz, act, **kw):
         return den.denoise(torch.as_tensor(il), torch.as_tensor(ie), torch.as_tensor(nz), act, **kw).cpu().numpy()

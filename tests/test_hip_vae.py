@@ -141,7 +141,7 @@ def test_hip_frontend_protocol(vae_pair):
     clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
                                                           num_attention_heads=2, image_size=224, patch_size=32,
                                                           projection_dim=1024)).eval()
-    fe = HIPFrontend(vae, clip, dtype=torch.float32)
+    fe = HIPFrontend(vae, clip, dtype=torch.float32, clip="torch")   # 32-wide toy CLIP: below the HIP kernels' 64-channel granularity
     rs = np.random.RandomState(0)
     x = np.tanh(rs.standard_normal((2, 3, 128, 256))).astype(np.float32)
     lat, emb = fe.encode(x, rs.standard_normal(x.shape).astype(np.float32), 0.02)

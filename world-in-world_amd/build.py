@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwiwsvd.so")
-SOURCES = ["gemm.hip", "gemm_huge.hip", "attention.hip", "temporal.hip", "norm.hip", "elementwise.hip", "vae.hip"]
+SOURCES = ["gemm.hip", "gemm_huge.hip", "attention.hip", "temporal.hip", "clip.hip", "norm.hip", "elementwise.hip", "vae.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extras: the attention softmax never sees NaNs (infinities are used and preserved); dropping NaN

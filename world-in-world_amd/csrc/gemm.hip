@@ -318,13 +318,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 
     constexpr bool geglu = GE;   // compile-time: keeps the GEGLU-only / residual-only epilogue registers apart
     const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
+    const int act = p.epilogue & (WIW_EPI_GELU | WIW_EPI_QUICK_GELU);   // CLIP MLP activations (direct path only)
     const bool scale_acc = p.alpha != 1.0f;   // wave-uniform: most GEMMs skip the alpha multiply
     const bool out_f32 = (p.epilogue & WIW_EPI_OUT_F32) != 0;
     const int n_valid = geglu ? p.n_out : p.N;
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
     // staged (fast) epilogue: bf16 output on 16-byte aligned rows; everything else takes the direct path
-    const bool staged = !out_f32 && !do_silu && (n_valid % 8 == 0) && (p.ldo % 8 == 0) &&
+    const bool staged = !out_f32 && !do_silu && act == 0 && (n_valid % 8 == 0) && (p.ldo % 8 == 0) &&
                         (r1 == nullptr || p.ldr1 % 8 == 0) && (r2 == nullptr || p.ldr2 % 8 == 0) &&
                         ((((uintptr_t)p.bias | (uintptr_t)p.rowvec) & 15) == 0) && (p.rowvec_ld % 4 == 0);
 
@@ -644,6 +645,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                                 if (rv) y += rv[n];
                                 y *= p.alpha;
                                 if (do_silu) y = silu_f(y);
+                                if (act == WIW_EPI_GELU) y = gelu_erf_f(y);
+                                else if (act == WIW_EPI_QUICK_GELU)   // x * sigmoid(1.702 x)
+                                    y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * y));
                                 if (r1) y += p.beta1 * bf2f(r1[(int64_t)m * p.ldr1 + n]);
                                 if (r2) y += p.beta2 * bf2f(r2[(int64_t)m * p.ldr2 + n]);
                             }

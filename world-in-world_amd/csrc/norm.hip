@@ -28,7 +28,7 @@ constexpr int GN_MAXC = 4096;
 WIW_DEV void chan_merge(float& na, float& ma, float& Ma, float nb, float mb, float Mb) {
     if (nb <= 0.f) return;
     if (na <= 0.f) { na = nb; ma = mb; Ma = Mb; return; }
-    const float n = na + nb, d = mb - ma, f = nb / n;
+    const float n = na + nb, d = mb - ma, f = nb * __builtin_amdgcn_rcpf(n);   // 1-ulp reciprocal: deterministic, far below the bf16 output
     ma = __builtin_fmaf(d, f, ma);
     Ma = Ma + Mb + d * d * na * f;
     na = n;
@@ -55,44 +55,54 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
         const int chunk = cbase + ci;
         const bool active = rl < rp && chunk < chunks && r0 + rl < r1;
         const int c0 = chunk * 8;
-        float s[8], q[8], pv[8];
+        // packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two channels per VALU instruction) keeps this pass memory-bound:
+        // per 16-byte load 8 unpack + 4 sub + 4 add + 4 fma instructions
+        wiw_f32x2 s2[4], q2[4], p2[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; pv[e] = 0.f; }
+        for (int j = 0; j < 4; ++j) { s2[j] = wiw_f32x2{0.f, 0.f}; q2[j] = s2[j]; p2[j] = s2[j]; }
         int cnt = 0;
+        auto unpack2 = [](uint32_t u) { return wiw_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
+        auto accum = [&](const uint4& raw) {
+            const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const wiw_f32x2 d = unpack2(u[j]) - p2[j];
+                s2[j] += d;
+                q2[j] = __builtin_elementwise_fma(d, d, q2[j]);
+            }
+        };
         if (active) {
             const uint16_t* src;
             int ld, coff;
             if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
             int r = r0 + rl;
-            unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), pv);   // pivot = first row (re-read below: L1 hit)
+            {   // pivot = first row (re-read below: L1 hit)
+                const uint4 raw = *(const uint4*)(src + (base_row + r) * ld + coff);
+                p2[0] = unpack2(raw.x); p2[1] = unpack2(raw.y); p2[2] = unpack2(raw.z); p2[3] = unpack2(raw.w);
+            }
             for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent 16-byte loads in flight per thread
                 uint4 raw[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (base_row + r + u * rp) * ld + coff);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float f[8];
-                    unpack8(raw[u], f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = __builtin_fmaf(d, d, q[e]); }
-                }
+                for (int u = 0; u < 4; ++u) accum(raw[u]);
                 cnt += 4;
             }
             for (; r < r1; r += rp) {
-                float f[8];
-                unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = f[e] - pv[e]; s[e] += d; q[e] = __builtin_fmaf(d, d, q[e]); }
+                accum(*(const uint4*)(src + (base_row + r) * ld + coff));
                 ++cnt;
             }
         }
         {
             const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float ms = s[e] * inv;                       // mean of the shifted values
-                red[tid][e] = pv[e] + ms;
-                red[tid][8 + e] = fmaxf(q[e] - s[e] * ms, 0.f);    // M2 around the thread's own mean
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float sv = s2[j][h], ms = sv * inv;           // mean of the shifted values
+                    red[tid][2 * j + h] = p2[j][h] + ms;
+                    red[tid][8 + 2 * j + h] = fmaxf(q2[j][h] - sv * ms, 0.f);    // M2 around the thread's own mean
+                }
             }
         }
         __syncthreads();

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WIW_LIB", os.path.join(_HERE, "libwiwsvd.so"))
 
 A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1, 2, 3, 4, 5
-EPI_GEGLU, EPI_SILU, EPI_OUT_F32 = 1, 2, 4
+EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 
 
@@ -45,6 +45,11 @@ EXPORTS = {
                                          C.c_int, C.c_int, C.c_float]),
     "wiw_temporal_attn_block_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "wiw_clip_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "wiw_attn_small_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "wiw_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
@@ -180,6 +185,19 @@ class Hip:
                                                   heads, eps, scale, self.zeros.data_ptr()),
             "wiw_temporal_attn_block_bf16"))
         return O
+
+    def attn_small(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, seqs, S, Sp, heads, head_dim, scale):
+        self._timed("attn_small", 4.0 * seqs * heads * S * S * head_dim, 8.0 * seqs * S * heads * head_dim, lambda: self._ck(
+            self.lib.wiw_attn_small_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo, seqs, S, Sp,
+                                         heads, head_dim, scale), "wiw_attn_small_bf16"))
+        return O
+
+    def clip_preprocess(self, img, B, H0, W0, out_size, patch, taps_x, taps_y, mean, inv_std, tmp, A, rows_per_image, ldA):
+        fa = lambda v: (C.c_float * len(v))(*[float(x) for x in v])   # noqa: E731  small HOST parameter arrays
+        self._ck(self.lib.wiw_clip_preprocess(self._stream(), _p(img), B, H0, W0, out_size, patch, fa(taps_x), len(taps_x),
+                                              fa(taps_y), len(taps_y), fa(mean), fa(inv_std), _p(tmp), _p(A), rows_per_image,
+                                              ldA), "wiw_clip_preprocess")
+        return A
 
     @staticmethod
     def gn_rows_per_block(rows_per_unit: int, clip: bool) -> int:

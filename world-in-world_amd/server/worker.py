@@ -83,10 +83,11 @@ class SVDWorker:
         latents = self.denoise_fn(image_latents, image_embeddings, lat_noise, b_action,
                                   num_steps=self.num_inference_steps, fps=7, motion_bucket_id=127,
                                   noise_aug_strength=0.02)
-        lat = np.asarray(latents, dtype=np.float32)
-        if hasattr(self.frontend, "decode_uint8"):    # frame quantisation on the device (same arithmetic, same bytes)
-            clips = [[P.Image.fromarray(f) for f in clip] for clip in self.frontend.decode_uint8(lat)]
+        if hasattr(self.frontend, "decode_uint8"):    # frame quantisation on the device (same arithmetic, same bytes);
+            # `latents` may be a device tensor: nothing crosses PCIe between the loop and the decoder
+            clips = [[P.Image.fromarray(f) for f in clip] for clip in self.frontend.decode_uint8(latents)]
         else:
+            lat = np.asarray(latents.cpu() if hasattr(latents, "cpu") else latents, dtype=np.float32)
             frames = self.frontend.decode(lat)         # (B,T,3,H,W) in [-1,1]
             clips = [P.frames_to_pil(f) for f in frames]
         video = P.images_to_tensor(clips, save_size=self.out_size)

@@ -284,33 +284,56 @@ class VAEHIP:
 
 
 class HIPFrontend:
-    """`server.worker.Frontend` with the VAE on the HIP kernels; the CLIP image encoder stays the third-party
-    `transformers` module it is in the reference (pipeline:183-229), run by PyTorch-ROCm."""
+    """`server.worker.Frontend` on the HIP kernels: temporal VAE (`VAEHIP`) and the CLIP image encoder
+    (`clip.CLIPVisionHIP`, built from the weights of the `transformers` module the reference uses, pipeline:183-229)."""
 
-    def __init__(self, vae: VAEHIP, image_encoder, dtype=torch.bfloat16):
+    def __init__(self, vae: VAEHIP, image_encoder, dtype=torch.bfloat16, device_io: bool = False, clip: str = "hip"):
+        """image_encoder: a `transformers.CLIPVisionModelWithProjection` (its weights are taken).
+        clip = "hip" (product): the encoder runs on the HIP kernels and raises if its geometry is unsupported;
+        clip = "torch": the module itself runs on PyTorch-ROCm (checker / reduced-width test models only).
+        device_io: `encode` returns DEVICE tensors (and `decode*` accept them): the latents stay in HBM between
+        encode -> denoise -> decode instead of bouncing through host numpy."""
         from .frontend import clip_preprocess
+        self.device_io = device_io
         self._clip_preprocess = clip_preprocess
         self.vae = vae
         self.device = vae.device
         self.dtype = dtype
-        self.image_encoder = image_encoder.to(self.device, dtype).eval() if image_encoder is not None else None
+        self.clip_hip = None
+        self.image_encoder = None
+        if clip == "hip":
+            from .clip import CLIPVisionHIP
+            self.clip_hip = CLIPVisionHIP.from_transformers(image_encoder, self.device, hip=vae.hip)
+        elif clip == "torch":
+            self.image_encoder = image_encoder.to(self.device, dtype).eval() if image_encoder is not None else None
+        else:
+            raise ValueError("clip must be 'hip' or 'torch'")
+
+    def _embed(self, x: torch.Tensor, clip_images) -> torch.Tensor:
+        """(B,1,D) fp32 CLIP image embeddings; `clip_images` = per-candidate un-resized images (pipeline:192-199) or None."""
+        groups = [x] if clip_images is None else [torch.from_numpy(np.ascontiguousarray(c))[None].to(self.device, torch.float32)
+                                                   for c in clip_images]
+        if clip_images is not None and len({tuple(g.shape) for g in groups}) == 1:
+            groups = [torch.cat(groups)]                     # same size (the normal case): one batched pass
+        if self.clip_hip is not None:
+            emb = torch.cat([self.clip_hip(g) for g in groups])
+        else:
+            emb = torch.cat([self.image_encoder(self._clip_preprocess(g).to(self.dtype)).image_embeds for g in groups])
+        return emb[:, None].float()
 
     @torch.no_grad()
     def encode(self, images: np.ndarray, image_noise: np.ndarray, noise_aug_strength: float, clip_images=None):
         x = torch.from_numpy(np.ascontiguousarray(images)).to(self.device, torch.float32)
-        if clip_images is None:
-            pix = self._clip_preprocess(x)
-        else:   # CLIP branch on the un-resized images (pipeline:192-199); sizes may differ between candidates
-            pix = torch.cat([self._clip_preprocess(torch.from_numpy(np.ascontiguousarray(c))[None].to(self.device, torch.float32))
-                             for c in clip_images])
-        emb = self.image_encoder(pix.to(self.dtype)).image_embeds[:, None].float()
+        emb = self._embed(x, clip_images)
         xn = x + noise_aug_strength * torch.from_numpy(np.ascontiguousarray(image_noise)).to(self.device, torch.float32)
         lat = self.vae.encode_mode(xn)
+        if self.device_io:
+            return lat, emb
         return lat.cpu().numpy(), emb.cpu().numpy()
 
     @torch.no_grad()
-    def decode(self, latents: np.ndarray) -> np.ndarray:
-        z = torch.from_numpy(np.ascontiguousarray(latents))
+    def decode(self, latents) -> np.ndarray:
+        z = latents if torch.is_tensor(latents) else torch.from_numpy(np.ascontiguousarray(latents))
         return self.vae.decode(z).cpu().numpy()
 
     @torch.no_grad()
@@ -318,7 +341,7 @@ class HIPFrontend:
         """decode + the frame quantisation of `frames_to_pil` on the device: (x/2 + 0.5).clamp(0, 1) * 255, round half
         to even, uint8, HWC (image_processor.py:133-147) — the same fp32 operations in the same order, so the bytes
         are identical; 25 MB instead of 99 MB cross PCIe per candidate and the host skips a 0.3-0.7 s numpy pass."""
-        z = torch.from_numpy(np.ascontiguousarray(latents))
+        z = latents if torch.is_tensor(latents) else torch.from_numpy(np.ascontiguousarray(latents))
         out = []
         for b in range(z.shape[0]):          # per clip: bounds the fp32 frame buffer to one candidate
             out.append(frames_to_uint8_device(self.vae.decode(z[b:b + 1])[0]).cpu().numpy())
