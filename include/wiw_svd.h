@@ -248,7 +248,7 @@ int wiw_nchw_f32_to_nhwc_bf16(void* stream, const float* X, int frames, int Cin,
  *   (ViT-H/14: S = 257, 16 heads of 80; F.scaled_dot_product_attention in transformers' CLIPAttention):
  *     QK bf16 [seqs*Sp][ldqk] (Q at column h*head_dim, K at k_col_off + h*head_dim), Vt bf16 [heads*head_dim][ldvt]
  *     (V TRANSPOSED, token index = seq*Sp + s), O bf16 [seqs*Sp][ldo]; Sp = row stride of a sequence, multiple of 16,
- *     >= S; keys >= S are masked, query rows >= S are not written.
+ *     >= S; keys >= S are masked, query rows S .. Sp-1 are written as zeros.
  * ---------------------------------------------------------------------------------------------- */
 int wiw_clip_preprocess(void* stream, const float* img, int B, int H0, int W0, int out_size, int patch,
                         const float* taps_x, int ntx, const float* taps_y, int nty, const float* mean, const float* inv_std,

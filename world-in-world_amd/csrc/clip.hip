@@ -170,14 +170,15 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
         }
     }
     const int qi = qt * 16 + fr;
-    if (qi < S) {
-        const float inv = 1.0f / l_run;
+    if (qi < Sp) {   // padding query rows (S <= qi < Sp) are written as ZEROS: downstream GEMMs / LayerNorms stay finite
+        const float inv = qi < S ? 1.0f / l_run : 0.0f;
         uint16_t* dst = O + (row0 + qi) * ldo + h * D + fq * 4;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
             uint2 pk;
             pk.x = pack2bf(o[db][0] * inv, o[db][1] * inv);
             pk.y = pack2bf(o[db][2] * inv, o[db][3] * inv);
+            if (qi >= S) pk = uint2{0u, 0u};
             *(uint2*)(dst + db * 16) = pk;
         }
     }
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
 template <int D>
 void launch_small(hipStream_t s, const uint16_t* QK, int ldqk, int k_col_off, const uint16_t* Vt, int64_t ldvt, uint16_t* O,
                   int ldo, int seqs, int S, int Sp, int heads, float scale) {
-    const int q_tiles = (S + 15) / 16;
+    const int q_tiles = Sp / 16;   // all rows of a sequence, padding included (written as zeros)
     const int64_t total = (int64_t)seqs * heads * q_tiles;
     hipLaunchKernelGGL((attn_small_kernel<D>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, QK, ldqk, k_col_off, Vt,
                        ldvt, O, ldo, S, Sp, heads, q_tiles, total, scale * LOG2E);
@@ -206,7 +207,7 @@ extern "C" int wiw_attn_small_bf16(void* stream, const void* QK, int ldqk, int k
     WIW_REQUIRE(Sp % 16 == 0, "attn_small: the row stride of a sequence (Sp) must be a multiple of 16");
     WIW_REQUIRE(head_dim % 16 == 0 && head_dim >= 16 && head_dim <= 128, "attn_small: head_dim must be a multiple of 16, <= 128");
     WIW_REQUIRE(ldqk % 8 == 0 && k_col_off % 8 == 0 && ldvt % 4 == 0 && ldo % 4 == 0, "attn_small: misaligned strides");
-    WIW_REQUIRE((int64_t)seqs * heads * ((S + 15) / 16) < (1ll << 32), "attn_small: grid too large");
+    WIW_REQUIRE((int64_t)seqs * heads * (Sp / 16) < (1ll << 32), "attn_small: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const uint16_t* q = (const uint16_t*)QK;
     const uint16_t* v = (const uint16_t*)Vt;

@@ -106,29 +106,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
             }
         }
         __syncthreads();
-        if (tid < cpb && chunk < chunks) {   // row lane 0 of every chunk column: merge the row lanes in lane order
-            float tn[8], tm[8], tM[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { tn[e] = 0.f; tm[e] = 0.f; tM[e] = 0.f; }
-            for (int j = 0; j < rp; ++j) {
-                const int left = r1 - r0 - j;
-                const float nj = left > 0 ? (float)((left + rp - 1) / rp) : 0.f;   // rows row-lane j walked
-                const float* rr = red[j * cpb + ci];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) chan_merge(tn[e], tm[e], tM[e], nj, rr[e], rr[8 + e]);
+        // merge of the row lanes of a channel, fixed order, all 256 threads (thread = (chunk column ci, element pair)):
+        // mean = sum n_j mean_j / N, M2 = sum M2_j + sum n_j (mean_j - mean)^2  — the parallel-variance formula in its
+        // two-pass form (no per-merge division; stable: every term is a non-negative second moment about the merged mean)
+        for (int t = tid; t < cpb * 8; t += 256) {
+            const int cc = t >> 3, e = t & 7;
+            if (cbase + cc < chunks) {
+                const float inv_n = 1.0f / (float)(r1 - r0);
+                float ms = 0.f;
+                for (int j = 0; j < rp; ++j) {
+                    const int left = r1 - r0 - j;
+                    const float nj = left > 0 ? (float)((left + rp - 1) / rp) : 0.f;   // rows row-lane j walked
+                    ms += nj * red[j * cpb + cc][e];
+                }
+                const float mean = ms * inv_n;
+                float M2 = 0.f;
+                for (int j = 0; j < rp; ++j) {
+                    const int left = r1 - r0 - j;
+                    const float nj = left > 0 ? (float)((left + rp - 1) / rp) : 0.f;
+                    const float dm = red[j * cpb + cc][e] - mean;
+                    M2 += red[j * cpb + cc][8 + e] + nj * dm * dm;
+                }
+                chan[0][(cbase + cc) * 8 + e] = mean;
+                chan[1][(cbase + cc) * 8 + e] = M2;
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { chan[0][c0 + e] = tm[e]; chan[1][c0 + e] = tM[e]; }
         }
         __syncthreads();
     }
     if (tid < GROUPS) {   // channels of a group in channel order; every channel carries (r1 - r0) rows
         const int g = tid;
         const float nr = (float)(r1 - r0);
-        float n = 0.f, m = 0.f, M2 = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) chan_merge(n, m, M2, nr, chan[0][c], chan[1][c]);
+        float ms = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) ms += chan[0][c];
+        const float mean = ms / (float)cg;
+        float M2 = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { const float dm = chan[0][c] - mean; M2 += chan[1][c] + nr * dm * dm; }
         float* dst = partials + ((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + 2 * g;
-        dst[0] = m;
+        dst[0] = mean;
         dst[1] = M2;
     }
 }
@@ -145,13 +159,22 @@ __global__ __launch_bounds__(64 * GN_RED_PARTS) void gn_reduce_kernel(const floa
     const int unit = blockIdx.x, t = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (splits + GN_RED_PARTS - 1) / GN_RED_PARTS;
     const int b0 = w * per, b1 = b0 + per < splits ? b0 + per : splits;
-    if (t < GROUPS) {
+    if (t < GROUPS) {   // two-pass merge of this wave's blocks (block order): weighted mean, then M2 about it
         const float2* p = (const float2*)(partials + (int64_t)unit * splits * (GROUPS * 2)) + t;
-        float n = 0.f, m = 0.f, M2 = 0.f;
+        float n = 0.f, ms = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            const int rows = rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
+            const float nb_ = (float)rows * (float)cg;
+            n += nb_;
+            ms += nb_ * p[(int64_t)b * GROUPS].x;
+        }
+        const float m = n > 0.f ? ms / n : 0.f;
+        float M2 = 0.f;
         for (int b = b0; b < b1; ++b) {
             const int rows = rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
             const float2 v = p[(int64_t)b * GROUPS];
-            chan_merge(n, m, M2, (float)rows * (float)cg, v.x, v.y);
+            const float dm = v.x - m;
+            M2 += v.y + (float)rows * (float)cg * dm * dm;
         }
         part[w][t][0] = n; part[w][t][1] = m; part[w][t][2] = M2;
     }
