@@ -159,22 +159,31 @@ __global__ __launch_bounds__(64 * GN_RED_PARTS) void gn_reduce_kernel(const floa
     const int unit = blockIdx.x, t = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (splits + GN_RED_PARTS - 1) / GN_RED_PARTS;
     const int b0 = w * per, b1 = b0 + per < splits ? b0 + per : splits;
-    if (t < GROUPS) {   // two-pass merge of this wave's blocks (block order): weighted mean, then M2 about it
+    if (t < GROUPS) {   // two-pass merge of this wave's blocks (block order): weighted mean, then M2 about it.
+        // The partials are loaded ONCE (all loads independent, then held in registers for the second pass).
+        constexpr int CACHE = 32;
         const float2* p = (const float2*)(partials + (int64_t)unit * splits * (GROUPS * 2)) + t;
+        float2 v[CACHE];
+#pragma unroll
+        for (int i = 0; i < CACHE; ++i)
+            if (b0 + i < b1) v[i] = p[(int64_t)(b0 + i) * GROUPS];
+        auto rows_of = [&](int b) {
+            return rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
+        };
         float n = 0.f, ms = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            const int rows = rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
-            const float nb_ = (float)rows * (float)cg;
-            n += nb_;
-            ms += nb_ * p[(int64_t)b * GROUPS].x;
-        }
+#pragma unroll
+        for (int i = 0; i < CACHE; ++i)
+            if (b0 + i < b1) { const float nb_ = (float)rows_of(b0 + i) * (float)cg; n += nb_; ms += nb_ * v[i].x; }
+        for (int b = b0 + CACHE; b < b1; ++b) { const float nb_ = (float)rows_of(b) * (float)cg; n += nb_; ms += nb_ * p[(int64_t)b * GROUPS].x; }
         const float m = n > 0.f ? ms / n : 0.f;
         float M2 = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            const int rows = rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
-            const float2 v = p[(int64_t)b * GROUPS];
-            const float dm = v.x - m;
-            M2 += v.y + (float)rows * (float)cg * dm * dm;
+#pragma unroll
+        for (int i = 0; i < CACHE; ++i)
+            if (b0 + i < b1) { const float dm = v[i].x - m; M2 += v[i].y + (float)rows_of(b0 + i) * (float)cg * dm * dm; }
+        for (int b = b0 + CACHE; b < b1; ++b) {
+            const float2 u = p[(int64_t)b * GROUPS];
+            const float dm = u.x - m;
+            M2 += u.y + (float)rows_of(b) * (float)cg * dm * dm;
         }
         part[w][t][0] = n; part[w][t][1] = m; part[w][t][2] = M2;
     }
