@@ -101,9 +101,11 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
         return den.denoise(torch.as_tensor(image_latents), torch.as_tensor(image_embeddings), torch.as_tensor(noise),
                            actions, **kw)
 
-    return SVDWorker(denoise, fe, width=args.width, height=args.height, out_width=args.out_width,
-                     out_height=args.out_height, num_frames=args.num_frames,
-                     num_inference_steps=args.num_inference_steps)
+    worker = SVDWorker(denoise, fe, width=args.width, height=args.height, out_width=args.out_width,
+                       out_height=args.out_height, num_frames=args.num_frames,
+                       num_inference_steps=args.num_inference_steps)
+    worker.bind_thread = unet.hip.bind_thread     # serve_tcp handler threads start on HIP device 0
+    return worker
 
 
 def main(argv=None) -> None:

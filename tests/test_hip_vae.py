@@ -149,8 +149,9 @@ def test_hip_frontend_protocol(vae_pair):
     lat = rs.standard_normal((2, 4, 4, 16, 32)).astype(np.float32)
     fr = fe.decode(lat)
     assert fr.shape == (2, 4, 3, 128, 256) and np.isfinite(fr).all()
-    # device-side quantisation == frames_to_pil on the host, on the SAME decoded frames (two decodes differ in the
-    # last bits: GroupNorm statistics are accumulated with fp32 atomics)
+    # device-side quantisation == frames_to_pil on the host, on the SAME decoded frames (the kernels are deterministic —
+    # no atomics — so a second decode would give the same bytes; the comparison below only allows for decode_uint8
+    # running clip by clip)
     from wiw_amd.server import plumbing as P
     from wiw_amd.vae import frames_to_uint8_device
     frd = vae.decode(torch.from_numpy(lat))[0]

@@ -96,7 +96,7 @@ WIW_DEV float wave_max(float v) {
     return xor32_max(xor16_max(v));
 }
 
-// Host-side error bookkeeping (api.cpp)
+// Host-side error bookkeeping (elementwise.hip)
 void wiw_set_error(const char* msg);
 #define WIW_REQUIRE(cond, msg)        \
     do {                              \

@@ -109,6 +109,9 @@ class Hip:
         if rc != 0:
             raise RuntimeError(f"wiw_device_check: {self.lib.wiw_last_error().decode()}")
         self.arch = name.value.decode()
+        # HIP's current device is PER THREAD: grids are sized from the current device's CU count, streams belong to
+        # self.device.  One process serves one GPU (make it current here); server threads call bind_thread().
+        torch.cuda.set_device(self.device)
         self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
         # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
@@ -117,6 +120,11 @@ class Hip:
         self.kernel_profile = None
 
     # ---- helpers
+    def bind_thread(self) -> None:
+        """Make this library's device the calling thread's current HIP device (handler threads of serve_tcp start on
+        device 0 whatever --device says)."""
+        torch.cuda.set_device(self.device)
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 

@@ -60,9 +60,12 @@ class SVDWorker:
         # persistent generator: the draws of request k depend on requests 0..k-1, as in the reference
         self._rng = np.random.Generator(np.random.Philox(seed))
         self.noise_fn = noise_fn or (lambda shape: self._rng.standard_normal(shape, dtype=np.float32))
+        self.bind_thread: Optional[Callable[[], None]] = None   # set by the launcher: per-thread HIP device binding
 
     def __call__(self, request: dict) -> dict:
         """do_some_tasks (eval_inference.py:313-349)."""
+        if self.bind_thread is not None:
+            self.bind_thread()
         b_action, save_dirs, return_objects, images = P.parse_request(request, self.world_model_name)
         b_action = np.asarray(b_action)
         if b_action.ndim != 2 or b_action.shape[1] != self.num_frames:
