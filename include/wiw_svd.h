@@ -67,6 +67,11 @@ int wiw_device_check(int dev, char* name, int name_len);
  *        dp/models/upsampling.py:142-186 (Upsample2D).
  * mode WIW_A_CONV_T3   : (3,1,1) temporal conv, zero pad 1 over T; S = H*Wd       (K = 3 * C1)
  *        dp/models/resnet.py:570-592 (TemporalResnetBlock.conv1/conv2).
+ * W layouts: plain bf16 [N][K], or (epilogue bit WIW_W_TILED, static weights) TILED: ceil(N/8) x (K/64) blocks of 1 KiB,
+ *   block (nb, kt) = rows 8*nb .. 8*nb+7 (zero rows past N), k-values 64*kt .. 64*kt+63; inside a block row r occupies bytes
+ *   r*128 .. r*128+127 and its eight 16-byte chunks are stored XOR-swizzled: position p holds chunk p ^ r.  One LDS-DMA
+ *   instruction of the kernel then reads one contiguous KiB — 63 B/clk/CU against 25 B/clk/CU for eight row segments K*2 bytes
+ *   apart (tools/ubench/lds_fill.hip); the LDS image and every result bit are identical.  (`hip.tile_weight` builds it.)
  * Constraints: C1, C2, C3 % 64 == 0; K = C1 + C2 (dense), taps * C1 (conv) or 9 * C1 + C2 + C3 (conv3x3 + shortcut);
  * A2 only with WIW_A_DENSE / WIW_A_CONV3X3, A3 only with WIW_A_CONV3X3.
  * ---------------------------------------------------------------------------------------------- */
@@ -74,7 +79,8 @@ enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_U
        WIW_A_CONV3X3_S2P = 5 };
 enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
        WIW_EPI_GELU = 8,        /* y = gelu_erf(y)           (CLIP ViT-H MLP, transformers `gelu`) */
-       WIW_EPI_QUICK_GELU = 16  /* y = y * sigmoid(1.702 y)  (OpenAI CLIP `quick_gelu`) */ };
+       WIW_EPI_QUICK_GELU = 16, /* y = y * sigmoid(1.702 y)  (OpenAI CLIP `quick_gelu`) */
+       WIW_W_TILED = 32         /* W is pre-tiled for the LDS-DMA stream (below) */ };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -130,7 +136,7 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  * (dp/models/attention.py:735-737; to_q/to_k/to_v of dp/models/attention_processor.py:2358-2366 — no bias;
  * nn.LayerNorm of attention.py:659-694), rows m = (b*T + t)*S + s as above.
  *   X    : bf16 [batch*T*S][C]  the residual stream BEFORE norm1 (C = heads*64)
- *   Wqkv : bf16 [heads*192][C]  rows of head h = [to_q rows h*64.. | to_k rows | to_v rows], each row multiplied by the
+ *   Wqkv : bf16 [heads*192][C], TILED as described for wiw_gemm_bf16 (WIW_W_TILED);  rows of head h = [to_q rows h*64.. | to_k rows | to_v rows], each row multiplied by the
  *          LayerNorm weight gamma (W' = W * gamma, rounded to bf16): the kernel runs its MFMAs on the raw rows of X
  *   fold : fp32 [heads][512]    per head: s[192] = sum_k W'[n][k] (of the bf16-rounded W'), t[192] = sum_k W[n][k]*beta[k],
  *          128 floats of padding;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd

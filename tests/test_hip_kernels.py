@@ -529,3 +529,35 @@ def test_attn_spatial_long_sequence_many_blocks(hip):
     hip.attn_spatial(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads, 0.125)
     ref = sdpa(q.reshape(frames, S, C), k.reshape(frames, S, C), v.reshape(frames, S, C), heads).reshape(frames * S, C)
     check(o, ref, what="attn_spatial 8 x 2304 x 8 heads")
+
+
+# ----------------------------------------------------------------------------------------------
+# tiled weights (hip.TiledW): same LDS image, same bits
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,mode,epi", [(300, 320, 320, 0, 0), (4032, 1280, 1280, 0, 0), (130, 4, 64, 0, 0), (1000, 200, 128, 0, 0),
+                                            (128, 13, 192, 0, 0), (520, 2560, 320, 0, 1), (16384, 640, 2560, 0, 0),
+                                            (2 * 18 * 32, 320, 9 * 128, 1, 0), (70000, 320, 9 * 64, 1, 0), (2 * 4 * 64, 128, 3 * 128, 4, 0)])
+def test_gemm_tiled_weight_is_bit_identical(hip, M, N, K, mode, epi):
+    """The tiled layout only changes WHERE the LDS-DMA reads W from; every output bit must equal the row-major run."""
+    from wiw_amd import hip as H
+
+    taps = {0: 1, 1: 9, 4: 3}[mode]
+    C1 = K // taps
+    a = dev_bf(rnd(M, C1, seed=1))
+    w = dev_bf(rnd(N, K, seed=2) / math.sqrt(K))
+    bias = dev_f(rnd(N, seed=3))
+    kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi)
+    if mode == 1:
+        kw.update(H=18 if M == 2 * 18 * 32 else 250, Wd=32 if M == 2 * 18 * 32 else 280)
+    if mode == 4:
+        kw.update(H=8, Wd=8, T=4)
+    if epi & H.EPI_GEGLU:
+        kw["n_out"] = N // 2
+    outs = []
+    for W in (w, H.TiledW(w)):
+        out = torch.full((M, N // 2 if epi & H.EPI_GEGLU else N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        hip.gemm(a, W, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), f"tiled W changed the result (M={M} N={N} K={K} mode={mode} epi={epi})"

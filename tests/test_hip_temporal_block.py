@@ -44,8 +44,17 @@ def test_pack_temporal_qkv_fold_algebra():
     C, heads = 128, 2
     wq, wk, wv = (rnd(C, C, seed=s) / math.sqrt(C) for s in (1, 2, 3))
     gamma, beta = 1 + 0.3 * rnd(C, seed=4), 0.2 * rnd(C, seed=5)
-    wg, fold = pack_temporal_qkv(wq, wk, wv, gamma, beta)
+    from wiw_amd.hip import TiledW, tile_weight, untile_weight
+
+    wg, fold = pack_temporal_qkv(wq, wk, wv, gamma, beta, tiled=False)
     assert wg.shape == (heads * 192, C) and wg.dtype == torch.bfloat16 and fold.shape == (heads, 512)
+    # the kernel's operand = the same matrix in the tiled LDS-DMA layout (1-KiB blocks, swizzled chunks): a bijection
+    tiled, _ = pack_temporal_qkv(wq, wk, wv, gamma, beta)
+    assert tiled.shape == (heads * 192 * C,) and torch.equal(untile_weight(tiled, heads * 192, C), wg)
+    odd = torch.randn(13, 128).to(torch.bfloat16)              # N not a multiple of 8: zero rows pad the last block
+    assert torch.equal(TiledW(odd).untiled(), odd) and tile_weight(odd).numel() == 16 * 128
+    blk = tile_weight(wg).reshape(-1, 8, 8, 8)                 # [block][row r][position p][8 elements]
+    assert torch.equal(blk[0, 3, 5], wg[3, (5 ^ 3) * 8:(5 ^ 3) * 8 + 8])   # position p of row r holds chunk p ^ r
     x = rnd(7, C, seed=6) * 2 + 0.5
     mean, var = x.double().mean(-1, keepdim=True), x.double().var(-1, unbiased=False, keepdim=True)
     rstd = 1.0 / torch.sqrt(var + 1e-5)

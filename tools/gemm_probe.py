@@ -31,6 +31,8 @@ def main():
         rows_in = M * 4 if mode == 2 else (M // 4 if mode == 3 else M)
         A = torch.randn(rows_in, C1, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        if os.environ.get("TILED"):
+            W = H.TiledW(W)
         bias = torch.randn(N, device=dev)
         kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi)
         if mode:

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from .frontend import CLIP_MEAN, CLIP_STD
-from .hip import EPI_GELU, EPI_OUT_F32, EPI_QUICK_GELU, Hip
+from .hip import EPI_GELU, EPI_OUT_F32, EPI_QUICK_GELU, Hip, TiledW
 
 
 def gaussian_taps(in_size: int, out_size: int):
@@ -108,6 +108,9 @@ class CLIPVisionHIP:
                 w[f"{i}.{n}.weight"] = self._t(sd, p + f"mlp.{n}.weight").to(bf).contiguous()
                 w[f"{i}.{n}.bias"] = self._t(sd, p + f"mlp.{n}.bias").contiguous()
         w["proj.weight"] = self._t(sd, "visual_projection.weight").to(bf).contiguous()
+        for k in list(w):   # static GEMM weights in the LDS-DMA tiled layout; `v.weight` is the A operand of a swapped GEMM
+            if k.endswith(".weight") and w[k].dim() == 2 and w[k].dtype == bf and not k.endswith(".v.weight"):
+                w[k] = TiledW(w[k])
         torch.cuda.synchronize(self.device)
 
     def _buffers(self, B: int, H0: int, W0: int):

@@ -51,12 +51,26 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 WIW_DEV void glds16(const char* g, char* l) {
+#if WIW_ABLATE == 10   // no LDS-DMA at all (timing only: the MFMAs run on whatever the LDS holds)
+    asm volatile("" ::"v"(g), "s"(l));
+#else
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+#endif
 }
 // Sink for the epilogue stores / loads of lanes that own no valid output element: every epilogue VMEM
 // instruction is then executed by every wave unconditionally, which makes the number of stores queued behind the
 // prefetched LDS-DMA a compile-time constant (needed for the counted vmcnt waits below).
 __device__ uint4 g_dump[512 * 64];
+
+#ifdef WIW_TRACE   // debug build: block 0 records s_memtime at every slot boundary of its SECOND output tile (waves 0 and 4)
+__device__ long long g_trace[2][4096];
+#define WIW_TP(idx)                                                                                          \
+    do {                                                                                                     \
+        if (trace_on && (idx) < 4096) g_trace[wave >> 2][(idx)] = __builtin_readcyclecounter();            \
+    } while (0)
+#else
+#define WIW_TP(idx) do { } while (0)
+#endif
 
 template <int N>
 WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -153,6 +167,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     bool a_ok[4];
     int a_fb[4], a_y[4], a_x[4];   // conv: input-frame base row, output y / x  (temporal: a_y = t)
     const char* w_row[B_FULL + 1];
+    // WIW_W_TILED: W pre-tiled by the host into 1-KiB blocks [n / 8][k tile][8 rows x 128 B, chunks pre-swizzled]: one
+    // DMA instruction then reads ONE contiguous KiB (63 B/clk/CU) instead of 8 row segments K*2 bytes apart (25 B/clk/CU,
+    // tools/ubench/lds_fill.hip) — the LDS image is byte-identical
+    const bool w_tiled = (p.epilogue & WIW_W_TILED) != 0;
+    const int64_t w_kstep = w_tiled ? 1024 : BK * 2;
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
     auto setup_loader = [&](int tile) {
@@ -173,13 +192,24 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                 a_y[i] = (m / HW) % p.T;
             }
         }
+        const int w_last = ((p.N + 7) >> 3) - 1;   // tiled W: last 8-row block (blocks past N re-read it: computed, never stored)
 #pragma unroll
         for (int i = 0; i < B_FULL; ++i) {
-            int n = n0 + (wave * B_FULL + i) * 8 + rsub;
-            n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
-            w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+            if (w_tiled) {
+                int blk = (n0 >> 3) + wave * B_FULL + i;
+                blk = blk < w_last ? blk : w_last;
+                w_row[i] = (const char*)p.W + (int64_t)blk * nk * 1024 + lane * 16;
+            } else {
+                int n = n0 + (wave * B_FULL + i) * 8 + rsub;
+                n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
+                w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+            }
         }
-        {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
+        if (w_tiled) {   // NW = 8: rows 128..159 = blocks 16..19, half a block (4 rows = 512 contiguous bytes) per wave
+            int blk = (n0 >> 3) + B_FULL * NW + (wave >> 1);
+            blk = blk < w_last ? blk : w_last;
+            w_row[B_FULL] = (const char*)p.W + (int64_t)blk * nk * 1024 + (wave & 1) * 512 + (lane & 31) * 16;
+        } else {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
             const int r_h = B_FULL * NW * 8 + wave * 4 + (rsub & 3);   // r_h & 7 != rsub for odd waves
             const int chunk_h = (lane & 7) ^ (r_h & 7);
             int n = n0 + r_h;
@@ -233,10 +263,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(a_src(i, ld_tap, ld_cc), sA + i * 1024);
 #pragma unroll
-        for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * (BK * 2), sB + i * 1024);
+        for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * w_kstep, sB + i * 1024);
         if (B_HALF) {
             char* sH = smem + stage * STAGE_BYTES + A_BYTES + B_FULL * NW * 1024 + wave * 512;
-            if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * (BK * 2), sH);
+            if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * w_kstep, sH);
         }
         ++ld_kt;
         ld_cc += BK;
@@ -255,11 +285,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
         } else if (part == 2) {
 #pragma unroll
-            for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * (BK * 2), sB + i * 1024);
+            for (int i = 0; i < B_FULL; ++i) glds16(w_row[i] + (int64_t)ld_kt * w_kstep, sB + i * 1024);
         } else {
             if (B_HALF) {
                 char* sH = smem + stage * STAGE_BYTES + A_BYTES + B_FULL * NW * 1024 + wave * 512;
-                if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * (BK * 2), sH);
+                if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * w_kstep, sH);
             }
             ++ld_kt;
             ld_cc += BK;
@@ -334,11 +364,17 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     ld_tap = 0; ld_cc = 0; ld_kt = 0;
     int st_c = 0;   // ring stage holding the K tile the MFMAs consume next
     int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 6 / 12)
+#ifdef WIW_TRACE
+    int tiles_done = 0;
+#endif
 #pragma unroll
     for (int j = 0; j < D; ++j)
         if (j < nk) issue_next(j);
 
     while (t >= 0) {
+#ifdef WIW_TRACE
+        const bool trace_on = blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && tiles_done == 1;
+#endif
         const int tile_n = t % Nt;
         const int m0 = (t / Nt) * BM, n0 = tile_n * BN;
         setup_loader(t);   // recomputed (not kept live across the previous epilogue: VGPR budget); counters ld_* persist
@@ -378,30 +414,40 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         using ILPT = std::integral_constant<int, LPT>; using I6 = std::integral_constant<int, LPT - 1>;
         wait_tile(0, ILPT{});
         if (NW == 8) {
+            WIW_TP(0);
             if (lag) slot_barrier();
             for (int kt = 0; kt < nk; ++kt) {
                 slot_barrier();                                  // local barrier 4kt
+                WIW_TP(1 + 8 * kt);
                 const bool more = kt + D < nk;
                 int si = st_c + D;
                 si = si >= STAGES ? si - STAGES : si;
                 if (more) issue_part(si, I0{});
                 read_frags(st_c, 0);
+                WIW_TP(2 + 8 * kt);
                 slot_barrier_i();                                // 4kt+1
+                WIW_TP(3 + 8 * kt);
                 if (more) issue_part(si, I1{});
                 mma();
+                WIW_TP(4 + 8 * kt);
                 slot_barrier_i();                                // 4kt+2
+                WIW_TP(5 + 8 * kt);
                 if (more) issue_part(si, I2{});
                 read_frags(st_c, 1);
                 if (kt + 1 < nk) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     wait_tile(kt + 1, I6{});                     // 6 of tile kt+2's 7 DMA instructions are younger
                 }
+                WIW_TP(6 + 8 * kt);
                 slot_barrier_i();                                // 4kt+3
+                WIW_TP(7 + 8 * kt);
                 if (more) issue_part(si, I3{});
                 mma();
+                WIW_TP(8 + 8 * kt);
                 st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
             }
             if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
+            WIW_TP(1 + 8 * nk);
         } else {
             // SMALL (4 waves, one per SIMD, two blocks per CU): the co-resident block provides the overlap; one
             // barrier per K tile, both k-steps back to back
@@ -662,6 +708,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         }
         t = t_next;
         q = q_next;
+#ifdef WIW_TRACE
+        WIW_TP(2 + 8 * nk);      // end of the epilogue
+        ++tiles_done;
+#endif
     }
 }
 
@@ -712,6 +762,12 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
 }
 
 }  // namespace
+
+#ifdef WIW_TRACE
+extern "C" int wiw_gemm_trace_read(long long* out) {   // debug builds only: copy the slot-boundary timestamps to the host
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(long long) * 2 * 4096) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     WIW_REQUIRE(args != nullptr, "gemm: null args");

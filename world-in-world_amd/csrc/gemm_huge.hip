@@ -123,6 +123,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     bool a_ok[4];
     int a_fb[4], a_y[4], a_x[4];
     const char* w_row[5];
+    // WIW_W_TILED: W pre-tiled by the host into 1-KiB blocks [n / 8][k tile][8 rows x 128 B, chunks pre-swizzled]: one
+    // DMA instruction then reads ONE contiguous KiB (63 B/clk/CU) instead of 8 row segments K*2 bytes apart (25 B/clk/CU,
+    // tools/ubench/lds_fill.hip) — the LDS image is byte-identical
+    const bool w_tiled = (p.epilogue & WIW_W_TILED) != 0;
+    const int64_t w_kstep = w_tiled ? 1024 : HK * 2;
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
     auto setup_loader = [&](int tile) {
@@ -145,9 +150,16 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            int n = n0 + (wave * 5 + i) * 8 + rsub;
-            n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
-            w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+            if (w_tiled) {
+                int blk = (n0 >> 3) + wave * 5 + i;
+                const int last = ((p.N + 7) >> 3) - 1;
+                blk = blk < last ? blk : last;       // blocks past N re-read the last one (computed, never stored)
+                w_row[i] = (const char*)p.W + (int64_t)blk * nk * 1024 + lane * 16;
+            } else {
+                int n = n0 + (wave * 5 + i) * 8 + rsub;
+                n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
+                w_row[i] = (const char*)p.W + ((int64_t)n * p.K + chunk * 8) * 2;
+            }
         }
     };
 
@@ -198,10 +210,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
         } else if constexpr (part < 4) {
             constexpr int i = 2 * (part - 2);
-            glds16(w_row[i] + (int64_t)ld_kt * (HK * 2), sB + i * 1024);
-            glds16(w_row[i + 1] + (int64_t)ld_kt * (HK * 2), sB + (i + 1) * 1024);
+            glds16(w_row[i] + (int64_t)ld_kt * w_kstep, sB + i * 1024);
+            glds16(w_row[i + 1] + (int64_t)ld_kt * w_kstep, sB + (i + 1) * 1024);
         } else {
-            glds16(w_row[4] + (int64_t)ld_kt * (HK * 2), sB + 4 * 1024);
+            glds16(w_row[4] + (int64_t)ld_kt * w_kstep, sB + 4 * 1024);
             ++ld_kt;
             ld_cc += HK;
             if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }

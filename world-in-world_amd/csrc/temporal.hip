@@ -57,7 +57,7 @@ __device__ uint4 t_dump[512 * 64];
 
 struct TemporalArgs {
     const uint16_t* X;      // bf16 [batch*T*S][C]
-    const uint16_t* W;      // bf16 [heads*192][C]   rows of head h: q_h (64) | k_h (64) | v_h (64), gamma folded
+    const uint16_t* W;      // bf16 [heads*192][C] TILED (1-KiB blocks, see setup_loader); rows of head h: q_h | k_h | v_h, gamma folded
     const float* fold;      // fp32 [heads][512]     s[192] | t[192] | pad
     uint16_t* O;            // bf16 [batch*T*S][ldo]
     const char* zeros;
@@ -127,14 +127,15 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         }
 #pragma unroll
         for (int i = 0; i < W_FULL; ++i) {
-            const int n = (wave * W_FULL + i) * 8 + rsub;
-            const int chunk = (lane & 7) ^ (n & 7);
-            w_ofs[i] = (uint32_t)((((int64_t)h * W_ROWS + n) * p.C + chunk * 8) * 2);
+            // Wqkv is TILED by the host: 1-KiB blocks [row / 8][k tile][8 rows x 128 B, chunks pre-swizzled] — one DMA
+            // instruction reads one contiguous KiB (63 instead of 25 B/clk/CU, tools/ubench/lds_fill.hip)
+            const int blk = h * (W_ROWS / 8) + wave * W_FULL + i;
+            w_ofs[i] = (uint32_t)((int64_t)blk * (p.C / BK) * 1024 + lane * 16);
         }
         f_ofs = (uint32_t)(h * 2048 + (wave & 1) * 1024 + lane * 16);
     };
     auto a_src = [&](int i) -> const char* { return a_ok[i] ? Xb + (a_ofs[i] + (uint32_t)ld_kt * (BK * 2)) : p.zeros; };
-    auto w_src = [&](int i) -> const char* { return Wb + (w_ofs[i] + (uint32_t)ld_kt * (BK * 2)); };
+    auto w_src = [&](int i) -> const char* { return Wb + (w_ofs[i] + (uint32_t)ld_kt * 1024u); };
 
     // all DMA instructions of the loader's next K tile (prologue / cross-item prefetch)
     auto issue_next = [&](int stage) {

@@ -16,7 +16,49 @@ LIB_PATH = os.environ.get("WIW_LIB", os.path.join(_HERE, "libwiwsvd.so"))
 
 A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1, 2, 3, 4, 5
 EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
+W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
+
+
+class TiledW:
+    """A static GEMM weight [N][K] (bf16) re-laid-out ONCE for the kernels' LDS-DMA stream: ceil(N/8) x (K/64) blocks of
+    1 KiB, block (nb, kt) = rows 8nb..8nb+7 x k-values 64kt..64kt+63, row r of a block at bytes r*128.. with its eight
+    16-byte chunks XOR-swizzled (position p holds chunk p ^ r) — exactly the LDS image of gemm.hip, so one DMA
+    instruction copies one contiguous KiB: 63 B/clk/CU instead of 25 for eight row segments K*2 bytes apart
+    (tools/ubench/lds_fill.hip).  Quacks like the [N, K] tensor it replaces (`shape`, `data_ptr`)."""
+
+    def __init__(self, w: torch.Tensor):
+        assert w.dim() == 2 and w.dtype == torch.bfloat16 and w.shape[1] % 64 == 0, "TiledW: bf16 [N, K] with K % 64 == 0"
+        self.shape = tuple(w.shape)
+        self.data = tile_weight(w)
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def untiled(self) -> torch.Tensor:
+        return untile_weight(self.data, *self.shape)
+
+
+def tile_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] bf16 -> flat tiled tensor (layout: class TiledW)."""
+    N, K = w.shape
+    Np = -(-N // 8) * 8
+    if Np != N:
+        w = torch.cat([w, w.new_zeros(Np - N, K)])
+    x = w.reshape(Np // 8, 8, K // 64, 8, 8).permute(0, 2, 1, 3, 4)           # [nb][kt][r][chunk][e]
+    r = torch.arange(8, device=w.device)
+    idx = (r[None, :] ^ r[:, None])                                          # [r][p] -> chunk stored at position p
+    x = torch.gather(x, 3, idx[None, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
+    return x.contiguous().reshape(-1)
+
+
+def untile_weight(t: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    Np = -(-N // 8) * 8
+    x = t.reshape(Np // 8, K // 64, 8, 8, 8)
+    r = torch.arange(8, device=t.device)
+    idx = (r[None, :] ^ r[:, None])                                          # the swizzle is an involution per row
+    x = torch.gather(x, 3, idx[None, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
+    return x.permute(0, 2, 1, 3, 4).reshape(Np, K)[:N].contiguous()
 
 
 class WiwGemmArgs(C.Structure):
@@ -112,7 +154,7 @@ class Hip:
         # HIP's current device is PER THREAD: grids are sized from the current device's CU count, streams belong to
         # self.device.  One process serves one GPU (make it current here); server threads call bind_thread().
         torch.cuda.set_device(self.device)
-        self.zeros = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        self.zeros = torch.zeros(16384 + 64, dtype=torch.uint8, device=self.device)   # the kernels' zero page (include/wiw_svd.h)
         # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
@@ -158,7 +200,7 @@ class Hip:
         a.ldr1, a.ldr2, a.n_out = ldr1, ldr2, n_out
         a.rowvec_ld, a.rows_per_vec = rowvec_ld, rows_per_vec
         a.alpha, a.beta1, a.beta2 = alpha, beta1, beta2
-        a.epilogue = epilogue
+        a.epilogue = epilogue | (W_TILED if isinstance(W, TiledW) else 0)
         if self.gemm_profile is None:
             self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
             return out

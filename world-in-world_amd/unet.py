@@ -28,7 +28,7 @@ import torch
 
 from .config import UNetConfig
 from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI_GEGLU, EPI_OUT_F32, EPI_SILU,
-                  GEGLU_TILE, Hip)
+                  GEGLU_TILE, Hip, TiledW, tile_weight)
 from .weights import validate_state_dict
 
 CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
@@ -70,7 +70,8 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     return wp.contiguous(), bp.contiguous(), n_half
 
 
-def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                      tiled: bool = True):
     """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
     weight folded in (W' = bf16(W * gamma)), and per head the fold vectors s = sum_k W'[n][k] (of the ROUNDED weights,
     so the fold is exact for what the MFMAs multiply), t = sum_k W[n][k] * beta[k]:
@@ -82,7 +83,8 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     fold = torch.zeros(heads, 512, dtype=torch.float32, device=wp.device)
     fold[:, :192] = wg.float().sum(dim=1).reshape(heads, 192)
     fold[:, 192:384] = (wp @ beta.float()).reshape(heads, 192)
-    return wg, fold.contiguous()
+    # the kernel streams the weight in the tiled layout of hip.TiledW (1-KiB blocks, one contiguous KiB per DMA instruction)
+    return (tile_weight(wg) if tiled else wg), fold.contiguous()
 
 
 @dataclass
@@ -234,6 +236,15 @@ class UNetHIP:
         w["temb_all.weight"] = torch.cat(temb_w).to(bf).contiguous()
         w["temb_all.bias"] = torch.cat(temb_b).contiguous()
         self.temb_total = off
+        # Every static GEMM weight is re-laid-out for the LDS-DMA stream (hip.TiledW).  Exceptions: `attn1.to_v` of the
+        # spatial block is the A operand of a swapped-operand GEMM (V^T = Wv . a^T) and stays row-major; the fused
+        # temporal weights are tiled by pack_temporal_qkv.
+        if not os.environ.get("WIW_W_UNTILED"):    # A/B knob
+            for k in list(w):
+                t_ = w[k]
+                if (k.endswith(".weight") and torch.is_tensor(t_) and t_.dim() == 2 and t_.dtype == bf
+                        and t_.shape[1] % 64 == 0 and not k.endswith(".attn1.to_v.weight") and ".fused." not in k):
+                    w[k] = TiledW(t_)
         # frame-position embeddings depend only on the frame index -> computed once (transformer_temporal.py:329-339)
         T = cfg.num_frames
         self.pos_emb_T: Dict[str, torch.Tensor] = {}

@@ -134,6 +134,13 @@ class VAEHIP:
         conv3("decoder.conv_out")
         w["decoder.time_conv_out.weight"] = self._t(sd, "decoder.time_conv_out.weight")[:, :, :, 0, 0].contiguous()  # [co][ci][dt]
         w["decoder.time_conv_out.bias"] = self._t(sd, "decoder.time_conv_out.bias").contiguous()
+        # static GEMM weights in the LDS-DMA tiled layout (hip.TiledW); `to_v` is the A operand of a swapped GEMM
+        from .hip import TiledW
+        for k in list(w):
+            t_ = w[k]
+            if (k.endswith(".weight") and torch.is_tensor(t_) and t_.dim() == 2 and t_.dtype == bf and t_.shape[1] % 64 == 0
+                    and not k.endswith(".to_v.weight")):
+                w[k] = TiledW(t_)
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------------------------------
