@@ -27,6 +27,9 @@
 //     All global loads of the epilogue are issued before the LDS transpose so their latency overlaps it.
 //   * tile order is XCD-aware: each of the 8 XCDs (private L2) gets a contiguous range of tiles.
 #include <stdlib.h>
+#ifndef WIW_DMA_BURST
+#define WIW_DMA_BURST 1   // 1: all DMA instructions of a K tile are issued in ONE slot (0: spread 2|2|2|1 over the four slots)
+#endif
 #ifndef WIW_ABLATE
 #define WIW_ABLATE 0
 #endif
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        using ILPT = std::integral_constant<int, LPT>; using I6 = std::integral_constant<int, LPT - 1>;
+        using ILPT = std::integral_constant<int, LPT>; using I6 [[maybe_unused]] = std::integral_constant<int, LPT - 1>;
         wait_tile(0, ILPT{});
         if (NW == 8) {
             WIW_TP(0);
@@ -422,26 +425,42 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                 const bool more = kt + D < nk;
                 int si = st_c + D;
                 si = si >= STAGES ? si - STAGES : si;
+#if WIW_DMA_BURST
+                // A slot that issues ANY LDS-DMA pays ~180 cycles once, every further instruction of the same slot ~25
+                // (tools/trace_probe.py): the 7 instructions of K tile kt+2 go out together here instead of 2|2|2|1
+                if (more) { issue_part(si, I0{}); issue_part(si, I1{}); issue_part(si, I2{}); issue_part(si, I3{}); }
+#else
                 if (more) issue_part(si, I0{});
+#endif
                 read_frags(st_c, 0);
                 WIW_TP(2 + 8 * kt);
                 slot_barrier_i();                                // 4kt+1
                 WIW_TP(3 + 8 * kt);
+#if !WIW_DMA_BURST
                 if (more) issue_part(si, I1{});
+#endif
                 mma();
                 WIW_TP(4 + 8 * kt);
                 slot_barrier_i();                                // 4kt+2
                 WIW_TP(5 + 8 * kt);
+#if !WIW_DMA_BURST
                 if (more) issue_part(si, I2{});
+#endif
                 read_frags(st_c, 1);
                 if (kt + 1 < nk) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if WIW_DMA_BURST
+                    wait_tile(kt + 1, ILPT{});                   // all 7 DMA instructions of tile kt+2 are younger
+#else
                     wait_tile(kt + 1, I6{});                     // 6 of tile kt+2's 7 DMA instructions are younger
+#endif
                 }
                 WIW_TP(6 + 8 * kt);
                 slot_barrier_i();                                // 4kt+3
                 WIW_TP(7 + 8 * kt);
+#if !WIW_DMA_BURST
                 if (more) issue_part(si, I3{});
+#endif
                 mma();
                 WIW_TP(8 + 8 * kt);
                 st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;

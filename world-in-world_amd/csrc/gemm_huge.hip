@@ -18,6 +18,9 @@
 //     R(k0: A, W[0:5]) | M | R(k0: W[5:10]) | M | R(k1: A, W[0:5]) | M | R(k1: W[5:10]), confirm next tile | M
 // DMA of K tile kt+1 (9 instructions per wave) is issued 2|2|2|2|1 in slots 0..4 of tile kt.
 #include <stdlib.h>
+#ifndef WIW_DMA_BURST
+#define WIW_DMA_BURST 0   // 1: all DMA instructions of a K tile in ONE slot; 0: spread over five slots (measured: burst -2...-5 % on this tile, +2...+4 % on the 256x160 tile and the temporal block)
+#endif
 #ifndef WIW_ABLATE
 #define WIW_ABLATE 0
 #endif
@@ -294,20 +297,33 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             const bool more = kt + 1 < nk;
             const int si = st_c ^ 1;
             slot_barrier();                                    // 8kt
+#if WIW_DMA_BURST
+            // a slot that issues ANY LDS-DMA pays ~180 cycles once, further instructions ~25 each (tools/trace_probe.py)
+            if (more) issue_all(si);
+#else
             if (more) issue_part(si, IC<0>{});
+#endif
             read_a(st_c, 0);
             read_b(st_c, 0, IC<0>{});
             slot_barrier();                                    // +1
+#if !WIW_DMA_BURST
             if (more) issue_part(si, IC<1>{});
+#endif
             mma(IC<0>{});
             slot_barrier();                                    // +2
+#if !WIW_DMA_BURST
             if (more) issue_part(si, IC<2>{});
+#endif
             read_b(st_c, 0, IC<1>{});
             slot_barrier();                                    // +3
+#if !WIW_DMA_BURST
             if (more) issue_part(si, IC<3>{});
+#endif
             mma(IC<1>{});
             slot_barrier();                                    // +4
+#if !WIW_DMA_BURST
             if (more) issue_part(si, IC<4>{});
+#endif
             read_a(st_c, 1);
             read_b(st_c, 1, IC<0>{});
             slot_barrier();                                    // +5

@@ -31,6 +31,10 @@
 
 #include "common.h"
 
+#ifndef WIW_DMA_BURST
+#define WIW_DMA_BURST 1   // 1: all DMA instructions of a K tile are issued in ONE slot (0: spread over the four slots)
+#endif
+
 namespace {
 
 constexpr int BK = 64;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        using ILPT = std::integral_constant<int, LPT>; using ILATE = std::integral_constant<int, LPT - P3>;
+        using ILPT = std::integral_constant<int, LPT>; using ILATE [[maybe_unused]] = std::integral_constant<int, LPT - P3>;
         wait_tile(0, ILPT{});
         if (lag) slot_barrier();
         for (int kt = 0; kt < nk; ++kt) {
@@ -281,20 +285,35 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
             const bool more = kt + D < nk;
             int si = st_c + D;
             si = si >= STAGES ? si - STAGES : si;
+#if WIW_DMA_BURST
+            // a slot that issues ANY LDS-DMA pays ~180 cycles once, further instructions ~25 each (tools/trace_probe.py)
+            if (more) { issue_part(si, I0{}); issue_part(si, I1{}); issue_part(si, I2{}); issue_part(si, I3{}); }
+#else
             if (more) issue_part(si, I0{});
+#endif
             read_frags(st_c, 0);
             slot_barrier();                                  // 4kt+1
+#if !WIW_DMA_BURST
             if (more) issue_part(si, I1{});
+#endif
             mma();
             slot_barrier();                                  // 4kt+2
+#if !WIW_DMA_BURST
             if (more) issue_part(si, I2{});
+#endif
             read_frags(st_c, 1);
             if (kt + 1 < nk) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if WIW_DMA_BURST
+                wait_tile(kt + 1, ILPT{});
+#else
                 wait_tile(kt + 1, ILATE{});
+#endif
             }
             slot_barrier();                                  // 4kt+3
+#if !WIW_DMA_BURST
             if (more) issue_part(si, I3{});
+#endif
             mma();
             st_c = (st_c + 1 == STAGES) ? 0 : st_c + 1;
         }
