@@ -262,6 +262,11 @@ int wiw_clip_preprocess(void* stream, const float* img, int B, int H0, int W0, i
 int wiw_attn_small_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O,
                         int ldo, int seqs, int S, int Sp, int heads, int head_dim, float scale);
 
+/* Y[c][r] = X[r][c0 + c] for c < C, r < rows (bf16; 64x64 LDS tiles, 128-byte segments on both sides).  Hands
+ * wiw_attn_spatial_bf16 its V^T operand from the V columns of ONE fused q|k|v projection (to_q / to_k / to_v of
+ * dp/models/attention_processor.py:2358-2366 as a single GEMM).  rows, C, c0, ldx, ldy multiples of 8. */
+int wiw_transpose_bf16(void* stream, const void* X, int64_t ldx, int c0, int64_t rows, int C, void* Y, int64_t ldy);
+
 /* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);
 

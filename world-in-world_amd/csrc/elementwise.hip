@@ -130,7 +130,45 @@ inline int grid_for(int64_t total, int block) {
     return (int)g;
 }
 
+// Y[c][r] = X[r][c0 + c]  (bf16), 64 x 64 tiles through LDS: 128-byte row segments on both sides.
+// Used to hand the attention kernel V^T from a V that one fused q|k|v projection wrote row-major.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int c0, int64_t rows,
+                                                              int C, uint16_t* __restrict__ Y, int64_t ldy) {
+    __shared__ uint16_t tile[64][66];   // +2: the column reads below hit 64 different banks pairs
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int cb = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    // load: 64 rows x 128 B; thread -> (row = tid / 4 + 0 / 64 ..., 32-byte piece)
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int r = i >> 3, ch = i & 7;                       // 8 chunks of 16 B per row
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (r0 + r < rows && cb + ch * 8 < C) v = *(const uint4*)(X + (r0 + r) * ldx + c0 + cb + ch * 8);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { tile[r][ch * 8 + 2 * e] = (uint16_t)(u[e] & 0xffffu); tile[r][ch * 8 + 2 * e + 1] = (uint16_t)(u[e] >> 16); }
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int c = i >> 3, ch = i & 7;                       // output row c, 8 consecutive source rows
+        if (cb + c < C && r0 + ch * 8 < rows) {
+            uint32_t u[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
+            *(uint4*)(Y + (int64_t)(cb + c) * ldy + r0 + ch * 8) = uint4{u[0], u[1], u[2], u[3]};
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wiw_transpose_bf16(void* stream, const void* X, int64_t ldx, int c0, int64_t rows, int C, void* Y, int64_t ldy) {
+    WIW_REQUIRE(X && Y, "transpose: null pointer");
+    WIW_REQUIRE(rows > 0 && C > 0 && rows % 8 == 0 && C % 8 == 0 && c0 % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0,
+                "transpose: rows, C, c0, ldx, ldy must be multiples of 8");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)X, ldx, c0, rows, C, (uint16_t*)Y, ldy);
+    return wiw_check_launch("wiw_transpose_bf16");
+}
 
 extern "C" int wiw_fill_f32(void* stream, float* p, int64_t n, float value) {
     WIW_REQUIRE(p != nullptr && n > 0, "fill: bad args");

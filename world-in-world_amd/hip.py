@@ -109,6 +109,7 @@ EXPORTS = {
                                       C.c_int, C.c_void_p]),
     "wiw_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_float, C.c_float]),
+    "wiw_transpose_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -317,6 +318,12 @@ class Hip:
             self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
                                         addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16"))
         return out
+
+    def transpose(self, X, ldx, c0, rows, Cn, Y, ldy):
+        """Y[c][r] = X[r][c0 + c] (bf16)."""
+        self._timed("transpose", 0.0, 4.0 * rows * Cn, lambda: self._ck(
+            self.lib.wiw_transpose_bf16(self._stream(), _p(X), ldx, c0, rows, Cn, _p(Y), ldy), "wiw_transpose_bf16"))
+        return Y
 
     def emb_combine(self, time, act, noise, Bc, B, T, E, out):
         self._ck(self.lib.wiw_emb_combine(self._stream(), _p(time), _p(act), _p(noise), Bc, B, T, E, _p(out)),

@@ -109,6 +109,7 @@ class UNetHIP:
         validate_state_dict(cfg, state_dict)
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
+        self.swapped_vt = bool(os.environ.get("WIW_SWAPPED_VT"))   # A/B knob: V^T by a swapped-operand GEMM (round 1)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         self._prepare(state_dict)
 
@@ -186,6 +187,8 @@ class UNetHIP:
             norm(b + ".norm1"); norm(b + ".norm3"); norm(t + ".norm_in"); norm(t + ".norm1"); norm(t + ".norm3")
             w[b + ".attn1.to_qk.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"),
                                                       self._t(sd, b + ".attn1.to_k.weight")]).to(bf).contiguous()
+            w[b + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"), self._t(sd, b + ".attn1.to_k.weight"),
+                                                       self._t(sd, b + ".attn1.to_v.weight")]).to(bf).contiguous()
             lin(b + ".attn1.to_v", bias=False); lin(b + ".attn1.to_out.0")
             w[t + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, t + ".attn1.to_q.weight"),
                                                        self._t(sd, t + ".attn1.to_k.weight"),
@@ -373,12 +376,20 @@ class UNetHIP:
         h = self._linear(xn, p + ".proj_in", M)
         # ---- spatial block (attention.py:462-582)
         a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
-        qk = self._empty(M, 2 * Cn)
-        hip.gemm(a, w[b + ".attn1.to_qk.weight"], qk, M=M, N=2 * Cn, K=Cn, C1=Cn)
-        vt = self._empty(Cn, M)  # V^T = Wv . a^T  (operands swapped: keys become the contiguous dim)
-        hip.gemm(w[b + ".attn1.to_v.weight"], a, vt, M=Cn, N=M, K=Cn, C1=Cn)
+        vt = self._empty(Cn, M)
         o = self._empty(M, Cn)
-        hip.attn_spatial(qk, 2 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
+        if self.swapped_vt:     # A/B knob (round-1 form): V^T = Wv . a^T as a second, operand-swapped GEMM
+            qk = self._empty(M, 2 * Cn)
+            hip.gemm(a, w[b + ".attn1.to_qk.weight"], qk, M=M, N=2 * Cn, K=Cn, C1=Cn)
+            hip.gemm(w[b + ".attn1.to_v.weight"], a, vt, M=Cn, N=M, K=Cn, C1=Cn)
+            hip.attn_spatial(qk, 2 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
+        else:
+            # ONE q|k|v projection (the activation is read once, N = 3C fills the tiles better than the 320-row swapped
+            # GEMM did: 200 us -> 45 + 65 us at the C = 320 level), then a 64x64-tiled transpose of the V columns
+            qkv = self._empty(M, 3 * Cn)
+            hip.gemm(a, w[b + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
+            hip.transpose(qkv, 3 * Cn, 2 * Cn, M, Cn, vt, M)
+            hip.attn_spatial(qkv, 3 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
         # The adds that follow a GEMM in the reference — the single-key cross-attention output (one vector per CFG item,
         # attention.py:545-551, 740-743) and the frame-position embedding (transformer_temporal.py:352-353) — ride in that
         # GEMM's epilogue as its per-row-group vector, so every LayerNorm below is a plain one-read / one-write pass.
