@@ -31,8 +31,9 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 3   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
-                             3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance) */
+#define WIW_ABI_VERSION 4   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+                             3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
+                             4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16 */
 
 int wiw_abi_version(void);
 const char* wiw_last_error(void);
@@ -102,6 +103,10 @@ typedef struct WiwGemmArgs {
     int32_t rowvec_ld, rows_per_vec;
     float alpha, beta1, beta2;
     int32_t epilogue;    /* WIW_EPI_* bits */
+    int32_t splitk;      /* 0 / 1: off.  S > 1: the K loop is cut into S equal ranges (K / 64 divisible by S) whose raw fp32
+                          * sums go to `workspace`; a second kernel adds them IN RANGE ORDER and applies the epilogue
+                          * (deterministic; for launches whose M alone cannot fill 256 CUs).  Not with GEGLU / GELU. */
+    void* workspace;     /* split-K only: S * M * N floats of device scratch */
 } WiwGemmArgs;
 
 int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args);

@@ -34,15 +34,17 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported"
     lib.wiw_abi_version.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 3
+    assert lib.wiw_abi_version() == 4
 
 
 def test_gemm_args_struct_layout():
     from wiw_amd.hip import WiwGemmArgs
 
-    # 10 pointers + 20 x 4-byte fields, natural alignment (matches the C struct in wiw_svd.h)
-    assert ctypes.sizeof(WiwGemmArgs) == 10 * 8 + 20 * 4
+    # 10 pointers + 21 x 4-byte fields (+ 4 bytes of padding) + the split-K workspace pointer, natural alignment
+    # (matches the C struct in wiw_svd.h)
+    assert ctypes.sizeof(WiwGemmArgs) == 10 * 8 + 21 * 4 + 4 + 8
     assert WiwGemmArgs.M.offset == 80 and WiwGemmArgs.epilogue.offset == 80 + 19 * 4
+    assert WiwGemmArgs.splitk.offset == 80 + 20 * 4 and WiwGemmArgs.workspace.offset == 168
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -561,3 +561,108 @@ def test_gemm_tiled_weight_is_bit_identical(hip, M, N, K, mode, epi):
     torch.cuda.synchronize()
     assert torch.isfinite(outs[0].float()).all()
     assert torch.equal(outs[0], outs[1]), f"tiled W changed the result (M={M} N={N} K={K} mode={mode} epi={epi})"
+
+
+# ----------------------------------------------------------------------------------------------
+# split-K (WiwGemmArgs.splitk): K ranges as extra schedule rows, fp32 partial slabs, reduce + epilogue kernel
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sk", [2, 4])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_gemm_splitk_dense_all_epilogue_terms(hip, sk, tiled):
+    from wiw_amd import hip as H
+
+    M, N, K = 1000, 320, 2048            # 4 x 2 tiles of 256 x 160, partial last M tile, 32 K tiles
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    b, rv = rnd(N, seed=3), rnd(M // 100, 2 * N, seed=4)
+    r1, r2 = bf(rnd(M, N, seed=5)), bf(rnd(M, N, seed=6))
+    W = H.TiledW(dev_bf(w)) if tiled else dev_bf(w)
+    kw = dict(M=M, N=N, K=K, C1=K, bias=dev_f(b), rowvec=dev_f(rv)[:, N // 2:], rowvec_ld=2 * N, rows_per_vec=100,
+              alpha=0.75, res1=dev_bf(r1), ldr1=N, beta1=0.5, res2=dev_bf(r2), ldr2=N, beta2=-0.25)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), W, out, splitk=sk, **kw)
+    rows = torch.arange(M) // 100
+    ref = 0.75 * (a @ w.t() + b + rv[rows][:, N // 2:N // 2 + N]) + 0.5 * r1 - 0.25 * r2
+    check(out, ref, what=f"split-K {sk} dense, all epilogue terms, tiled={tiled}")
+    one = torch.empty_like(out)
+    hip.gemm(dev_bf(a), W, one, **kw)
+    check(out, one.float(), max_tol=1.2e-2, rms_tol=3e-3, what="split-K vs single pass")   # two independent bf16 roundings
+    again = torch.empty_like(out)
+    hip.gemm(dev_bf(a), W, again, splitk=sk, **kw)
+    assert torch.equal(out, again), "split-K must be deterministic (slabs are added in range order)"
+    f32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    hip.gemm(dev_bf(a), W, f32, M=M, N=N, K=K, C1=K, bias=dev_f(b), epilogue=H.EPI_OUT_F32 | H.EPI_SILU, splitk=sk)
+    check(f32, F.silu(a @ w.t() + b), max_tol=1e-4, rms_tol=1e-5, what="split-K fp32 + SiLU")
+
+
+@pytest.mark.parametrize("sk,c,c2,c3", [(2, 128, 64, 64), (3, 64, 64, 128), (2, 64, 384, 320), (4, 256, 0, 0)])
+def test_gemm_splitk_conv3x3_with_shortcut_segment(hip, sk, c, c2, c3):
+    """K ranges that start at a tap, in the middle of a tap (c = 256: 4.5 taps per range) and INSIDE the fused-shortcut
+    segment (c = 64 with a 704-channel concat: the second range starts one K tile into the segment)."""
+    from wiw_amd import hip as H
+
+    n, h, w, cout = 3, 12, 16, 320
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+    b = rnd(cout, seed=6)
+    M = n * h * w
+    out = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    if c2:
+        s1, s2 = bf(rnd(n, c2, h, w, seed=2)), bf(rnd(n, c3, h, w, seed=3))
+        wsc = bf(rnd(cout, c2 + c3, 1, 1, seed=5) / math.sqrt(c2 + c3))
+        wk = dev_bf(torch.cat([wt.permute(0, 2, 3, 1).reshape(cout, -1), wsc[:, :, 0, 0]], dim=1))
+        hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=cout, K=9 * c + c2 + c3, C1=c, mode=H.A_CONV3X3, H=h, Wd=w,
+                 A2=dev_bf(nhwc(s1)), C2=c2, A3=dev_bf(nhwc(s2)), C3=c3, bias=dev_f(b), splitk=sk)
+        ref = F.conv2d(x, wt, b, padding=1) + F.conv2d(torch.cat([s1, s2], dim=1), wsc)
+    else:
+        wk = dev_bf(wt.permute(0, 2, 3, 1).reshape(cout, -1))
+        K = 9 * c
+        hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=cout, K=K, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b), splitk=sk)
+        ref = F.conv2d(x, wt, b, padding=1)
+    check(from_nhwc(out, n, h, w), ref, what=f"split-K {sk} conv3x3 {c}|{c2}+{c3}")
+
+
+def test_gemm_splitk_conv_temporal_and_validation(hip):
+    from wiw_amd import hip as H
+
+    B, T, c, h, w = 2, 6, 128, 4, 8
+    x = bf(rnd(B, c, T, h, w, seed=1))
+    wt = bf(rnd(c, c, 3, 1, 1, seed=2) / math.sqrt(3 * c))
+    b = rnd(c, seed=3)
+    tok = x.permute(0, 2, 3, 4, 1).reshape(-1, c)
+    M = tok.shape[0]
+    out = torch.empty(M, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(tok), dev_bf(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, -1)), out, M=M, N=c, K=3 * c, C1=c,
+             mode=H.A_CONV_T3, H=h, Wd=w, T=T, bias=dev_f(b), splitk=2)
+    ref = F.conv3d(x, wt, b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c)
+    check(out, ref, what="split-K 2 temporal conv")
+    with pytest.raises(RuntimeError, match="divisible"):
+        hip.gemm(dev_bf(tok), dev_bf(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, -1)), out, M=M, N=c, K=3 * c, C1=c,
+                 mode=H.A_CONV_T3, H=h, Wd=w, T=T, splitk=4)
+
+
+def test_gemm_splitk_on_the_256x320_tile(hip):
+    """Shapes whose K ranges the launcher puts on gemm_huge.hip (N % 320 == 0, >= 10 K tiles per range, >= 200 items):
+    dense with every epilogue term, and a conv3x3 + fused shortcut whose ranges start in the middle of a tap."""
+    from wiw_amd import hip as H
+
+    M, N, K, sk = 6400, 640, 2560, 4
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2) / math.sqrt(K))
+    b, r1 = rnd(N, seed=3), bf(rnd(M, N, seed=5))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(a), H.TiledW(dev_bf(w)), out, M=M, N=N, K=K, C1=K, bias=dev_f(b), alpha=0.5, res1=dev_bf(r1), ldr1=N,
+             beta1=1.0, splitk=sk)
+    check(out, 0.5 * (a @ w.t() + b) + r1, what="split-K 4 dense on the 256x320 tile")
+
+    n, h, w_, c, c2, c3, cout, sk = 4, 40, 56, 256, 128, 64, 640, 3
+    x = bf(rnd(n, c, h, w_, seed=1))
+    s1, s2 = bf(rnd(n, c2, h, w_, seed=2)), bf(rnd(n, c3, h, w_, seed=3))
+    wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+    wsc = bf(rnd(cout, c2 + c3, 1, 1, seed=5) / math.sqrt(c2 + c3))
+    bb = rnd(cout, seed=6)
+    wk = H.TiledW(dev_bf(torch.cat([wt.permute(0, 2, 3, 1).reshape(cout, -1), wsc[:, :, 0, 0]], dim=1)))
+    M = n * h * w_
+    out = torch.full((M, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=M, N=cout, K=9 * c + c2 + c3, C1=c, mode=H.A_CONV3X3, H=h, Wd=w_,
+             A2=dev_bf(nhwc(s1)), C2=c2, A3=dev_bf(nhwc(s2)), C3=c3, bias=dev_f(bb), splitk=sk)
+    ref = F.conv2d(x, wt, bb, padding=1) + F.conv2d(torch.cat([s1, s2], dim=1), wsc)
+    check(from_nhwc(out, n, h, w_), ref, what="split-K 3 conv3x3 + shortcut on the 256x320 tile")

@@ -3,6 +3,7 @@
 the kernel and to attach rocprofv3 PMC counters to ONE shape.
 
     python tools/gemm_probe.py M,N,K[,mode[,epi]] ...      e.g.  258048,2560,320,0,1   (GEGLU)
+env: ITERS, TILED=1 (hip.TiledW weights), RES=1 (residual operand), SPLITK=n (WiwGemmArgs.splitk)
 mode: 0 dense 1 conv3x3 2 s2 3 up 4 temporal (conv shapes use H=72,W=128-like factorisation of M)
 """
 import math
@@ -34,7 +35,7 @@ def main():
         if os.environ.get("TILED"):
             W = H.TiledW(W)
         bias = torch.randn(N, device=dev)
-        kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi)
+        kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi, splitk=int(os.environ.get("SPLITK", "1")))
         if mode:
             frames = 28 if M % 28 == 0 else 1
             hw = M // frames

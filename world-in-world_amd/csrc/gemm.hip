@@ -108,7 +108,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     // equal work per K tile — and 4 MiB of L2 absorbs several K tiles of skew).  Block b is assumed to run on XCD
     // b % 8 (observed dispatch order; a different placement changes speed only).
     const int Nt = (p.N + BN - 1) / BN;
-    const int Mt = (p.M + BM - 1) / BM;
+    // split-K (p.splitk = S > 1): the S K-ranges of an output tile are scheduled as S extra tile rows; range ks of tile
+    // row tr is schedule row ks * Mt1 + tr and writes raw fp32 sums to slab ks of the workspace (reduced, with the
+    // whole epilogue, by splitk_reduce_kernel).  Used where M alone cannot fill the chip (M = 4032 at the 1280 level).
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const int Mt1 = (p.M + BM - 1) / BM;
+    const int Mt = Mt1 * S;
     const int total = Mt * Nt;
     const int nb = gridDim.x;
     const bool super = (nb & 7) == 0 && nb >= 64;      // otherwise: small grid, contiguous ranges
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     const char* const zeros = (const char*)p.zeros;
     const int HW = p.H * p.Wd;
     const int Ctot = MODE == WIW_A_DENSE ? p.C1 + p.C2 : p.C1;   // channels per tap (the shortcut segment is tap 9)
-    const int nk = p.K / BK;
+    const int nk = p.K / BK / S;       // K tiles per output tile (of one split range)
+    const int nk_w = p.K / BK;         // K tiles per 8-row block of a tiled W
 
     int a_m[4];
     bool a_ok[4];
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
     auto setup_loader = [&](int tile) {
-        const int m0 = (tile / Nt) * BM, n0 = (tile % Nt) * BN;
+        const int m0 = ((tile / Nt) % Mt1) * BM, n0 = (tile % Nt) * BN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + (wave * 4 + i) * 8 + rsub;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             if (w_tiled) {
                 int blk = (n0 >> 3) + wave * B_FULL + i;
                 blk = blk < w_last ? blk : w_last;
-                w_row[i] = (const char*)p.W + (int64_t)blk * nk * 1024 + lane * 16;
+                w_row[i] = (const char*)p.W + (int64_t)blk * nk_w * 1024 + lane * 16;
             } else {
                 int n = n0 + (wave * B_FULL + i) * 8 + rsub;
                 n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
@@ -211,13 +217,25 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         if (w_tiled) {   // NW = 8: rows 128..159 = blocks 16..19, half a block (4 rows = 512 contiguous bytes) per wave
             int blk = (n0 >> 3) + B_FULL * NW + (wave >> 1);
             blk = blk < w_last ? blk : w_last;
-            w_row[B_FULL] = (const char*)p.W + (int64_t)blk * nk * 1024 + (wave & 1) * 512 + (lane & 31) * 16;
+            w_row[B_FULL] = (const char*)p.W + (int64_t)blk * nk_w * 1024 + (wave & 1) * 512 + (lane & 31) * 16;
         } else {   // NW = 8: rows 128..159 of the W tile are fetched 4 rows per wave by lanes 0..31
             const int r_h = B_FULL * NW * 8 + wave * 4 + (rsub & 3);   // r_h & 7 != rsub for odd waves
             const int chunk_h = (lane & 7) ^ (r_h & 7);
             int n = n0 + r_h;
             n = n < p.N ? n : p.N - 1;
             w_row[B_FULL] = (const char*)p.W + ((int64_t)n * p.K + chunk_h * 8) * 2;
+        }
+    };
+
+    // K position of the loader at the start of `tile`: K tile ks * nk of its split range
+    auto reset_loader = [&](int tile) {
+        ld_kt = S > 1 ? ((tile / Nt) / Mt1) * nk : 0;
+        const int k0 = ld_kt * BK;
+        if (MODE == WIW_A_DENSE) { ld_tap = 0; ld_cc = k0; }
+        else {
+            int tp = k0 / Ctot;
+            if (MODE == WIW_A_CONV3X3 && tp > 9) tp = 9;     // inside the fused-shortcut segment (longer than one tap)
+            ld_tap = tp; ld_cc = k0 - tp * Ctot;
         }
     };
 
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 
     // ---- prologue: first D K tiles of the first output tile
     setup_loader(t);
-    ld_tap = 0; ld_cc = 0; ld_kt = 0;
+    reset_loader(t);
     int st_c = 0;   // ring stage holding the K tile the MFMAs consume next
     int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 6 / 12)
 #ifdef WIW_TRACE
@@ -379,7 +397,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         const bool trace_on = blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && tiles_done == 1;
 #endif
         const int tile_n = t % Nt;
-        const int m0 = (t / Nt) * BM, n0 = tile_n * BN;
+        const int m0 = ((t / Nt) % Mt1) * BM, n0 = tile_n * BN;
+        const int64_t out_slab = S > 1 ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;   // fp32 workspace slab of this K range
         setup_loader(t);   // recomputed (not kept live across the previous epilogue: VGPR budget); counters ld_* persist
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         const int t_next = next_tile(q_next);
         if (t_next >= 0) {
             setup_loader(t_next);
-            ld_tap = 0; ld_cc = 0; ld_kt = 0;
+            reset_loader(t_next);
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 if (j < nk) {
@@ -718,7 +737,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                             }
                         }
                         if (ok) {
-                            if (out_f32) ((float*)p.out)[(int64_t)m * p.ldo + n] = y;
+                            if (out_f32) ((float*)p.out)[out_slab + (int64_t)m * p.ldo + n] = y;
                             else ((uint16_t*)p.out)[(int64_t)m * p.ldo + n] = f2bf(y);
                         }
                     }
@@ -731,6 +750,49 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         WIW_TP(2 + 8 * nk);      // end of the epilogue
         ++tiles_done;
 #endif
+    }
+}
+
+// split-K second pass: out = epilogue(sum over the S fp32 slabs, in slab order — deterministic), 8 columns per thread.
+// Same arithmetic as the direct epilogue path: ((sum + bias + rowvec) * alpha [SiLU]) + beta1 res1 + beta2 res2.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const WiwGemmArgs p) {
+    const int nch = p.N >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.M * nch) return;
+    const int64_t m = i / nch;
+    const int n = (int)(i - m * nch) * 8;
+    const float* ws = (const float*)p.workspace + m * p.N + n;
+    const int64_t slab = (int64_t)p.M * p.N;
+    float v[8];
+    {
+        const float4 a = *(const float4*)ws, b = *(const float4*)(ws + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    for (int s = 1; s < p.splitk; ++s) {
+        const float4 a = *(const float4*)(ws + s * slab), b = *(const float4*)(ws + s * slab + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    const float* rv = p.rowvec ? p.rowvec + (m / p.rows_per_vec) * p.rowvec_ld + n : nullptr;
+    const uint16_t* r1 = p.res1 ? (const uint16_t*)p.res1 + m * p.ldr1 + n : nullptr;
+    const uint16_t* r2 = p.res2 ? (const uint16_t*)p.res2 + m * p.ldr2 + n : nullptr;
+    const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float y = v[e];
+        if (p.bias) y += p.bias[n + e];
+        if (rv) y += rv[e];
+        y *= p.alpha;
+        if (do_silu) y = silu_f(y);
+        if (r1) y += p.beta1 * bf2f(r1[e]);
+        if (r2) y += p.beta2 * bf2f(r2[e]);
+        v[e] = y;
+    }
+    if (p.epilogue & WIW_EPI_OUT_F32) {
+        float* o = (float*)p.out + m * p.ldo + n;
+        *(float4*)o = float4{v[0], v[1], v[2], v[3]};
+        *(float4*)(o + 4) = float4{v[4], v[5], v[6], v[7]};
+    } else {
+        *(uint4*)((uint16_t*)p.out + m * p.ldo + n) = pack8(v);
     }
 }
 
@@ -753,7 +815,7 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
         wiw_set_error("hipFuncSetAttribute(gemm) failed");
         return WIW_ELAUNCH;
     }
-    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * (a.splitk > 1 ? a.splitk : 1);
     int64_t grid = (int64_t)num_cu * blocks_per_cu;   // persistent: every CU slot gets one block
     if (tiles < grid) grid = tiles >= 64 ? (tiles / 8) * 8 : tiles;   // keep the per-XCD super-tile schedule usable
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
@@ -772,6 +834,23 @@ inline bool use_big_tile(const WiwGemmArgs& a) {
 
 template <int MODE>
 int launch(hipStream_t s, const WiwGemmArgs& a) {
+    if (a.splitk > 1) {   // pass 1: raw fp32 partial sums of every K range on the 256x160 tile; pass 2: reduce + epilogue
+        WiwGemmArgs g = a;
+        g.out = a.workspace; g.ldo = a.N;
+        g.bias = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.res2 = nullptr;
+        g.alpha = 1.0f; g.epilogue = WIW_EPI_OUT_F32 | (a.epilogue & WIW_W_TILED);
+        // tile: 256 x 320 when N fills it, every K range keeps >= 10 K tiles and the ranges give (nearly) every CU an
+        // item; else 256 x 160.   WIW_GEMM_TILE=huge|big overrides (A/B).
+        static const char* force_sk = getenv("WIW_GEMM_TILE");
+        const int64_t tiles_h = (int64_t)((a.M + 255) / 256) * ((a.N + 319) / 320) * a.splitk;
+        bool huge = a.N % 320 == 0 && a.K / a.splitk >= 640 && tiles_h >= 200;
+        if (force_sk) huge = force_sk[0] == 'h' && a.N % 320 == 0;
+        const int rc = huge ? wiw_gemm_huge_launch(s, g) : launch_cfg<MODE, 8, 3, false>(s, g, 1);
+        if (rc != WIW_OK) return rc;
+        const int64_t n_thr = (int64_t)a.M * (a.N >> 3);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, s, a);
+        return wiw_check_launch("wiw_gemm_bf16 (split-K reduce)");
+    }
     static const char* force = getenv("WIW_GEMM_TILE");   // tuning knob: "huge" / "big" / "small" overrides the heuristic
     if ((!force || force[0] == 'h') && wiw_gemm_huge_ok(a)) return wiw_gemm_huge_launch(s, a);   // gemm_huge.hip
     const bool big = force ? (force[0] != 's') : use_big_tile(a);
@@ -816,6 +895,13 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
         WIW_REQUIRE(a.rowvec == nullptr && a.res1 == nullptr && a.res2 == nullptr, "gemm: GEGLU takes bias only");
         WIW_REQUIRE((((uintptr_t)a.bias) & 15) == 0, "gemm: GEGLU bias must be 16-byte aligned");
         WIW_REQUIRE(a.mode == WIW_A_DENSE, "gemm: GEGLU only in dense mode");
+    }
+    if (a.splitk > 1) {
+        WIW_REQUIRE(a.workspace != nullptr, "gemm: split-K needs a workspace of splitk * M * N floats");
+        WIW_REQUIRE((a.K / 64) % a.splitk == 0, "gemm: split-K needs K / 64 divisible by splitk");
+        WIW_REQUIRE(!(a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)), "gemm: split-K does not take GEGLU / GELU epilogues");
+        WIW_REQUIRE(a.N % 8 == 0 && a.ldo % 8 == 0 && (a.res1 == nullptr || a.ldr1 % 8 == 0) && (a.res2 == nullptr || a.ldr2 % 8 == 0),
+                    "gemm: split-K needs N, ldo, ldr1, ldr2 multiples of 8");
     }
     hipStream_t s = (hipStream_t)stream;
     switch (a.mode) {

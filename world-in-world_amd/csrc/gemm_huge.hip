@@ -70,7 +70,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 
     // ---- tile schedule: per-XCD sm x sn super-tiles (identical to gemm.hip, with this tile shape)
     const int Nt = (p.N + HN - 1) / HN;
-    const int Mt = (p.M + HM - 1) / HM;
+    // split-K (p.splitk = S > 1), as in gemm.hip: K range ks of tile row tr is schedule row ks * Mt1 + tr and writes raw
+    // fp32 sums to slab ks of the workspace (p.out here)
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const int Mt1 = (p.M + HM - 1) / HM;
+    const int Mt = Mt1 * S;
     const int total = Mt * Nt;
     const int nb = gridDim.x;
     const bool super = (nb & 7) == 0 && nb >= 64;
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const char* const zeros = (const char*)p.zeros;
     const int HW = p.H * p.Wd;
     const int Ctot = MODE == WIW_A_DENSE ? p.C1 + p.C2 : p.C1;   // channels per tap (the shortcut segment is tap 9)
-    const int nk = p.K / HK;
+    const int nk = p.K / HK / S;       // K tiles per output tile (of one split range)
+    const int nk_w = p.K / HK;         // K tiles per 8-row block of a tiled W
 
     int a_m[4];
     bool a_ok[4];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
     auto setup_loader = [&](int tile) {
-        const int m0 = (tile / Nt) * HM, n0 = (tile % Nt) * HN;
+        const int m0 = ((tile / Nt) % Mt1) * HM, n0 = (tile % Nt) * HN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + (wave * 4 + i) * 8 + rsub;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 int blk = (n0 >> 3) + wave * 5 + i;
                 const int last = ((p.N + 7) >> 3) - 1;
                 blk = blk < last ? blk : last;       // blocks past N re-read the last one (computed, never stored)
-                w_row[i] = (const char*)p.W + (int64_t)blk * nk * 1024 + lane * 16;
+                w_row[i] = (const char*)p.W + (int64_t)blk * nk_w * 1024 + lane * 16;
             } else {
                 int n = n0 + (wave * 5 + i) * 8 + rsub;
                 n = n < p.N ? n : p.N - 1;   // clamped rows are computed but never stored
@@ -266,15 +271,28 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
 
+    auto reset_loader = [&](int tile) {   // K position of the loader at the start of `tile` (its split range)
+        ld_kt = S > 1 ? ((tile / Nt) / Mt1) * nk : 0;
+        const int k0 = ld_kt * HK;
+        if (MODE == WIW_A_DENSE) { ld_tap = 0; ld_cc = k0; }
+        else {
+            int tp = k0 / Ctot;
+            if (MODE == WIW_A_CONV3X3 && tp > 9) tp = 9;
+            ld_tap = tp; ld_cc = k0 - tp * Ctot;
+        }
+    };
+
     // ---- prologue: K tile 0 of the first output tile
     setup_loader(t);
+    reset_loader(t);
     int st_c = 0;
     int pending_stores = 0;   // 0 / 12 (GEGLU) / 24
     issue_all(0);
 
     while (t >= 0) {
         const int tile_n = t % Nt;
-        const int m0 = (t / Nt) * HM;
+        const int m0 = ((t / Nt) % Mt1) * HM;
+        const int64_t out_slab = S > 1 ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;
         setup_loader(t);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -394,13 +412,32 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         const int t_next = next_tile(q_next);
         if (t_next >= 0) {
             setup_loader(t_next);
-            ld_tap = 0; ld_cc = 0; ld_kt = 0;
+            reset_loader(t_next);
             issue_all(st_c);            // stage st_c is free (it held K tile nk-2); staging uses the other one
         }
         pending_stores = 0;
 
         // ---- epilogue, part 2 (per wave, no block barrier)
-        {
+        if (S > 1) {
+            // split-K: raw fp32 partial sums straight from the fragment layout (a lane holds 4 consecutive columns of
+            // one row: 16-byte stores, 64-byte runs per row) into this K range's slab; bias / residual / rounding happen
+            // in splitk_reduce_kernel.  The stores are conditional, so the next tile waits with vmcnt(0).
+            float* const ws = (float*)p.out + out_slab;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = mw0 + mi * 16 + frow;
+#pragma unroll
+                for (int ni = 0; ni < 10; ++ni) {
+                    const int n = tile_nw * 160 + ni * 16 + fq * 4;
+                    if (m < p.M && n < p.N) {
+                        float* d = ws + (int64_t)m * p.ldo + n;
+                        const f32x4 v = acc[mi][ni];
+                        __builtin_nontemporal_store(v[0], d); __builtin_nontemporal_store(v[1], d + 1);
+                        __builtin_nontemporal_store(v[2], d + 2); __builtin_nontemporal_store(v[3], d + 3);
+                    }
+                }
+            }
+        } else {
             char* stg = smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE;
             uint4* dump = g_dump_h + (blockIdx.x & 511) * 64 + lane;
             auto pass = [&](auto mi_tag) {
@@ -510,7 +547,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
         wiw_set_error("hipFuncSetAttribute(gemm_huge) failed");
         return WIW_ELAUNCH;
     }
-    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
+    const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN) * (a.splitk > 1 ? a.splitk : 1);
     int64_t grid = num_cu;
     if (tiles < grid) grid = tiles;   // one tile per block (a grid that is not a multiple of 8 uses contiguous ranges)
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");

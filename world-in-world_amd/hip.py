@@ -72,7 +72,7 @@ class WiwGemmArgs(C.Structure):
         ("ldo", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32), ("n_out", C.c_int32),
         ("rowvec_ld", C.c_int32), ("rows_per_vec", C.c_int32),
         ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-        ("epilogue", C.c_int32),
+        ("epilogue", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p),
     ]
 
 
@@ -142,7 +142,7 @@ class Hip:
 
     def __init__(self, device: torch.device):
         self.lib = load_library()
-        if self.lib.wiw_abi_version() != 3:
+        if self.lib.wiw_abi_version() != 4:
             raise RuntimeError("libwiwsvd.so ABI version mismatch")
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -159,6 +159,7 @@ class Hip:
         # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
+        self._splitk_ws = None
         # ... and this one for the non-GEMM kernels: (start_event, end_event, family, algorithmic_flops, algorithmic_bytes)
         self.kernel_profile = None
 
@@ -189,7 +190,7 @@ class Hip:
     # ---- operators
     def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, A3=None, C3=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
              rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,
-             ldo=None, epilogue=0, n_out=0):
+             ldo=None, epilogue=0, n_out=0, splitk=1):
         a = WiwGemmArgs()
         a.A, a.A2, a.W, a.out = _p(A), _p(A2), _p(W), _p(out)
         a.bias, a.rowvec, a.res1, a.res2 = _p(bias), _p(rowvec), _p(res1), _p(res2)
@@ -202,6 +203,11 @@ class Hip:
         a.rowvec_ld, a.rows_per_vec = rowvec_ld, rows_per_vec
         a.alpha, a.beta1, a.beta2 = alpha, beta1, beta2
         a.epilogue = epilogue | (W_TILED if isinstance(W, TiledW) else 0)
+        if splitk > 1:   # fp32 partial sums of the K ranges: one grow-only scratch buffer per Hip (stream-ordered reuse)
+            need = splitk * M * N
+            if self._splitk_ws is None or self._splitk_ws.numel() < need:
+                self._splitk_ws = torch.empty(need, dtype=torch.float32, device=self.device)
+            a.splitk, a.workspace = splitk, self._splitk_ws.data_ptr()
         if self.gemm_profile is None:
             self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
             return out

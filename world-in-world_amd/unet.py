@@ -109,6 +109,7 @@ class UNetHIP:
         validate_state_dict(cfg, state_dict)
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
+        self.no_splitk = bool(os.environ.get("WIW_NO_SPLITK"))     # A/B knob
         self.swapped_vt = bool(os.environ.get("WIW_SWAPPED_VT"))   # A/B knob: V^T by a swapped-operand GEMM (round 1)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         self._prepare(state_dict)
@@ -263,6 +264,27 @@ class UNetHIP:
     def _empty(self, *shape, dtype=torch.bfloat16):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def _splitk(self, rows_per_item, N, K):
+        """Split-K factor of an implicit-GEMM conv.  At the innermost 1280-channel level one candidate has M = 4032 rows:
+        16 x 4 = 64 tiles of 256 x 320 for 256 CUs.  Cutting K into 4 ranges (256 items, fp32 partial slabs, a reduce
+        kernel that applies the epilogue) measured -17 % at K = 11 520 and -31 % at K = 23 040; at K <= 5120 (temporal
+        convs, FF down-projections) the slab traffic costs more than the idle CUs (+30...+45 %), so those stay whole.
+        The factor is decided from the rows of ONE candidate (2 CFG items), never from the batch in flight: a candidate is
+        evaluated with the same arithmetic alone and inside any batch (the bit-exact batch contract)."""
+        if self.no_splitk or N % 320 or K < 8192:
+            return 1
+        tiles, nk = -(-2 * rows_per_item // 256) * (N // 320), K // 64
+        if tiles > 100:
+            return 1
+        for sk in (4, 2, 3):
+            if nk % sk == 0 and tiles * sk >= 200:
+                return sk
+        return 1
+        for sk in (2, 3, 4):
+            if nk % sk == 0 and tiles * sk >= 224 and nk // sk >= 16:
+                return sk
+        return 1
+
     def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, **kw):
         W = self.w[p + ".weight"]
         N, K = W.shape
@@ -335,12 +357,12 @@ class UNetHIP:
         h = self._empty(M, Cout)
         hip.gemm(xn, w[s + ".conv1.weight"], h, M=M, N=Cout, K=9 * Cin, C1=Cin, mode=A_CONV3X3, H=H, Wd=W,
                  bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
-                 rows_per_vec=S)
+                 rows_per_vec=S, splitk=self._splitk(T * S, Cout, 9 * Cin))
         hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
         xs = self._empty(M, Cout)
         if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
             hip.gemm(hn, w[s + ".conv2sc.weight"], xs, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     A2=x1, C2=C1, A3=x2, C3=C2, bias=w[s + ".conv2sc.bias"])
+                     A2=x1, C2=C1, A3=x2, C3=C2, bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin))
         else:
             if s + ".conv_shortcut.weight" in w:   # unfused A/B path: separate 1x1 GEMM, then residual
                 sc = self._empty(M, Cout)
@@ -350,7 +372,7 @@ class UNetHIP:
                 assert x2 is None
                 sc = x1
             hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0)
+                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0, splitk=self._splitk(T * S, Cout, 9 * Cout))
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
         xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True, clip=True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
