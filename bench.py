@@ -10,9 +10,11 @@ CFG + Euler) over one batch of synthetic candidates at 576x1024x14 (BASELINE.jso
 resident in HBM when the timed region starts; weights are seeded random-init of the exact served
 architecture (no checkpoint offline).  value = denoised frames/s of the whole job = N * B * 14 * K / t.
 
-N > 1: one process per GPU (RCCL over xGMI); rank 0 owns the request of N*B candidates, broadcasts the
-conditioning tensors, every rank denoises its slice, latents are gathered on rank 0 (weak scaling:
-B candidates per GPU).  Both collectives are inside the timed region.
+N > 1: one process per GPU (RCCL over xGMI); rank 0 owns the request of N*B candidates, SCATTERS every rank's slice
+of the conditioning tensors, every rank denoises its slice, latents are GATHERED on rank 0 (weak scaling: B candidates
+per GPU — `--gpus 8 --batch 8` is BASELINE config 3, 64 candidates sharded 8 per GPU).  `--total-candidates C` fixes
+the request at C candidates whatever N is (strong scaling, reported as "scaling": "strong").  Both collectives are
+inside the timed region; there is no exchange inside the loop.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (HIP-event timing of every GEMM
 launch inside the timed region, on the launch stream) and "cpu_baseline" (the CPU oracle timed on the
@@ -73,7 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed rollouts (each = num-inference-steps Euler steps)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="candidates per GPU")
+    ap.add_argument("--batch", type=int, default=1, help="candidates per GPU (weak scaling)")
+    ap.add_argument("--total-candidates", type=int, default=0,
+                    help="strong scaling: the request holds this many candidates in total, sharded over the N ranks")
     ap.add_argument("--num-inference-steps", type=int, default=25)
     ap.add_argument("--height", type=int, default=576)
     ap.add_argument("--width", type=int, default=1024)
@@ -123,6 +127,10 @@ def main():
 
     B = args.batch
     Btot = B * world
+    strong = args.total_candidates > 0
+    if strong:
+        Btot = args.total_candidates
+        B = -(-Btot // world)          # largest slice (rank 0's)
     g = torch.Generator(device="cpu").manual_seed(1234)
     req = None
     if rank == 0:
@@ -171,12 +179,12 @@ def main():
         res = {
             "metric": "denoised frames/sec (576x1024x14, 25 steps)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
-                                   f"CFG on, {B} candidate(s)/GPU, random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
+                                   f"CFG on, " + (f"{Btot} candidates in total" if strong else f"{B} candidate(s)/GPU") + ", random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}"},
         }
-        fwd_per_step = args.num_inference_steps * B
+        fwd_per_step = args.num_inference_steps * (Btot / world if strong else B)   # candidate-forwards per GPU
         algo = ALGO_TFLOP_PER_FORWARD * (h * w) / (72 * 128) * fwd_per_step  # linear in pixels & candidates
         if not args.tiny:
             # utilisation is quoted from FLOPs ISSUED to the matrix pipe (sum over the timed launches of 2*M*N*K per
