@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="per-launch HIP events are recorded on every n-th Euler step of the timed rollouts (every launch of "
+                         "those steps); n = 1 instruments every step and costs 3.4 %% of frames/s (21 k extra events / rollout)")
     ap.add_argument("--dump-shapes", type=str, default="", help="write per-(M,N,K) GEMM timings to this file")
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time whole requests (uint8 panorama in -> uint8 frames out: CLIP + VAE encode, denoise, VAE "
@@ -139,13 +142,32 @@ def main():
                    noise=torch.randn(Btot, T, 4, h, w, generator=torch.Generator().manual_seed(1)).to(device),
                    actions=synth_actions(Btot, T))
 
+    # Per-launch HIP events (on the launch stream) INSIDE the timed region, on a sample of its Euler steps: every step
+    # issues the same launches, so per-kernel averages from every n-th step are the rollout's; the other steps run
+    # without the event packets (two per launch: measured 3.4 % of frames/s when every step carries them).
+    ev = {"on": False, "gemm": [], "kern": [], "steps": 0}
+    every = max(1, args.event_every)
+
+    def arm(step_index):
+        on = ev["on"] and step_index % every == 0 and step_index < args.num_inference_steps
+        unet.hip.gemm_profile = ev["gemm"] if on else None
+        unet.hip.kernel_profile = ev["kern"] if on else None
+        ev["steps"] += int(on)
+
+    def after_step(i, _lat):
+        arm(i + 1)
+
     def rollout():
+        arm(0)
         if world == 1:
-            return den.denoise(req["image_latents"], req["image_embeddings"], req["noise"], req["actions"],
-                               num_steps=args.num_inference_steps)
-        r = req or dict(image_latents=None, image_embeddings=None, noise=None, actions=None)
-        return sharded_denoise(den.denoise, device, r["image_latents"], r["image_embeddings"], r["noise"], r["actions"],
-                               num_steps=args.num_inference_steps)
+            out_ = den.denoise(req["image_latents"], req["image_embeddings"], req["noise"], req["actions"],
+                               num_steps=args.num_inference_steps, callback=after_step)
+        else:
+            r = req or dict(image_latents=None, image_embeddings=None, noise=None, actions=None)
+            out_ = sharded_denoise(den.denoise, device, r["image_latents"], r["image_embeddings"], r["noise"], r["actions"],
+                                   num_steps=args.num_inference_steps, callback=after_step)
+        arm(args.num_inference_steps)     # off
+        return out_
 
     def barrier():
         if world > 1:
@@ -154,9 +176,7 @@ def main():
 
     for _ in range(args.warmup):
         rollout()
-    if not args.no_kernel_events:
-        unet.hip.gemm_profile = []
-        unet.hip.kernel_profile = []
+    ev["on"] = not args.no_kernel_events
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -168,10 +188,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
-    prof = unet.hip.gemm_profile
-    kprof = unet.hip.kernel_profile
+    prof, kprof = ev["gemm"], ev["kern"]
     unet.hip.gemm_profile = None
     unet.hip.kernel_profile = None
+    # fraction of the timed Euler steps that carried events: per-family seconds / FLOPs below are scaled by 1 / ev_frac
+    ev_frac = ev["steps"] / float(args.num_inference_steps * args.steps) if ev["steps"] else 0.0
     if rank == 0:
         assert out is not None and torch.isfinite(out).all(), "non-finite latents"
         frames = Btot * T * args.steps
@@ -195,8 +216,11 @@ def main():
             issued = (ALGO_TFLOP_PER_FORWARD - ELIDED_TFLOP_PER_FORWARD) * (h * w) / (72 * 128) * fwd_per_step * args.steps
             src = "reference graph minus elided cross-attention (no per-launch events)"
             if prof:
-                issued = (sum(e[2] for e in prof) + sum(e[3] for e in (kprof or []))) / 1e12
+                issued = (sum(e[2] for e in prof) + sum(e[3] for e in (kprof or []))) / 1e12 / ev_frac
                 src = "sum of per-launch algorithmic FLOPs of the timed region (GEMM/conv launches + attention kernels)"
+                res["kernel_events"] = (f"HIP events around every launch of every {every}-th Euler step of the timed rollouts "
+                                        f"({ev['steps']} of {args.num_inference_steps * args.steps} steps); seconds / launches "
+                                        "below are of those steps, shares are relative to their part of the timed region")
             res["issued_tflop_per_step"] = round(issued / args.steps, 1)
             res["mfma_util"] = round(issued / dt / PEAK_BF16_TFLOPS, 4)
             res["mfma_util_source"] = src
@@ -219,7 +243,7 @@ def main():
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
-                               "share_of_timed_region": round(tsec / dt, 3)}
+                               "share_of_timed_region": round(tsec / (dt * ev_frac), 3)}
             res["gemm_kernels"] = {MODE_NAMES[m]: {"launches": v[2], "seconds": round(v[0], 4),
                                                    "tflops": round(v[1] / v[0] / 1e12, 1)} for m, v in sorted(by_mode.items())}
             # the dense family mixes regimes: the K <= 320 launches (C = 320 level) sit below the machine
@@ -249,7 +273,7 @@ def main():
                     d[2] += nb_
                     d[3] += 1
                 res["other_kernels"] = {
-                    k: dict(launches=v[3], seconds=round(v[0], 4), share_of_timed_region=round(v[0] / dt, 4),
+                    k: dict(launches=v[3], seconds=round(v[0], 4), share_of_timed_region=round(v[0] / (dt * ev_frac), 4),
                             **({"tflops": round(v[1] / v[0] / 1e12, 1)} if v[1] > 0 else {}),
                             algorithmic_GBps=round(v[2] / v[0] / 1e9, 1))
                     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
@@ -318,7 +342,7 @@ def pmc_traffic(mode: int):
     import csv
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_*.csv")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_1step.csv")))
     if not files:
         return None, None
     tot = n = 0.0

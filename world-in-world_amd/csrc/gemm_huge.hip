@@ -59,7 +59,10 @@ WIW_DEV void wave_lds_sync() {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
-template <int MODE, bool GE>
+// SK: split-K instantiation (raw fp32 slabs, no staged epilogue).  A separate template parameter because this kernel
+// lives at the 256-VGPR limit: with the split path compiled into the common instantiation its spills doubled
+// (80 -> 163 VGPRs) and every K >= 640 launch lost ~15 %.
+template <int MODE, bool GE, bool SK>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const int Nt = (p.N + HN - 1) / HN;
     // split-K (p.splitk = S > 1), as in gemm.hip: K range ks of tile row tr is schedule row ks * Mt1 + tr and writes raw
     // fp32 sums to slab ks of the workspace (p.out here)
-    const int S = p.splitk > 1 ? p.splitk : 1;
+    const int S = SK ? p.splitk : 1;
     const int Mt1 = (p.M + HM - 1) / HM;
     const int Mt = Mt1 * S;
     const int total = Mt * Nt;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
 
     auto setup_loader = [&](int tile) {
-        const int m0 = ((tile / Nt) % Mt1) * HM, n0 = (tile % Nt) * HN;
+        const int m0 = (SK ? (tile / Nt) % Mt1 : tile / Nt) * HM, n0 = (tile % Nt) * HN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + (wave * 4 + i) * 8 + rsub;
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const uint16_t* r2 = (const uint16_t*)p.res2;
 
     auto reset_loader = [&](int tile) {   // K position of the loader at the start of `tile` (its split range)
-        ld_kt = S > 1 ? ((tile / Nt) / Mt1) * nk : 0;
+        ld_kt = SK ? ((tile / Nt) / Mt1) * nk : 0;
         const int k0 = ld_kt * HK;
         if (MODE == WIW_A_DENSE) { ld_tap = 0; ld_cc = k0; }
         else {
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 
     while (t >= 0) {
         const int tile_n = t % Nt;
-        const int m0 = ((t / Nt) % Mt1) * HM;
-        const int64_t out_slab = S > 1 ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;
+        const int m0 = (SK ? (t / Nt) % Mt1 : t / Nt) * HM;
+        const int64_t out_slab = SK ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;
         setup_loader(t);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         pending_stores = 0;
 
         // ---- epilogue, part 2 (per wave, no block barrier)
-        if (S > 1) {
+        if (SK) {
             // split-K: raw fp32 partial sums straight from the fragment layout (a lane holds 4 consecutive columns of
             // one row: 16-byte stores, 64-byte runs per row) into this K range's slab; bias / residual / rounding happen
             // in splitk_reduce_kernel.  The stores are conditional, so the next tile waits with vmcnt(0).
@@ -530,14 +533,14 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 }
 
-template <int MODE, bool GE>
+template <int MODE, bool GE, bool SK>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
     static std::once_flag once;
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -552,7 +555,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     if (tiles < grid) grid = tiles;   // one tile per block (a grid that is not a multiple of 8 uses contiguous ranges)
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     const int stagger = stg_env ? atoi(stg_env) : 0;
-    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }
 
@@ -580,12 +583,22 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
 
 int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
+    if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)
+        switch (a.mode) {
+            case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, true>(s, a);
+            case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, true>(s, a);
+            case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, true>(s, a);
+            case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, true>(s, a);
+            case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, true>(s, a);
+            default: return launch_huge<WIW_A_CONV_T3, false, true>(s, a);
+        }
+    }
     switch (a.mode) {
-        case WIW_A_DENSE: return ge ? launch_huge<WIW_A_DENSE, true>(s, a) : launch_huge<WIW_A_DENSE, false>(s, a);
-        case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false>(s, a);
-        case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false>(s, a);
-        case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false>(s, a);
-        case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false>(s, a);
-        default: return launch_huge<WIW_A_CONV_T3, false>(s, a);
+        case WIW_A_DENSE: return ge ? launch_huge<WIW_A_DENSE, true, false>(s, a) : launch_huge<WIW_A_DENSE, false, false>(s, a);
+        case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false>(s, a);
+        case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false>(s, a);
+        case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false>(s, a);
+        case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, false>(s, a);
+        default: return launch_huge<WIW_A_CONV_T3, false, false>(s, a);
     }
 }
