@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--num-inference-steps", type=int, default=25)
     ap.add_argument("--height", type=int, default=576)
     ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit storage / MFMA operand type: bf16 (BASELINE's, libwiwsvd.so) or fp16 (the reference's "
+                         "served default, libwiwsvd_f16.so)")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -120,7 +123,7 @@ def main():
     T = cfg.num_frames
     h, w = args.height // 8, args.width // 8
     sd = random_state_dict_torch(cfg, 0, device, torch.float32)
-    unet = UNetHIP(cfg, sd, device)
+    unet = UNetHIP(cfg, sd, device, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16)
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
@@ -200,7 +203,7 @@ def main():
         res = {
             "metric": "denoised frames/sec (576x1024x14, 25 steps)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
                                    f"CFG on, " + (f"{Btot} candidates in total" if strong else f"{B} candidate(s)/GPU") + ", random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}"},

@@ -31,11 +31,18 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 4   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 5   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
-                             4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16 */
+                             4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
+                             5: wiw_dtype (the library exists in a bf16 and an fp16 build) */
 
 int wiw_abi_version(void);
+
+/* 16-bit storage type of THIS library: 0 = bfloat16 (libwiwsvd.so), 1 = IEEE half (libwiwsvd_f16.so, the same sources
+ * compiled with -DWIW_F16: the reference serves fp16 by default, FTsvd/eval_inference.py:294).  Every "bf16" in the
+ * entry-point names and comments below reads "the library's 16-bit type": tensors are 16-bit words of that type,
+ * accumulation / statistics / softmax are fp32 in both builds. */
+int wiw_dtype(void);
 const char* wiw_last_error(void);
 /* Returns WIW_OK when device `dev` is a gfx950 (MI355X) and fills optional name buffer. */
 int wiw_device_check(int dev, char* name, int name_len);

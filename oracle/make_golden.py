@@ -205,9 +205,18 @@ def gen_unet_full(ns):
         m = m.to(torch.bfloat16)
         out_bf16 = m(args[0].bfloat16(), args[1], args[2].bfloat16(), args[3].bfloat16(), return_dict=False,
                      added_action_ids=aid.bfloat16())[0]
+        # the same two yardsticks for fp16, the reference's served default dtype (eval_inference.py:294)
+        m = ref_unet(ns, cfg, seed=4)
+        for prm in m.parameters():
+            prm.data = prm.data.to(torch.float16).to(torch.float32)
+        out_w16 = m(*args, return_dict=False, added_action_ids=aid)[0]
+        m = m.to(torch.float16)
+        out_fp16 = m(args[0].half(), args[1], args[2].half(), args[3].half(), return_dict=False,
+                     added_action_ids=aid.half())[0]
     save("unet_full_16x32.npz", weight_seed=np.array(4), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
          added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(),
-         out_ref_bf16_weights_fp32_math=out_w.numpy(), out_ref_bf16=out_bf16.float().numpy())
+         out_ref_bf16_weights_fp32_math=out_w.numpy(), out_ref_bf16=out_bf16.float().numpy(),
+         out_ref_fp16_weights_fp32_math=out_w16.numpy(), out_ref_fp16=out_fp16.float().numpy())
 
 
 def gen_schema(ns):

@@ -88,9 +88,16 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
         unet_sd = load_safetensors(resolve_unet_weights(args.unet_path, args.svd_path))
         vae_sd = load_safetensors(_find_safetensors(os.path.join(args.svd_path, "vae")))
     torch.cuda.set_device(torch.device(args.device))   # the C ABI sizes its grids from the CURRENT device
-    unet = UNetHIP(cfg, unet_sd, args.device)
+    # 16-bit storage / MFMA operand type of UNet, VAE and CLIP: bf16 (BASELINE's dtype, the default here) or fp16 (the
+    # reference's own default, eval_inference.py:294) — libwiwsvd.so / libwiwsvd_f16.so.  fp32 is not a serving dtype of
+    # this path (the reference upcasts only the VAE encoder, pipeline:525-527).
+    names = {"bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "torch.bfloat16": torch.bfloat16,
+             "float16": torch.float16, "fp16": torch.float16, "half": torch.float16, "torch.float16": torch.float16}
+    if args.weight_dtype not in names:
+        raise SystemExit(f"--weight_dtype {args.weight_dtype!r}: the HIP path serves bfloat16 or float16")
+    dtype = names[args.weight_dtype]
+    unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype)
     den = SVDDenoiser(unet)
-    dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}[args.weight_dtype]
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)
     # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module.  There is no PyTorch / MIOpen VAE
     # route in the product (it needed > 6 minutes per decode on a fresh box); the fp32 PyTorch chain lives in oracle/.

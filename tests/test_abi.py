@@ -29,12 +29,18 @@ def test_header_and_binding_agree(lib_path):
     assert declared_symbols() == sorted(EXPORTS)
 
 
-def test_library_exports_every_declared_symbol(lib_path):
-    lib = ctypes.CDLL(lib_path)
+@pytest.mark.parametrize("variant,code", [("bf16", 0), ("fp16", 1)])
+def test_library_exports_every_declared_symbol(lib_path, variant, code):
+    """Both builds of the same sources (bf16: libwiwsvd.so, fp16: libwiwsvd_f16.so) export the whole header."""
+    from wiw_amd.build import LIB_F16
+
+    path = lib_path if variant == "bf16" else LIB_F16
+    lib = ctypes.CDLL(path)
     for name in declared_symbols():
-        assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported by {os.path.basename(path)}"
     lib.wiw_abi_version.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 4
+    lib.wiw_dtype.restype = ctypes.c_int
+    assert lib.wiw_abi_version() == 5 and lib.wiw_dtype() == code
 
 
 def test_gemm_args_struct_layout():

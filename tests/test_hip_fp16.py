@@ -1,0 +1,314 @@
+"""The fp16 build of the HIP path (libwiwsvd_f16.so: the same sources compiled with -DWIW_F16 — the reference's served
+default dtype, FTsvd/eval_inference.py:294; bf16 is BASELINE's).  GPU only.
+
+Tolerances.  fp16 keeps 11 significand bits against bf16's 8, so every gate here is 8x tighter than its bf16 twin in
+tests/test_hip_kernels.py / test_hip_served_width.py:
+  * kernels, on identical fp16-rounded inputs, fp32 reference: max <= 1.5e-3 max|ref|, rms <= 5e-4 (the final fp16
+    rounding is 2^-11 = 4.9e-4 relative, 2.8e-4 rms); attention (probabilities rounded to fp16 before P.V): 3e-3 / 1e-3;
+  * networks: the HIP path must be at least as close to the fp32 reference as the REFERENCE'S OWN fp16 run stored in the
+    fixture (full width: rms 1.50e-3, max 1.81e-3).  The fixture also holds the reference in fp32 arithmetic on
+    fp16-ROUNDED WEIGHTS: rms 7.3e-4 — with fp16 storage north_star's 1e-3 sits between the weight-rounding floor and the
+    reference's own fp16 run.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import svd_oracle as O
+import vae_oracle as VO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H16 = torch.float16
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)), float(
+        np.sqrt(((a - b) ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30))
+
+
+def h16(x):
+    return x.to(H16).float()
+
+
+def dev16(x):
+    return x.to(DEV, H16).contiguous()
+
+
+def dev_f(x):
+    return x.to(DEV, torch.float32).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def check(out, ref, max_tol=1.5e-3, rms_tol=5e-4, what=""):
+    assert tuple(out.shape) == tuple(ref.shape) and torch.isfinite(out.float()).all(), what
+    mx, rms = rel(out, ref)
+    print(f"[parity fp16] {what}: max_rel={mx:.3e} rms_rel={rms:.3e}")
+    assert mx <= max_tol and rms <= rms_tol, f"{what}: max_rel={mx:.3e} rms_rel={rms:.3e}"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+def from_nhwc(t, n, h, w):
+    return t.float().cpu().reshape(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    h = Hip(torch.device(DEV), H16)
+    assert h.lib.wiw_dtype() == 1
+    return h
+
+
+def test_dtype_mismatch_is_refused():
+    """One Hip serves one 16-bit type: loading the other build under it must fail loudly, not compute garbage."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd import hip as Hm
+
+    saved = Hm.LIB_PATH_F16
+    Hm.LIB_PATH_F16 = Hm.LIB_PATH        # the bf16 library where the fp16 one is expected
+    try:
+        with pytest.raises(RuntimeError, match="wiw_dtype"):
+            Hm.Hip(torch.device(DEV), H16)
+    finally:
+        Hm.LIB_PATH_F16 = saved
+
+
+# ----------------------------------------------------------------------------------------------
+# kernels
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,tiled", [(300, 320, 320, False), (4032, 1280, 1280, True), (16384, 640, 2560, True)])
+def test_gemm_dense_with_epilogue(hip, M, N, K, tiled):
+    from wiw_amd import hip as Hm
+
+    a, w = h16(rnd(M, K, seed=1)), h16(rnd(N, K, seed=2) / math.sqrt(K))
+    b, r1 = rnd(N, seed=3), h16(rnd(M, N, seed=4))
+    W = Hm.TiledW(dev16(w)) if tiled else dev16(w)
+    out = torch.full((M, N), float("nan"), dtype=H16, device=DEV)
+    hip.gemm(dev16(a), W, out, M=M, N=N, K=K, C1=K, bias=dev_f(b), alpha=0.5, res1=dev16(r1), ldr1=N, beta1=1.0)
+    # the staged epilogue rounds alpha * acc to 16 bits before the fp32 bias / residual math: two roundings
+    check(out, 0.5 * (a @ w.t() + b) + r1, max_tol=2e-3, rms_tol=6e-4, what=f"gemm {M}x{N}x{K} + bias + residual")
+
+
+def test_gemm_geglu_and_splitk(hip):
+    from wiw_amd import hip as Hm
+    from wiw_amd.unet import pack_geglu
+
+    M, Cn = 520, 320
+    a = h16(rnd(M, Cn, seed=1))
+    w, b = rnd(8 * Cn, Cn, seed=2) / math.sqrt(Cn), rnd(8 * Cn, seed=3) * 0.1
+    wp, bp, n_half = pack_geglu(w, b)
+    out = torch.empty(M, n_half, dtype=H16, device=DEV)
+    hip.gemm(dev16(a), dev16(wp), out, M=M, N=wp.shape[0], K=Cn, C1=Cn, bias=dev_f(bp), epilogue=Hm.EPI_GEGLU, n_out=n_half)
+    y = a @ h16(w).t() + b
+    check(out, y[:, :n_half] * F.gelu(y[:, n_half:]), what="gemm GEGLU C=320")
+    # split-K (fp32 slabs + reduce kernel) in the fp16 build
+    M, N, K = 1000, 320, 2048
+    a, w = h16(rnd(M, K, seed=5)), h16(rnd(N, K, seed=6) / math.sqrt(K))
+    out = torch.empty(M, N, dtype=H16, device=DEV)
+    hip.gemm(dev16(a), dev16(w), out, M=M, N=N, K=K, C1=K, splitk=4)
+    check(out, a @ w.t(), what="split-K 4")
+
+
+def test_conv_modes(hip):
+    from wiw_amd import hip as Hm
+
+    n, cin, cout, h, w = 2, 128, 320, 9, 16
+    x = h16(rnd(n, cin, h, w, seed=1))
+    wt = h16(rnd(cout, cin, 3, 3, seed=2) / math.sqrt(9 * cin))
+    b = rnd(cout, seed=3)
+    out = torch.empty(n * h * w, cout, dtype=H16, device=DEV)
+    hip.gemm(dev16(nhwc(x)), dev16(wt.permute(0, 2, 3, 1).reshape(cout, -1)), out, M=n * h * w, N=cout, K=9 * cin, C1=cin,
+             mode=Hm.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+    check(from_nhwc(out, n, h, w), F.conv2d(x, wt, b, padding=1), what="conv3x3")
+    B, T, c, h, w = 1, 14, 128, 3, 8
+    x = h16(rnd(B * T, c, h, w, seed=4))
+    wt = h16(rnd(c, c, 3, 1, 1, seed=5) / math.sqrt(3 * c))
+    out = torch.empty(B * T * h * w, c, dtype=H16, device=DEV)
+    hip.gemm(dev16(nhwc(x)), dev16(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, -1)), out, M=B * T * h * w, N=c, K=3 * c,
+             C1=c, mode=Hm.A_CONV_T3, H=h, Wd=w, T=T)
+    ref = F.conv3d(x.reshape(B, T, c, h, w).permute(0, 2, 1, 3, 4), wt, None, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4)
+    check(from_nhwc(out, B * T, h, w), ref.reshape(B * T, c, h, w), what="temporal conv")
+
+
+@pytest.mark.parametrize("frames,S,heads", [(2, 200, 5), (1, 1024, 1)])
+def test_attn_spatial(hip, frames, S, heads):
+    C = heads * 64
+    qkv = h16(rnd(frames * S, 3 * C, seed=21))
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = torch.empty(frames * S, C, dtype=H16, device=DEV)
+    hip.attn_spatial(dev16(torch.cat([q, k], dim=1)), 2 * C, C, dev16(v.t().contiguous()), frames * S, o, C, frames, S,
+                     heads, 0.125)
+
+    def hd(t):
+        return t.reshape(frames, S, heads, 64).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(hd(q), hd(k), hd(v)).transpose(1, 2).reshape(frames * S, C)
+    check(o, ref, max_tol=3e-3, rms_tol=1e-3, what=f"attn_spatial S={S} h={heads}")
+
+
+@pytest.mark.parametrize("B,T,S,heads", [(1, 14, 80, 5), (2, 3, 8, 2), (1, 14, 16, 20)])
+def test_temporal_attn_block(hip, B, T, S, heads):
+    from wiw_amd.unet import pack_temporal_qkv
+
+    C = heads * 64
+    x = h16(rnd(B, T, S, C, seed=1) * 1.5 + 0.3)
+    x[..., 5] += 4.0
+    wq, wk, wv = (rnd(C, C, seed=s) / math.sqrt(C) for s in (2, 3, 4))
+    gamma, beta = 1 + 0.2 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    wg, fold = pack_temporal_qkv(wq, wk, wv, gamma, beta, dtype=H16)
+    assert wg.dtype == H16
+    o = torch.full((B * T * S, C), float("nan"), dtype=H16, device=DEV)
+    hip.temporal_attn_block(dev16(x.reshape(-1, C)), wg.to(DEV), fold.to(DEV), o, C, B, T, S, heads, 1e-5, 0.125)
+    a = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    q, k, v = a @ wq.t(), a @ wk.t(), a @ wv.t()
+
+    def perm(t):
+        return t.permute(0, 2, 1, 3).reshape(B * S, T, heads, 64).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(perm(q), perm(k), perm(v)).transpose(1, 2).reshape(B, S, T, C).permute(0, 2, 1, 3)
+    # W * gamma, Q, K, V and P are each rounded to fp16 between the MFMA stages
+    check(o.float().cpu().reshape(B, T, S, C), ref, max_tol=4e-3, rms_tol=1.2e-3, what=f"temporal block T={T} S={S} h={heads}")
+
+
+def test_norms(hip):
+    n, c, h, w = 4, 320, 6, 8
+    x = h16(rnd(n, c, h, w, seed=1) * 2 + 0.5)
+    g, b = 1 + 0.3 * rnd(c, seed=2), 0.2 * rnd(c, seed=3)
+    out = hip.groupnorm(dev16(nhwc(x)), c, None, 0, n * h * w, h * w, dev_f(g), dev_f(b), 1e-5, True)
+    check(from_nhwc(out, n, h, w), F.silu(F.group_norm(x, 32, g, b, 1e-5)), what="groupnorm + SiLU")
+    rows, C = 777, 320
+    x = h16(rnd(rows, C, seed=4) * 1.5 + 0.2)
+    g, b = 1 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    out = hip.layernorm(dev16(x), rows, C, dev_f(g), dev_f(b), 1e-5)
+    check(out, F.layer_norm(x, (C,), g, b, 1e-5), what="layernorm")
+
+
+# ----------------------------------------------------------------------------------------------
+# networks
+# ----------------------------------------------------------------------------------------------
+def _run_unet(unet, g):
+    return unet(torch.from_numpy(g["sample"]), float(g["timestep"]), torch.from_numpy(g["ehs"]),
+                torch.from_numpy(g["added_time_ids"]), torch.from_numpy(g["action_ids"])).cpu().numpy()
+
+
+def test_unet_tiny_fp16(hip, golden):
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("unet_tiny_b1.npz")
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, int(g["weight_seed"])), DEV, hip=hip)
+    assert unet.dtype == H16
+    out = _run_unet(unet, g)
+    mx, rms = rel(out, g["out"])
+    mx_bf, rms_bf = rel(g["out_ref_bf16"], g["out"])
+    print(f"[parity fp16] unet tiny B=1: HIP fp16 max_rel={mx:.3e} rms_rel={rms:.3e} | reference bf16 run {mx_bf:.3e} {rms_bf:.3e}")
+    assert np.isfinite(out).all()
+    assert rms <= rms_bf / 4 and mx <= mx_bf / 3      # 8x finer rounding; a factor 4 / 3 is demanded
+
+
+def test_unet_full_width_fp16(hip, golden):
+    """The served architecture in the reference's served dtype: no worse than the reference's own fp16 run."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("unet_full_16x32.npz")
+    cfg = UNetConfig()
+    sd = {k: torch.from_numpy(v) for k, v in random_state_dict(cfg, int(g["weight_seed"])).items()}
+    unet = UNetHIP(cfg, sd, DEV, hip=hip)
+    out = _run_unet(unet, g)
+    mx, rms = rel(out, g["out"])
+    mx_ref, rms_ref = rel(g["out_ref_fp16"], g["out"])
+    mx_w, rms_w = rel(g["out_ref_fp16_weights_fp32_math"], g["out"])
+    print(f"[parity fp16] FULL-WIDTH unet 16x32x14 B=1: HIP fp16 max_rel={mx:.3e} rms_rel={rms:.3e} | reference fp16 run "
+          f"{mx_ref:.3e} {rms_ref:.3e} | reference, fp32 math on fp16-rounded weights {mx_w:.3e} {rms_w:.3e}")
+    assert np.isfinite(out).all()
+    assert rms <= rms_ref and mx <= 1.25 * mx_ref
+    # candidate independence is dtype-independent: B = 2 rows equal their B = 1 runs bit for bit
+    s2 = np.concatenate([g["sample"][:1], g["sample"][:1], g["sample"][1:], g["sample"][1:]])
+    e2 = np.concatenate([g["ehs"][:1], g["ehs"][:1], g["ehs"][1:], g["ehs"][1:]])
+    t2 = np.concatenate([g["added_time_ids"]] * 2)
+    a2 = np.concatenate([g["action_ids"]] * 2)
+    out2 = unet(torch.from_numpy(s2), float(g["timestep"]), torch.from_numpy(e2), torch.from_numpy(t2),
+                torch.from_numpy(a2)).cpu().numpy()
+    assert np.array_equal(out2[0], out[0]) and np.array_equal(out2[1], out[0])
+    assert np.array_equal(out2[2], out[1]) and np.array_equal(out2[3], out[1])
+
+
+def test_denoise_loop_fp16(hip, golden):
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("pipeline_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    den = SVDDenoiser(UNetHIP(cfg, random_state_dict(cfg, int(g["weight_seed"])), DEV, hip=hip))
+    lat = den.denoise(torch.from_numpy(g["image_latents"]), torch.from_numpy(g["image_embeddings"]),
+                      torch.from_numpy(g["latent_noise"]), g["actions"], num_steps=int(g["num_steps"]))
+    mx, rms = rel(lat, g["latents_out"])
+    print(f"[parity fp16] 3-step denoise loop: max_rel={mx:.3e} rms_rel={rms:.3e} (bf16 build: 2.7e-2)")
+    assert rms <= 8e-3      # the bf16 gate (3.5e-2, the reference's own bf16 error) divided by 4
+
+
+def test_vae_fp16(hip):
+    from wiw_amd import frontend as FE
+    from wiw_amd.vae import VAEHIP
+
+    vcfg = dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1)
+    sd = FE.vae_random_state_dict(31, **vcfg)
+    vae = VAEHIP(sd, DEV, hip=hip, **vcfg)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    T, h, w = 4, 16, 32
+    z = rnd(T, 4, h, w, seed=7) * 3.0
+    out = vae.decode_frames(z)
+    ref = VO.vae_decode(sdt, z, T, 4, 1)
+    mx, rms = rel(out, ref)
+    print(f"[parity fp16] VAE decode: max_rel={mx:.3e} rms_rel={rms:.3e}")
+    assert rms <= 6e-3           # bf16 gate 3e-2 (measured 1e-2)
+    x = torch.tanh(rnd(2, 3, 128, 256, seed=9))
+    mx, rms = rel(vae.encode_mode(x), VO.vae_encode_mode(sdt, x, 4, 1))
+    print(f"[parity fp16] VAE encode: max_rel={mx:.3e} rms_rel={rms:.3e}")
+    assert rms <= 6e-3
+
+
+def test_clip_encoder_fp16(hip):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from wiw_amd.clip import CLIPVisionHIP
+
+    torch.manual_seed(0)
+    m = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=320, intermediate_size=640, num_hidden_layers=2,
+                                                       num_attention_heads=4, image_size=224, patch_size=32,
+                                                       projection_dim=1024, hidden_act="gelu")).eval()
+    enc = CLIPVisionHIP.from_transformers(m, DEV, hip=hip)
+    img = torch.rand(2, 3, 300, 400, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    from wiw_amd.frontend import clip_preprocess
+
+    with torch.no_grad():
+        ref = m(clip_preprocess(img)).image_embeds
+    out = enc(img.to(DEV))
+    mx, rms = rel(out, ref)
+    print(f"[parity fp16] CLIP encoder (head_dim 80): max_rel={mx:.3e} rms_rel={rms:.3e}")
+    assert rms <= 4e-3

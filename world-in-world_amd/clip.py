@@ -80,7 +80,7 @@ class CLIPVisionHIP:
         return v.detach().to(self.device, torch.float32)
 
     def _prepare(self, sd):
-        w, bf, C = self.w, torch.bfloat16, self.C
+        w, bf, C = self.w, self.hip.dtype, self.C
         e = "vision_model.embeddings."
         pw = self._t(sd, e + "patch_embedding.weight").reshape(C, -1)          # (C, 3*P*P), flattened (c, ky, kx)
         w["patch.weight"] = torch.cat([pw, pw.new_zeros(C, self.Kp - pw.shape[1])], dim=1).to(bf).contiguous()
@@ -116,7 +116,7 @@ class CLIPVisionHIP:
     def _buffers(self, B: int, H0: int, W0: int):
         key = (B, H0, W0)
         if key not in self._buf:
-            A = torch.zeros(B * self.Sp, self.Kp, dtype=torch.bfloat16, device=self.device)   # class / padding rows stay zero
+            A = torch.zeros(B * self.Sp, self.Kp, dtype=self.hip.dtype, device=self.device)   # class / padding rows stay zero
             tmp = torch.empty(B * 3 * H0 * self.img, dtype=torch.float32, device=self.device)
             emb = self.w["embed_rows"].repeat(B, 1).contiguous()
             self._buf = {key: (A, tmp, emb)}                                                   # one geometry cached
@@ -133,7 +133,7 @@ class CLIPVisionHIP:
         A, tmp, emb = self._buffers(B, H0, W0)
         hip.clip_preprocess(x, B, H0, W0, self.img, self.P, gaussian_taps(W0, self.img), gaussian_taps(H0, self.img),
                             CLIP_MEAN, [1.0 / s for s in CLIP_STD], tmp, A, Sp, self.Kp)
-        bf = torch.bfloat16
+        bf = self.hip.dtype
         h = torch.empty(M, C, dtype=bf, device=self.device)
         hip.gemm(A, w["patch.weight"], h, M=M, N=C, K=self.Kp, C1=self.Kp, res1=emb, ldr1=C, beta1=1.0)
         h = hip.layernorm(h, M, C, w["pre_layrnorm.weight"], w["pre_layrnorm.bias"], self.eps)

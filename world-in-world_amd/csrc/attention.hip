@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
     f32x4 l_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+    for (int e = 0; e < 8; ++e) ones[e] = (short)WIW_ONE16;
 
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[f][0], z, 0, 0, 0);
-                s[kf][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[f][1], z, 0, 0, 0);
+                z = WIW_MFMA(k0, qf[f][0], z);
+                s[kf][f] = WIW_MFMA(k1, qf[f][1], z);
             }
         }
         // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag.
@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                     union { uint32_t u[4]; bf16x8 v; } pv;
                     pv.u[0] = pb[f][2 * ks][0]; pv.u[1] = pb[f][2 * ks][1];
                     pv.u[2] = pb[f][2 * ks + 1][0]; pv.u[3] = pb[f][2 * ks + 1][1];
-                    o[d][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, o[d][f], 0, 0, 0);
-                    if (d == 0) l_acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pv.v, l_acc[f], 0, 0, 0);
+                    o[d][f] = WIW_MFMA(va.v, pv.v, o[d][f]);
+                    if (d == 0) l_acc[f] = WIW_MFMA(ones, pv.v, l_acc[f]);
                 }
             }
         }
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
         *(uint4*)(vs + key * TV_LD + (lane & 7) * 8) = v;
     }
     f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
-    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, st, 0, 0, 0);
+    st = WIW_MFMA(k0, q0, st);
+    st = WIW_MFMA(k1, q1, st);
     // softmax over keys 4*fq + r for query fr
     float sv[4], mx = -INFINITY;
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
         const uint32_t e2 = vs[(fq * 4 + 2) * TV_LD + dcol], e3 = vs[(fq * 4 + 3) * TV_LD + dcol];
         va.u[0] = e0 | (e1 << 16); va.u[1] = e2 | (e3 << 16); va.u[2] = 0u; va.u[3] = 0u;
         f32x4 ot = f32x4{0.f, 0.f, 0.f, 0.f};
-        ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.v, pv.v, ot, 0, 0, 0);
+        ot = WIW_MFMA(va.v, pv.v, ot);
         if (store) {
             uint2 pk;
             pk.x = pack2bf(ot[0] * inv, ot[1] * inv);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             const bf16x8 kf = (kk * 32 + fq * 8 < D) ? *(const bf16x8*)(ksrc + kk * 32 + fq * 8) : zero8;
-            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st, 0, 0, 0);   // lane: query fr, keys 4*fq + r
+            st = WIW_MFMA(kf, qf[kk], st);   // lane: query fr, keys 4*fq + r
         }
         float sv[4], mx = -INFINITY;
 #pragma unroll
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const uint16_t* __restr
             vo.u[0] = vv.x; vo.u[1] = vv.y; vo.u[2] = 0u; vo.u[3] = 0u;
             f32x4 acc = o[db];
             acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vo.v, po.v, acc, 0, 0, 0);   // lane: query fr, d = 16*db + 4*fq + r
+            o[db] = WIW_MFMA(vo.v, po.v, acc);   // lane: query fr, d = 16*db + 4*fq + r
         }
     }
     const int qi = qt * 16 + fr;

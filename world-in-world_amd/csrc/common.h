@@ -12,14 +12,37 @@ typedef uint16_t bf16_t;
 
 #define WIW_DEV __device__ __forceinline__
 
-WIW_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// float -> bf16, round-to-nearest-even, on the native gfx950 converter (v_cvt_pk_bf16_f32: 2 values/instr)
-typedef __bf16 wiw_bf16x2 __attribute__((ext_vector_type(2)));
+// ---- 16-bit storage type of THIS build.  The library is compiled twice from the same sources: bf16 (libwiwsvd.so,
+// the default) and, with -DWIW_F16, IEEE fp16 (libwiwsvd_f16.so: the reference's served default dtype,
+// FTsvd/eval_inference.py:294).  Everything dtype-specific is here: the conversions, the MFMA opcode and the constant 1.0;
+// the kernels move 16-bit words and accumulate in fp32 either way.  (Helper names keep their "bf" spelling.)
 typedef float wiw_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef WIW_F16
+typedef _Float16 wiw_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 wiw_h16x8 __attribute__((ext_vector_type(8)));
+#define WIW_DTYPE_CODE 1
+#define WIW_ONE16 0x3C00   /* 1.0 */
+WIW_DEV float bf2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+WIW_DEV wiw_f32x2 unpack2(uint32_t u) { return __builtin_convertvector(__builtin_bit_cast(wiw_h16x2, u), wiw_f32x2); }
+// float -> fp16, round-to-nearest-even (v_cvt_f16_f32 x2 + v_pack)
+WIW_DEV uint32_t pack2bf(float lo, float hi) {
+    const wiw_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wiw_h16x2));
+}
+#define WIW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(wiw_h16x8, a), __builtin_bit_cast(wiw_h16x8, b), c, 0, 0, 0)
+#else
+typedef __bf16 wiw_bf16x2 __attribute__((ext_vector_type(2)));
+#define WIW_DTYPE_CODE 0
+#define WIW_ONE16 0x3F80   /* 1.0 */
+WIW_DEV float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+WIW_DEV wiw_f32x2 unpack2(uint32_t u) { return wiw_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+// float -> bf16, round-to-nearest-even, on the native gfx950 converter (v_cvt_pk_bf16_f32: 2 values/instr)
 WIW_DEV uint32_t pack2bf(float lo, float hi) {
     const wiw_f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wiw_bf16x2));
 }
+#define WIW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
 WIW_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); }
 WIW_DEV float silu_f(float x) {   // x * sigmoid(x) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; output is bf16)
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -44,10 +67,8 @@ WIW_DEV float gelu_erf_f(float x) {
 }
 
 WIW_DEV void unpack8(const uint4& v, float* f) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    const wiw_f32x2 a = unpack2(v.x), b = unpack2(v.y), c = unpack2(v.z), d = unpack2(v.w);
+    f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y; f[6] = d.x; f[7] = d.y;
 }
 WIW_DEV uint4 pack8(const float* f) {
     uint4 v;

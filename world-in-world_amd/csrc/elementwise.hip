@@ -27,6 +27,7 @@ int wiw_check_launch(const char* what) {
 }
 
 extern "C" int wiw_abi_version(void) { return WIW_ABI_VERSION; }
+extern "C" int wiw_dtype(void) { return WIW_DTYPE_CODE; }
 extern "C" const char* wiw_last_error(void) { return g_err; }
 
 extern "C" int wiw_device_check(int dev, char* name, int name_len) {

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         for (int ni = 0; ni < 10; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)   // swapped operands: lane gets n = 16*ni + 4*fq + r, m = 16*mi + frow
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = WIW_MFMA(fb[ni], fa[mi], acc[mi][ni]);
 #if WIW_ABLATE != 3
         __builtin_amdgcn_s_setprio(0);
 #endif

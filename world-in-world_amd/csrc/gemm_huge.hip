@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         for (int j = 0; j < 5; ++j)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)   // swapped operands: lane gets n = 16*(5h+j) + 4*fq + r, m = 16*mi + frow
-                acc[mi][h * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[mi], acc[mi][h * 5 + j], 0, 0, 0);
+                acc[mi][h * 5 + j] = WIW_MFMA(fb[j], fa[mi], acc[mi][h * 5 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
     auto slot_barrier = [&]() {

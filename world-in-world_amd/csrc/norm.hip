@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s2[j] = wiw_f32x2{0.f, 0.f}; q2[j] = s2[j]; p2[j] = s2[j]; }
         int cnt = 0;
-        auto unpack2 = [](uint32_t u) { return wiw_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; };
         auto accum = [&](const uint4& raw) {
             const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll

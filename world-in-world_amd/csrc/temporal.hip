@@ -206,12 +206,12 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)   // q, k: swapped operands -> lane = row frow, columns 16*ni + 4*fq + r
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = WIW_MFMA(fb[ni], fa[mi], acc[mi][ni]);
 #pragma unroll
         for (int ni = 8; ni < NF; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)   // v: lane = column (d) frow, rows (frames) 4*fq + r
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = WIW_MFMA(fa[mi], fb[ni], acc[mi][ni]);
         __builtin_amdgcn_s_setprio(0);
         // LayerNorm statistics from the A fragments just consumed (VALU, behind the MFMAs in flight)
 #pragma unroll
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
             x.v = fa[mi];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float lo = __uint_as_float(x.u[j] << 16), hi = __uint_as_float(x.u[j] & 0xffff0000u);
+                const wiw_f32x2 lh = unpack2(x.u[j]);
+                const float lo = lh.x, hi = lh.y;
                 sum1[mi] += lo + hi;
                 sum2[mi] = __builtin_fmaf(lo, lo, __builtin_fmaf(hi, hi, sum2[mi]));
             }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
                 ko.u[1] = pack2bf(acc[mi][4 + 2 * kk][2], acc[mi][4 + 2 * kk][3]);
                 ko.u[2] = pack2bf(acc[mi][4 + 2 * kk + 1][0], acc[mi][4 + 2 * kk + 1][1]);
                 ko.u[3] = pack2bf(acc[mi][4 + 2 * kk + 1][2], acc[mi][4 + 2 * kk + 1][3]);
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ko.v, qo.v, st, 0, 0, 0);
+                st = WIW_MFMA(ko.v, qo.v, st);
             }
             float sv4[4], mx = -INFINITY;
 #pragma unroll
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
                 union { uint32_t u[4]; bf16x8 v; } vo;
                 vo.u[0] = pack2bf(vv[0], vv[1]); vo.u[1] = pack2bf(vv[2], vv[3]); vo.u[2] = 0u; vo.u[3] = 0u;
                 f32x4 ot = f32x4{0.f, 0.f, 0.f, 0.f};
-                ot = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vo.v, po.v, ot, 0, 0, 0);
+                ot = WIW_MFMA(vo.v, po.v, ot);
                 uint2 pk;
                 pk.x = pack2bf(ot[0] * inv, ot[1] * inv);
                 pk.y = pack2bf(ot[2] * inv, ot[3] * inv);

@@ -13,6 +13,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WIW_LIB", os.path.join(_HERE, "libwiwsvd.so"))
+LIB_PATH_F16 = os.environ.get("WIW_LIB_F16", os.path.join(_HERE, "libwiwsvd_f16.so"))   # same sources, -DWIW_F16
+DTYPE_CODES = {torch.bfloat16: 0, torch.float16: 1}   # wiw_dtype() of the two builds
 
 A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1, 2, 3, 4, 5
 EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
@@ -28,7 +30,7 @@ class TiledW:
     (tools/ubench/lds_fill.hip).  Quacks like the [N, K] tensor it replaces (`shape`, `data_ptr`)."""
 
     def __init__(self, w: torch.Tensor):
-        assert w.dim() == 2 and w.dtype == torch.bfloat16 and w.shape[1] % 64 == 0, "TiledW: bf16 [N, K] with K % 64 == 0"
+        assert w.dim() == 2 and w.dtype in DTYPE_CODES and w.shape[1] % 64 == 0, "TiledW: 16-bit [N, K] with K % 64 == 0"
         self.shape = tuple(w.shape)
         self.data = tile_weight(w)
 
@@ -78,6 +80,7 @@ class WiwGemmArgs(C.Structure):
 
 EXPORTS = {
     "wiw_abi_version": (C.c_int, []),
+    "wiw_dtype": (C.c_int, []),
     "wiw_last_error": (C.c_char_p, []),
     "wiw_device_check": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "wiw_gemm_bf16": (C.c_int, [C.c_void_p, C.POINTER(WiwGemmArgs)]),
@@ -140,10 +143,18 @@ def _p(t: Optional[torch.Tensor]):
 class Hip:
     """Thin operator layer over the C ABI: argument checking + pointer marshalling only."""
 
-    def __init__(self, device: torch.device):
-        self.lib = load_library()
-        if self.lib.wiw_abi_version() != 4:
-            raise RuntimeError("libwiwsvd.so ABI version mismatch")
+    def __init__(self, device: torch.device, dtype: torch.dtype = torch.bfloat16):
+        """dtype: the 16-bit storage type of activations and weights — torch.bfloat16 (libwiwsvd.so) or torch.float16
+        (libwiwsvd_f16.so, the reference's served default).  One Hip serves one dtype; every tensor handed to it must
+        have that dtype (16-bit operands) or fp32 (vectors, latents)."""
+        if dtype not in DTYPE_CODES:
+            raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
+        self.dtype = dtype
+        self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
+        if self.lib.wiw_abi_version() != 5:
+            raise RuntimeError("libwiwsvd ABI version mismatch")
+        if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
+            raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the HIP path needs a ROCm device (torch device type 'cuda')")
@@ -284,7 +295,7 @@ class Hip:
         rpb = self.gn_rows_per_block(rows_per_unit, clip)
         stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
         if out is None:
-            out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((rows, Ct), dtype=self.dtype, device=self.device)
         s = self._stream()
 
         def launch():
@@ -306,7 +317,7 @@ class Hip:
         stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
         ab = torch.empty(units * 2 * Ct, dtype=torch.float32, device=self.device)
         if out is None:
-            out = torch.empty((rows, Ct), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((rows, Ct), dtype=self.dtype, device=self.device)
         s = self._stream()
         self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
                                               scratch.data_ptr()), "wiw_groupnorm_stats")
@@ -319,7 +330,7 @@ class Hip:
     def layernorm(self, X, rows, Cn, gamma, beta, eps=1e-5, addvec=None, addvec_ld=0, rows_per_vec=1, sum_out=None,
                   out=None):
         if out is None:
-            out = torch.empty((rows, Cn), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((rows, Cn), dtype=self.dtype, device=self.device)
         self._timed("layernorm", 0.0, (6.0 if sum_out is not None else 4.0) * rows * Cn, lambda: self._ck(
             self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
                                         addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16"))

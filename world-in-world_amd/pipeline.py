@@ -96,7 +96,7 @@ class SVDDenoiser:
         img = image_latents.to(self.device, torch.float32).contiguous()
         cond = self.unet.prepare_request(image_embeddings, act_ids, noise_aug_strength)
         hw = h * w
-        x_in = torch.empty((2 * B * T * hw, CIN_PAD), dtype=torch.bfloat16, device=self.device)
+        x_in = torch.empty((2 * B * T * hw, CIN_PAD), dtype=self.unet.dtype, device=self.device)
         for i in range(num_steps):
             s, sn = float(sig[i]), float(sig[i + 1])
             self.hip.prep_unet_input(lat, img, B, T, hw, s, CIN_PAD, x_in)

@@ -71,7 +71,7 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
 
 
 def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                      tiled: bool = True):
+                      tiled: bool = True, dtype: torch.dtype = torch.bfloat16):
     """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
     weight folded in (W' = bf16(W * gamma)), and per head the fold vectors s = sum_k W'[n][k] (of the ROUNDED weights,
     so the fold is exact for what the MFMAs multiply), t = sum_k W[n][k] * beta[k]:
@@ -79,7 +79,7 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     C = wq.shape[1]
     heads = C // 64
     wp = torch.stack([m.float().reshape(heads, 64, C) for m in (wq, wk, wv)], dim=1).reshape(heads * 192, C)
-    wg = (wp * gamma.float()[None, :]).to(torch.bfloat16).contiguous()
+    wg = (wp * gamma.float()[None, :]).to(dtype).contiguous()
     fold = torch.zeros(heads, 512, dtype=torch.float32, device=wp.device)
     fold[:, :192] = wg.float().sum(dim=1).reshape(heads, 192)
     fold[:, 192:384] = (wp @ beta.float()).reshape(heads, 192)
@@ -102,10 +102,13 @@ class RequestCond:
 
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
-                 hip: Optional[Hip] = None):
+                 hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16):
+        """dtype: 16-bit storage type of weights and activations (bf16, or fp16 = the reference's served default,
+        eval_inference.py:294); with `hip` given, its dtype is used."""
         self.cfg = cfg
         self.device = torch.device(device)
-        self.hip = hip or Hip(self.device)
+        self.hip = hip or Hip(self.device, dtype)
+        self.dtype = self.hip.dtype
         validate_state_dict(cfg, state_dict)
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
@@ -125,7 +128,7 @@ class UNetHIP:
 
     def _prepare(self, sd):
         cfg, w = self.cfg, self.w
-        bf = torch.bfloat16
+        bf = self.dtype
         temb_w, temb_b = [], []
         self.temb_off: Dict[str, int] = {}
         off = 0
@@ -197,7 +200,8 @@ class UNetHIP:
             lin(t + ".attn1.to_out.0")
             w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"] = pack_temporal_qkv(
                 self._t(sd, t + ".attn1.to_q.weight"), self._t(sd, t + ".attn1.to_k.weight"),
-                self._t(sd, t + ".attn1.to_v.weight"), self._t(sd, t + ".norm1.weight"), self._t(sd, t + ".norm1.bias"))
+                self._t(sd, t + ".attn1.to_v.weight"), self._t(sd, t + ".norm1.weight"), self._t(sd, t + ".norm1.bias"),
+                dtype=bf)
             for q in (b, t):  # single-key cross-attention: only to_v and to_out matter (§9.3)
                 lin(q + ".attn2.to_v", bias=False); lin(q + ".attn2.to_out.0")
             ff(b + ".ff"); ff(t + ".ff_in"); ff(t + ".ff")
@@ -261,8 +265,8 @@ class UNetHIP:
     # ------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------
-    def _empty(self, *shape, dtype=torch.bfloat16):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
     def _splitk(self, rows_per_item, N, K):
         """Split-K factor of an implicit-GEMM conv.  At the innermost 1280-channel level one candidate has M = 4032 rows:
@@ -288,7 +292,7 @@ class UNetHIP:
     def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, **kw):
         W = self.w[p + ".weight"]
         N, K = W.shape
-        out = self._empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        out = self._empty(M, N, dtype=torch.float32 if out_f32 else self.dtype)
         epi = (EPI_OUT_F32 if out_f32 else 0) | (EPI_SILU if silu else 0)
         return self.hip.gemm(x, W, out, M=M, N=N, K=K, C1=K, bias=self.w.get(p + ".bias"), epilogue=epi,
                              res1=res1, ldr1=N if res1 is not None else 0, beta1=1.0 if res1 is not None else 0.0, **kw)
@@ -319,7 +323,7 @@ class UNetHIP:
         B = image_embeddings.shape[0]
         Bc = 2 * B if cfg_batch else B
         T = cfg.num_frames
-        bf = torch.bfloat16
+        bf = self.dtype
         ie = image_embeddings.reshape(B, -1).to(self.device, torch.float32)
         ehs = torch.cat([torch.zeros_like(ie), ie]) if cfg_batch else ie
         ehs = ehs.to(bf).contiguous()
@@ -472,7 +476,7 @@ class UNetHIP:
         """silu(emb) rows for every (cfg item, frame): bf16 [Bc*T, E]  (unet:449-487 + resnet.py:343-344)."""
         cfg = self.cfg
         feat = torch.from_numpy(sinusoid(np.full((cond.Bc,), t, np.float32), cfg.block_out_channels[0]))
-        temb = self._mlp("time_embedding", feat.to(self.device, torch.bfloat16), cond.Bc)
+        temb = self._mlp("time_embedding", feat.to(self.device, self.dtype), cond.Bc)
         out = self._empty(cond.Bc * cfg.num_frames, cfg.time_embed_dim)
         return self.hip.emb_combine(temb, cond.act_emb, cond.noise_emb, cond.Bc, cond.B, cfg.num_frames,
                                     cfg.time_embed_dim, out)
@@ -556,8 +560,8 @@ class UNetHIP:
         if Bc == 2 * B and float(ehs[:B].abs().max()) != 0.0:
             raise ValueError("uncond image embeddings must be zeros (pipeline:221-227)")
         x = sample.to(self.device, torch.float32).permute(0, 1, 3, 4, 2).reshape(Bc * T * h * w_, Cin)
-        x_in = torch.zeros(Bc * T * h * w_, CIN_PAD, dtype=torch.bfloat16, device=self.device)
-        x_in[:, :Cin] = x.to(torch.bfloat16)
+        x_in = torch.zeros(Bc * T * h * w_, CIN_PAD, dtype=self.dtype, device=self.device)
+        x_in[:, :Cin] = x.to(self.dtype)
         emb = self.time_embedding(float(timestep), cond)
         out = self.forward(x_in, emb, cond, h, w_)
         return out.reshape(Bc, T, h, w_, self.cfg.out_channels).permute(0, 1, 4, 2, 3).contiguous()

@@ -64,7 +64,7 @@ class VAEHIP:
         return v.to(self.device, torch.float32)
 
     def _prepare(self, sd):
-        w, bf = self.w, torch.bfloat16
+        w, bf = self.w, self.hip.dtype
 
         def norm(p):
             w[p + ".weight"] = self._t(sd, p + ".weight").contiguous()
@@ -146,8 +146,8 @@ class VAEHIP:
     # ------------------------------------------------------------------------------------------
     # blocks (token-major bf16 [M, C], M = frames * H * W)
     # ------------------------------------------------------------------------------------------
-    def _empty(self, *shape, dtype=torch.bfloat16):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+    def _empty(self, *shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.hip.dtype, device=self.device)
 
     def _conv3(self, p, x, M, Cin, H, W, mode=A_CONV3X3, **kw):
         Wt = self.w[p + ".weight"]
@@ -294,7 +294,7 @@ class HIPFrontend:
     """`server.worker.Frontend` on the HIP kernels: temporal VAE (`VAEHIP`) and the CLIP image encoder
     (`clip.CLIPVisionHIP`, built from the weights of the `transformers` module the reference uses, pipeline:183-229)."""
 
-    def __init__(self, vae: VAEHIP, image_encoder, dtype=torch.bfloat16, device_io: bool = False, clip: str = "hip"):
+    def __init__(self, vae: VAEHIP, image_encoder, dtype=None, device_io: bool = False, clip: str = "hip"):
         """image_encoder: a `transformers.CLIPVisionModelWithProjection` (its weights are taken).
         clip = "hip" (product): the encoder runs on the HIP kernels and raises if its geometry is unsupported;
         clip = "torch": the module itself runs on PyTorch-ROCm (checker / reduced-width test models only).
@@ -305,14 +305,14 @@ class HIPFrontend:
         self._clip_preprocess = clip_preprocess
         self.vae = vae
         self.device = vae.device
-        self.dtype = dtype
+        self.dtype = dtype or vae.hip.dtype
         self.clip_hip = None
         self.image_encoder = None
         if clip == "hip":
             from .clip import CLIPVisionHIP
             self.clip_hip = CLIPVisionHIP.from_transformers(image_encoder, self.device, hip=vae.hip)
         elif clip == "torch":
-            self.image_encoder = image_encoder.to(self.device, dtype).eval() if image_encoder is not None else None
+            self.image_encoder = image_encoder.to(self.device, self.dtype).eval() if image_encoder is not None else None
         else:
             raise ValueError("clip must be 'hip' or 'torch'")
 
