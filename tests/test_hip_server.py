@@ -10,7 +10,8 @@ import vae_oracle as VO
 pytestmark = pytest.mark.gpu
 
 
-def test_worker_end_to_end_matches_oracle_chain(tmp_path):
+@pytest.mark.parametrize("dtype,psnr_gate", [(torch.bfloat16, 30.0), (torch.float16, 45.0)], ids=["bf16", "fp16"])
+def test_worker_end_to_end_matches_oracle_chain(tmp_path, dtype, psnr_gate):
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
 
     import wiw_amd  # noqa: F401
@@ -31,7 +32,7 @@ def test_worker_end_to_end_matches_oracle_chain(tmp_path):
     clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
                                                           num_attention_heads=2, image_size=224, patch_size=32,
                                                           projection_dim=1024)).eval()
-    den = SVDDenoiser(UNetHIP(cfg, sd, "cuda:0"))
+    den = SVDDenoiser(UNetHIP(cfg, sd, "cuda:0", dtype=dtype))   # bf16 (BASELINE) / fp16 (the reference's served default)
     fe_gpu = VO.TorchFrontend(vsd, clip, device="cuda:0", vae_dtype=torch.float32, dtype=torch.float32, **vcfg)
 
     def denoise(il, ie, nz, act, **kw):
@@ -68,7 +69,7 @@ def test_worker_end_to_end_matches_oracle_chain(tmp_path):
     mse = float((diff.astype(np.float64) ** 2).mean())
     psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
     print(f"[parity] end-to-end uint8 frames: mean|diff|={diff.mean():.3f} levels, max={diff.max()}, PSNR={psnr:.1f} dB")
-    assert psnr > 30.0   # per-pixel metric of the reference (evaluation/FVD/calculate_psnr.py:6-15); FVD needs absent I3D weights
+    assert psnr > psnr_gate   # per-pixel metric of the reference (evaluation/FVD/calculate_psnr.py:6-15); FVD needs absent I3D weights
 
 
 def test_serve_worker_full_size_over_tcp(tmp_path):
