@@ -46,9 +46,11 @@ def synth_actions(B, T):
     return np.tile(np.array(base, dtype=np.int64), (B, 1))
 
 
-def cpu_baseline(sd_cpu, cfg, threads):
+def cpu_baseline(sd_cpu, cfg, threads, device=None, dtype=None):
     """Oracle ("port") on the host cores: ONE fp32 UNet forward of BASELINE config 0 (256x256x8, CFG on)
-    = 1/10 of its 10-step rollout; frames/s extrapolated as 8 / (10 * t_forward)."""
+    = 1/10 of its 10-step rollout; frames/s extrapolated as 8 / (10 * t_forward).  With `device` given the HIP path
+    evaluates the SAME forward (same weights, same inputs) and the line carries its deviation from the oracle: the
+    bench number is then self-checking (the oracle stays the checker, never the thing measured)."""
     import svd_oracle as O
 
     torch.set_num_threads(threads)
@@ -57,17 +59,34 @@ def cpu_baseline(sd_cpu, cfg, threads):
     rs = np.random.RandomState(0)
     sample = torch.from_numpy(rs.standard_normal((2, T, 8, h, w)).astype(np.float32))
     ehs = torch.from_numpy(rs.standard_normal((2, 1, cfg.cross_attention_dim)).astype(np.float32))
+    ehs[:1] = 0            # CFG convention of the pipeline (pipeline:221-227, 244-250): the unconditional half carries
+    sample[:1, :, 4:] = 0  # zero image embeddings and zero conditioning latents
     tids = torch.tensor([[6, 127, 0.02]] * 2)
     # the nav checkpoint embeds 14-channel action rows; the 8-frame config uses the first 8 frames' rows
     aid = torch.from_numpy(O.action_ids_idx_encode(synth_actions(1, cfg.action_input_channel)))[:, :T]
     t0 = time.time()
     with torch.no_grad():
-        O.unet_forward(sd_cpu, ocfg, sample, torch.tensor(1.0), ehs, tids, aid)
+        ref = O.unet_forward(sd_cpu, ocfg, sample, torch.tensor(1.0), ehs, tids, aid)
     dt = time.time() - t0
-    return {"value": round(8.0 / (10.0 * dt), 5), "unit": "frames/s", "cores": threads, "kind": "port",
-            "seconds_per_forward": round(dt, 3),
-            "sample": "1 of the 10 UNet forwards (CFG batch 2, fp32, full-size weights) of BASELINE config 0 "
-                      "(256x256x8, 10 steps); frames/s = 8 / (10 * t_forward)"}
+    res = {"value": round(8.0 / (10.0 * dt), 5), "unit": "frames/s", "cores": threads, "kind": "port",
+           "seconds_per_forward": round(dt, 3),
+           "sample": "1 of the 10 UNet forwards (CFG batch 2, fp32, full-size weights) of BASELINE config 0 "
+                     "(256x256x8, 10 steps); frames/s = 8 / (10 * t_forward)"}
+    if device is not None:
+        from wiw_amd.config import UNetConfig
+        from wiw_amd.unet import UNetHIP
+
+        cfg8 = UNetConfig(num_frames=T, action_input_channel=cfg.action_input_channel)
+        u8 = UNetHIP(cfg8, sd_cpu, device, dtype=dtype or torch.bfloat16)
+        out = u8(sample, 1.0, ehs, tids, aid).float().cpu()
+        err = out - ref
+        res["hip_vs_oracle"] = {
+            "rms_rel": round(float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), 6),
+            "max_rel": round(float(err.abs().max() / ref.abs().max()), 6),
+            "what": "the HIP path on the same forward (same weights and inputs, 16-bit storage) against the fp32 oracle"}
+        del u8
+        torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -293,7 +312,7 @@ def main():
             res["end_to_end"] = end_to_end(den, unet, device, B, args)
         if sd_cpu is not None:
             try:
-                res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, min(os.cpu_count() or 1, 32))
+                res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, min(os.cpu_count() or 1, 32), device, unet.dtype)
             except Exception as e:  # the GPU number stands on its own; report why the baseline is absent
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -68,6 +68,13 @@ def test_pack_temporal_qkv_fold_algebra():
             # the only difference is the bf16 rounding of W * gamma (2^-9 relative per weight)
             assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
     assert float(fold[:, 384:].abs().max()) == 0.0
+    # the fp16 build packs the same operands in its own 16-bit type (libwiwsvd_f16.so); the tiling is a pure
+    # permutation of 16-bit words, so it is dtype-blind
+    wg16, fold16 = pack_temporal_qkv(wq, wk, wv, gamma, beta, tiled=False, dtype=torch.float16)
+    assert wg16.dtype == torch.float16 and torch.equal(fold16[:, 192:384], fold[:, 192:384])
+    assert float((wg16.float() - wg.float()).abs().max()) <= 2.0 ** -8 * float(wg.float().abs().max())
+    assert torch.equal(fold16[:, :192].reshape(-1), wg16.float().sum(dim=1))      # s is the sum of the ROUNDED rows
+    assert torch.equal(TiledW(wg16).untiled(), wg16)
 
 
 @pytest.mark.gpu

@@ -48,7 +48,9 @@ namespace {
 constexpr int BN = 160, BK = 64;
 constexpr int B_BYTES = BN * BK * 2;              // 20480
 constexpr int STG_ROWB = 336;                     // bytes per staged bf16 row (160 cols + 16 B skew)
-constexpr int STG_WAVE = 16 * STG_ROWB;           // 5376 B per wave (16 rows at a time)
+constexpr int STG_ROWB_G = 176;                   // GEGLU: 80 output cols + 16 B skew; all 32 rows of a wave are staged at once
+constexpr int STG_WAVE = 32 * STG_ROWB_G;         // 5632 B per wave (plain: 16 rows x 336 B = 5376)
+static_assert(16 * STG_ROWB <= STG_WAVE, "");
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     setup_loader(t);
     reset_loader(t);
     int st_c = 0;   // ring stage holding the K tile the MFMAs consume next
-    int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 6 / 12)
+    int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 5 / 12)
 #ifdef WIW_TRACE
     int tiles_done = 0;
 #endif
@@ -420,14 +422,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         auto wait_tile = [&](int j, auto ndma_tag) {
             constexpr int n_dma = decltype(ndma_tag)::value;
             const bool dma_younger = (D == 2) && (j + 1 < nk);
-            const int st_younger = (j < D) ? pending_stores : 0;   // wave-uniform: 0, 6 (GEGLU) or 12
+            const int st_younger = (j < D) ? pending_stores : 0;   // wave-uniform: 0, 5 (GEGLU) or 12
             if (dma_younger) {
                 if (st_younger == 12) wait_vmcnt<n_dma + 12>();
-                else if (st_younger == 6) wait_vmcnt<n_dma + 6>();
+                else if (st_younger == 5) wait_vmcnt<n_dma + 5>();
                 else wait_vmcnt<n_dma>();
             } else {
                 if (st_younger == 12) wait_vmcnt<12>();
-                else if (st_younger == 6) wait_vmcnt<6>();
+                else if (st_younger == 5) wait_vmcnt<5>();
                 else wait_vmcnt<0>();
             }
         };
@@ -687,9 +689,50 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #if WIW_ABLATE == 6
             if (p.M < 0) {
 #endif
-            half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 0>{});
-            half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 1>{});
-            if (fast_st) pending_stores = geglu ? 2 * ITEMS_G : 2 * ITEMS_P;
+            if constexpr (GE) {
+                // GEGLU: the output tile of a wave is 32 rows x 80 columns = 320 sixteen-byte chunks = EXACTLY five
+                // 64-lane sweeps (the 16-row passes above would take 2 x 3 sweeps of 6 rows and write two rows twice per
+                // pass: +12.5 % on the output stream, PMC WRITE_SIZE 743 MB for 660 MB algorithmic at L0).  No per-column
+                // math is left for the row-major phase (bias and GELU are applied in the fragment layout), so a lane may
+                // own a different column chunk in every sweep.
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    char* wrow = stg + (mi * 16 + frow) * STG_ROWB_G + fq * 8;
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
+                        if (p.bias) {
+                            v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
+                            g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
+                        }
+                        const wiw_f32x2 h01 = {v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1])};
+                        const wiw_f32x2 h23 = {v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3])};
+                        uint2 pk;
+                        pk.x = pack2bf(h01.x, h01.y);
+                        pk.y = pack2bf(h23.x, h23.y);
+                        *(uint2*)(wrow + ni * 32) = pk;
+                    }
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int slot = k * 64 + lane;           // 0..319
+                    const int rr = slot / 10, ch = slot - rr * 10;
+                    const int m = mw0 + rr;
+                    const int nc = tile_n * 80 + ch * 8;
+                    const bool ok = m < p.M && nc < n_valid;
+                    const uint4 ov = *(const uint4*)(stg + rr * STG_ROWB_G + ch * 16);
+                    uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + nc) : dump;
+                    __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
+                    __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+                }
+                wave_lds_sync();
+                if (fast_st) pending_stores = 5;
+            } else {
+                half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 0>{});
+                half_pass(std::integral_constant<bool, GE>{}, std::integral_constant<int, 1>{});
+                if (fast_st) pending_stores = 2 * ITEMS_P;
+            }
 #if WIW_ABLATE == 6
             } else {
 #pragma unroll

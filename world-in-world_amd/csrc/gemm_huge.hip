@@ -38,7 +38,9 @@ constexpr int HB_BYTES = HN * HK * 2;            // 40960
 constexpr int HSTAGE = HA_BYTES + HB_BYTES;      // 73728
 constexpr int H_SMEM = 2 * HSTAGE;               // 147456
 constexpr int HSTG_ROWB = 336;                   // bytes per staged bf16 row (160 cols + 16 B skew)
-constexpr int HSTG_WAVE = 16 * HSTG_ROWB;        // 5376 B per wave
+constexpr int HSTG_ROWB_G = 176;                 // GEGLU: 80 output cols + 16 B skew, 32 rows staged at once
+constexpr int HSTG_WAVE = 32 * HSTG_ROWB_G;      // 5632 B per wave (plain: 16 rows x 336 B = 5376)
+static_assert(16 * HSTG_ROWB <= HSTG_WAVE, "");
 static_assert(8 * HSTG_WAVE <= HSTAGE, "epilogue staging must fit in one ring stage");
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     setup_loader(t);
     reset_loader(t);
     int st_c = 0;
-    int pending_stores = 0;   // 0 / 12 (GEGLU) / 24
+    int pending_stores = 0;   // 0 / 10 (GEGLU) / 24
     issue_all(0);
 
     while (t >= 0) {
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         // K tile 0 was issued BEFORE the previous tile's epilogue stores: it has landed once at most those stores are
         // outstanding (in-order retirement; their number is a compile-time constant because they are unconditional)
         if (pending_stores == 24) wait_vmcnt<24>();
-        else if (pending_stores == 12) wait_vmcnt<12>();
+        else if (pending_stores == 10) wait_vmcnt<10>();
         else wait_vmcnt<0>();
 
         // Sync proof (same as gemm.hip with 8 slots): the lagging group's local barrier b is the leading group's b+1.
@@ -525,8 +527,48 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 }
                 wave_lds_sync();
             };
-            pass(IC<0>{}); pass(IC<1>{}); pass(IC<2>{}); pass(IC<3>{});
-            if (r2 == nullptr) pending_stores = GE ? 4 * ITEMS_G : 4 * ITEMS_P;
+            if constexpr (GE) {
+                // GEGLU: 32 rows x 80 columns of a wave = 320 sixteen-byte chunks = exactly five 64-lane sweeps (see
+                // gemm.hip): two double passes, no row written twice
+                auto pass32 = [&](auto half_tag) {
+                    constexpr int hh = decltype(half_tag)::value;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        char* wrow = stg + (m2 * 16 + frow) * HSTG_ROWB_G + fq * 8;
+#pragma unroll
+                        for (int ni = 0; ni < 5; ++ni) {
+                            f32x4 v = acc[hh * 2 + m2][ni], g = acc[hh * 2 + m2][ni + 5];
+                            if (p.bias) {
+                                v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
+                                g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
+                            }
+                            uint2 pk;
+                            pk.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
+                            pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+                            *(uint2*)(wrow + ni * 32) = pk;
+                        }
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const int slot = k * 64 + lane;
+                        const int rr = slot / 10, ch = slot - rr * 10;
+                        const int m = mw0 + hh * 32 + rr;
+                        const int nc = tile_nw * 80 + ch * 8;
+                        const bool ok = m < p.M && nc < n_valid;
+                        const uint4 ov = *(const uint4*)(stg + rr * HSTG_ROWB_G + ch * 16);
+                        uint4* dst = ok ? (uint4*)((uint16_t*)p.out + (int64_t)m * p.ldo + nc) : dump;
+                        __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
+                        __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+                    }
+                    wave_lds_sync();
+                };
+                pass32(IC<0>{}); pass32(IC<1>{});
+                pending_stores = 10;
+            } else {
+                pass(IC<0>{}); pass(IC<1>{}); pass(IC<2>{}); pass(IC<3>{});
+                if (r2 == nullptr) pending_stores = 4 * ITEMS_P;
+            }
         }
         t = t_next;
         q = q_next;
