@@ -124,8 +124,9 @@ int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args);
  * Replaces F.scaled_dot_product_attention at dp/models/attention_processor.py:2383-2385 as called
  * from BasicTransformerBlock.attn1 (dp/models/attention.py:507-512).
  *   QK : bf16 [frames*S][ldqk], Q at column h*64, K at column k_col_off + h*64
- *   Vt : bf16 [heads*64][ldvt] (V TRANSPOSED: Vt[h*64 + d][n*S + s]), produced by wiw_gemm_bf16 with
- *        swapped operands; S % 8 == 0 required (16-byte aligned key runs).
+ *   Vt : bf16 [heads*64][ldvt] (V TRANSPOSED: Vt[h*64 + d][n*S + s]), produced by wiw_transpose_bf16 from the V
+ *        columns of one fused q|k|v projection (or by wiw_gemm_bf16 with swapped operands); S % 8 == 0 required
+ *        (16-byte aligned key runs).
  *   O  : bf16 [frames*S][ldo];  zeros: >= 16 bytes of device zeros (V^T chunks past the frame end)
  * ---------------------------------------------------------------------------------------------- */
 int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt,
