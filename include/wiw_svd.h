@@ -31,10 +31,11 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 5   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 6   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
-                             5: wiw_dtype (the library exists in a bf16 and an fp16 build) */
+                             5: wiw_dtype (the library exists in a bf16 and an fp16 build);
+                             6: WiwGemmArgs gained lnfold / ln_eps (WIW_EPI_LNFOLD) */
 
 int wiw_abi_version(void);
 
@@ -80,6 +81,13 @@ int wiw_device_check(int dev, char* name, int name_len);
  *   r*128 .. r*128+127 and its eight 16-byte chunks are stored XOR-swizzled: position p holds chunk p ^ r.  One LDS-DMA
  *   instruction of the kernel then reads one contiguous KiB — 63 B/clk/CU against 25 B/clk/CU for eight row segments K*2 bytes
  *   apart (tools/ubench/lds_fill.hip); the LDS image and every result bit are identical.  (`hip.tile_weight` builds it.)
+ * LayerNorm fold (epilogue bit WIW_EPI_LNFOLD, dense mode, C2 == 0): A is the RAW input x of an nn.LayerNorm over K = C1
+ *   (dp/models/attention.py:659-694 norm1 / norm3 / norm_in feeding to_q|k|v and the GEGLU projections) and W holds
+ *   W * gamma (rounded to the 16-bit type):  LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n  with
+ *   lnfold = [s (N) | t (N)], s_n = sum_k W'[n][k] (of the ROUNDED rows), t_n = sum_k W[n][k] * beta[k] + bias_n (bias must be
+ *   NULL: it is inside t).  Row mean / rstd are accumulated inside the kernel from the operand fragments; the fold is
+ *   applied to the fp32 accumulators before the first rounding.  N % 160 == 0, alpha == 1, 16-bit aligned output only;
+ *   with WIW_EPI_GEGLU, s and t follow the packed row order of W.  Served by the 256x160 / 128x160 tiles.
  * Constraints: C1, C2, C3 % 64 == 0; K = C1 + C2 (dense), taps * C1 (conv) or 9 * C1 + C2 + C3 (conv3x3 + shortcut);
  * A2 only with WIW_A_DENSE / WIW_A_CONV3X3, A3 only with WIW_A_CONV3X3.
  * ---------------------------------------------------------------------------------------------- */
@@ -88,7 +96,8 @@ enum { WIW_A_DENSE = 0, WIW_A_CONV3X3 = 1, WIW_A_CONV3X3_S2 = 2, WIW_A_CONV3X3_U
 enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
        WIW_EPI_GELU = 8,        /* y = gelu_erf(y)           (CLIP ViT-H MLP, transformers `gelu`) */
        WIW_EPI_QUICK_GELU = 16, /* y = y * sigmoid(1.702 y)  (OpenAI CLIP `quick_gelu`) */
-       WIW_W_TILED = 32         /* W is pre-tiled for the LDS-DMA stream (below) */ };
+       WIW_W_TILED = 32,        /* W is pre-tiled for the LDS-DMA stream (above) */
+       WIW_EPI_LNFOLD = 64      /* A is the un-normalised LayerNorm input, W = W * gamma, lnfold = [s | t] (above) */ };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -114,6 +123,8 @@ typedef struct WiwGemmArgs {
                           * sums go to `workspace`; a second kernel adds them IN RANGE ORDER and applies the epilogue
                           * (deterministic; for launches whose M alone cannot fill 256 CUs).  Not with GEGLU / GELU. */
     void* workspace;     /* split-K only: S * M * N floats of device scratch */
+    const float* lnfold; /* WIW_EPI_LNFOLD only: [s (N) | t (N)] fp32, see below */
+    float ln_eps;        /* WIW_EPI_LNFOLD only: the LayerNorm epsilon */
 } WiwGemmArgs;
 
 int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args);

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path, variant, code):
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported by {os.path.basename(path)}"
     lib.wiw_abi_version.restype = ctypes.c_int
     lib.wiw_dtype.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 5 and lib.wiw_dtype() == code
+    assert lib.wiw_abi_version() == 6 and lib.wiw_dtype() == code
 
 
 def test_gemm_args_struct_layout():
@@ -48,9 +48,10 @@ def test_gemm_args_struct_layout():
 
     # 10 pointers + 21 x 4-byte fields (+ 4 bytes of padding) + the split-K workspace pointer, natural alignment
     # (matches the C struct in wiw_svd.h)
-    assert ctypes.sizeof(WiwGemmArgs) == 10 * 8 + 21 * 4 + 4 + 8
+    assert ctypes.sizeof(WiwGemmArgs) == 10 * 8 + 21 * 4 + 4 + 8 + 8 + 4 + 4     # + lnfold pointer, ln_eps, tail padding
     assert WiwGemmArgs.M.offset == 80 and WiwGemmArgs.epilogue.offset == 80 + 19 * 4
     assert WiwGemmArgs.splitk.offset == 80 + 20 * 4 and WiwGemmArgs.workspace.offset == 168
+    assert WiwGemmArgs.lnfold.offset == 176 and WiwGemmArgs.ln_eps.offset == 184
 
 
 def test_missing_library_fails_loudly(tmp_path):

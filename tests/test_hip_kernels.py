@@ -666,3 +666,69 @@ def test_gemm_splitk_on_the_256x320_tile(hip):
              A2=dev_bf(nhwc(s1)), C2=c2, A3=dev_bf(nhwc(s2)), C3=c3, bias=dev_f(bb), splitk=sk)
     ref = F.conv2d(x, wt, bb, padding=1) + F.conv2d(torch.cat([s1, s2], dim=1), wsc)
     check(from_nhwc(out, n, h, w_), ref, what="split-K 3 conv3x3 + shortcut on the 256x320 tile")
+
+
+# ----------------------------------------------------------------------------------------------
+# LayerNorm folded into the consumer GEMM (WIW_EPI_LNFOLD): x raw, W = W * gamma, [s | t], statistics in the kernel
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C,N", [(520, 320, 960), (70000, 320, 960), (1000, 64, 320), (300, 128, 160)])
+def test_gemm_layernorm_fold_plain(hip, M, C, N):
+    """Plain staged epilogue (the q|k|v projection after norm1), with a residual and a per-row-group vector on top;
+    small M takes the 128x160 tile, M = 70000 the 256x160 tile.  The only extra error over the two-kernel form is the
+    16-bit rounding of W * gamma (vs rounding LN(x)): gate 1.5e-2 / 5e-3."""
+    from wiw_amd import hip as H
+    from wiw_amd.unet import fold_layernorm
+
+    x = bf(rnd(M, C, seed=1) * 1.5 + 0.4)
+    x[:, 5] += 6.0                                              # a channel with a large offset: the fold must remove the mean
+    w, b = rnd(N, C, seed=2) / math.sqrt(C), rnd(N, seed=3) * 0.2
+    gamma, beta = 1 + 0.3 * rnd(C, seed=4), 0.2 * rnd(C, seed=5)
+    r1 = bf(rnd(M, N, seed=6))
+    rv = rnd(-(-M // 100), N, seed=7)
+    wg, st = fold_layernorm(w, b, gamma, beta, torch.bfloat16)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(x), H.TiledW(wg.to(DEV)), out, M=M, N=N, K=C, C1=C, lnfold=st.to(DEV), ln_eps=1e-5,
+             res1=dev_bf(r1), ldr1=N, beta1=1.0, rowvec=dev_f(rv), rowvec_ld=N, rows_per_vec=100)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5) @ w.t() + b + r1 + rv[torch.arange(M) // 100]
+    check(out, ref, max_tol=1.5e-2, rms_tol=5e-3, what=f"LN-fold GEMM {M}x{N}x{C}")
+    again = torch.empty_like(out)
+    hip.gemm(dev_bf(x), H.TiledW(wg.to(DEV)), again, M=M, N=N, K=C, C1=C, lnfold=st.to(DEV), ln_eps=1e-5,
+             res1=dev_bf(r1), ldr1=N, beta1=1.0, rowvec=dev_f(rv), rowvec_ld=N, rows_per_vec=100)
+    assert torch.equal(out, again)
+    # a row's result does not depend on which tile / block computed it: the first 300 rows alone give the same bits
+    part = torch.empty(300, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(x[:300]), H.TiledW(wg.to(DEV)), part, M=300, N=N, K=C, C1=C, lnfold=st.to(DEV), ln_eps=1e-5,
+             res1=dev_bf(r1[:300]), ldr1=N, beta1=1.0, rowvec=dev_f(rv), rowvec_ld=N, rows_per_vec=100)
+    assert torch.equal(part, out[:300])
+
+
+@pytest.mark.parametrize("M,C", [(520, 320), (66000, 320), (777, 64)])
+def test_gemm_layernorm_fold_geglu(hip, M, C):
+    """GEGLU projection after norm3 / norm_in: gamma-folded packed weights, s and t in the packed row order."""
+    from wiw_amd import hip as H
+    from wiw_amd.unet import pack_geglu
+
+    x = bf(rnd(M, C, seed=1) * 1.2 - 0.3)
+    x[:, 9] -= 5.0
+    w0, b0 = rnd(8 * C, C, seed=2) / math.sqrt(C), rnd(8 * C, seed=3) * 0.2
+    gamma, beta = 1 + 0.3 * rnd(C, seed=4), 0.2 * rnd(C, seed=5)
+    wgp, tp, n_half = pack_geglu(w0 * gamma[None, :], w0 @ beta + b0)
+    wgp = wgp.to(torch.bfloat16)
+    st = torch.stack([wgp.float().sum(dim=1), tp.float()]).contiguous()
+    out = torch.full((M, n_half), float("nan"), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(x), H.TiledW(wgp.to(DEV)), out, M=M, N=wgp.shape[0], K=C, C1=C, epilogue=H.EPI_GEGLU, n_out=n_half,
+             lnfold=st.to(DEV), ln_eps=1e-5)
+    y = F.layer_norm(x, (C,), gamma, beta, 1e-5) @ w0.t() + b0
+    check(out, y[:, :n_half] * F.gelu(y[:, n_half:]), max_tol=1.5e-2, rms_tol=5e-3, what=f"LN-fold GEGLU {M}x{C}")
+
+
+def test_gemm_layernorm_fold_validation(hip):
+    from wiw_amd import hip as H
+
+    a = dev_bf(rnd(128, 64, seed=1)); w = dev_bf(rnd(160, 64, seed=2)); st = dev_f(rnd(2, 160, seed=3))
+    out = torch.empty(128, 160, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="bias in t"):
+        hip.gemm(a, w, out, M=128, N=160, K=64, C1=64, lnfold=st, bias=dev_f(rnd(160)))
+    with pytest.raises(RuntimeError, match="N % 160"):
+        hip.gemm(a, dev_bf(rnd(128, 64, seed=2)), torch.empty(128, 128, dtype=torch.bfloat16, device=DEV), M=128, N=128, K=64,
+                 C1=64, lnfold=dev_f(rnd(2, 128)))

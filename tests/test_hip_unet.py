@@ -148,3 +148,20 @@ def test_unet_vs_oracle_other_seed(tiny):
     mx, rms = rel(out, ref)
     print(f"[parity] unet tiny vs oracle (seed 11, 8x64): max_rel={mx:.3e} rms_rel={rms:.3e}")
     assert rms < 2e-2 and mx < 4e-2
+
+
+def test_unet_with_folded_layernorms(tiny, golden):
+    """UNetHIP(fold_layernorm=True): norm1 / norm3 / norm_in evaluated INSIDE their consumer GEMMs (WIW_EPI_LNFOLD, row
+    statistics from the operand fragments).  Same gate as the default network, and close to it."""
+    from wiw_amd.unet import UNetHIP
+
+    g = golden("unet_tiny_b1.npz")
+    cfg, sd, unet = tiny(int(g["weight_seed"]))
+    folded = UNetHIP(cfg, sd, DEV, hip=unet.hip, fold_layernorm=True)
+    assert any(k.endswith(".lnfold.weight") for k in folded.w) and not any(k.endswith(".lnfold.weight") for k in unet.w)
+    out, base = _run_unet(folded, g), _run_unet(unet, g)
+    mx, rms = rel(out, g["out"])
+    mx_ref, rms_ref = rel(g["out_ref_bf16"], g["out"])
+    print(f"[parity] unet tiny, folded LayerNorms: max_rel={mx:.3e} rms_rel={rms:.3e} (reference bf16 run {rms_ref:.3e}); "
+          f"vs the unfolded network rms={rel(out, base)[1]:.3e}")
+    assert np.isfinite(out).all() and rms <= rms_ref and mx <= 1.25 * mx_ref

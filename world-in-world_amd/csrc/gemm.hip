@@ -86,7 +86,13 @@ WIW_DEV void wave_lds_sync() {   // order this wave's LDS writes before its foll
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int MODE, int NW, int STAGES, bool GE>
+// LNF (WIW_EPI_LNFOLD, dense mode): the A operand is the RAW input x of a LayerNorm over K = C1 and W holds W * gamma:
+//     LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n,   s_n = sum_k W'[n][k],  t_n = sum_k W[n][k] beta[k] + bias_n
+// (exact; p.lnfold = [s | t], fp32).  Every wave owns whole rows (32 rows x all 160 columns), so it accumulates the row
+// sums / sums of squares of its rows from the A fragments it feeds to the MFMAs anyway, and the fold is applied to the
+// fp32 accumulators in the fragment layout BEFORE the first 16-bit rounding.  The LayerNorm pass (one read + one write
+// of the activation) and the normalised tensor disappear.
+template <int MODE, int NW, int STAGES, bool GE, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, const int stagger) {
     constexpr int BM = NW * 32;
     constexpr int A_BYTES = BM * BK * 2;
@@ -97,6 +103,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     constexpr int D = STAGES - 1;                     // K tiles in flight ahead of the MFMAs
     static_assert(B_FULL * NW + (B_HALF ? NW / 2 : 0) == 20, "W tile must be covered exactly");
     static_assert(NW * STG_WAVE <= STAGE_BYTES, "per-wave epilogue staging must fit in one ring stage");
+    static_assert(!LNF || MODE == WIW_A_DENSE, "the LayerNorm fold needs whole rows of x in the K loop");
+    constexpr int FOLD_BYTES = 2 * BN * 4;            // s | t of one 160-column tile (fp32); two parities after the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -338,6 +346,16 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #pragma unroll
         for (int ni = 0; ni < 10; ++ni) fb[ni] = *(const bf16x8*)(sB + ni * 2048);
     };
+    float sum1[2] = {0.f, 0.f}, sum2[2] = {0.f, 0.f};   // LNF: per-lane partial row sums of x and x^2 (rows 16*mi + frow)
+    char* const fold_scr = smem + STAGES * STAGE_BYTES;   // LNF: [parity][s(160) | t(160)]
+    int fold_par = 0;
+    // LNF: waves 0 / 1 fetch s / t of tile `tile`'s 160 columns (40 lanes x 16 B each) into parity `par`
+    auto issue_fold = [&](int tile, int par) {
+        if (LNF && wave < 2 && lane < 40) {
+            const int n0f = (tile % Nt) * BN;
+            glds16((const char*)(p.lnfold + (int64_t)wave * p.N + n0f + lane * 4), fold_scr + par * FOLD_BYTES + wave * (BN * 4));
+        }
+    };
     auto mma = [&]() {
 #if WIW_ABLATE == 1
         asm volatile("" :: "v"(fa[0]), "v"(fb[0]));
@@ -354,6 +372,19 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #if WIW_ABLATE != 3
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (LNF) {   // row statistics from the A fragments just consumed (VALU, behind the MFMAs in flight)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                union { bf16x8 v; uint32_t u[4]; } x;
+                x.v = fa[mi];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const wiw_f32x2 lh = unpack2(x.u[j]);
+                    sum1[mi] += lh.x + lh.y;
+                    sum2[mi] = __builtin_fmaf(lh.x, lh.x, __builtin_fmaf(lh.y, lh.y, sum2[mi]));
+                }
+            }
+        }
     };
     auto slot_barrier = [&]() {   // close a slot: this wave's LDS reads are retired, then rendezvous
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -385,6 +416,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     // ---- prologue: first D K tiles of the first output tile
     setup_loader(t);
     reset_loader(t);
+    issue_fold(t, 0);
     int st_c = 0;   // ring stage holding the K tile the MFMAs consume next
     int pending_stores = 0;   // epilogue stores of the previous tile queued behind the prefetched DMA (0 / 5 / 12)
 #ifdef WIW_TRACE
@@ -406,6 +438,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 10; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sum1[0] = sum1[1] = sum2[0] = sum2[1] = 0.f;
 
         // ---- main loop.  Local slots of K tile kt:  [4kt] issue DMA(kt+D), R(kt,0)  [4kt+1] M  [4kt+2] R(kt,1),
         // wait(tile kt+1)  [4kt+3] M.   The lagging group executes one extra barrier before its first slot and the
@@ -574,6 +607,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         if (t_next >= 0) {
             setup_loader(t_next);
             reset_loader(t_next);
+            issue_fold(t_next, fold_par ^ 1);   // the other parity was last read in the previous tile's epilogue
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 if (j < nk) {
@@ -586,6 +620,31 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         int st_e = st_c + D;
         st_e = st_e >= STAGES ? st_e - STAGES : st_e;
         pending_stores = 0;
+
+        // LNF: finish the row statistics (the four lanes fq = 0..3 of a row hold partial sums) and the fold factors
+        float ln_rs[2] = {1.f, 1.f}, ln_nrm[2] = {0.f, 0.f};
+        const char* const fscr = fold_scr + fold_par * FOLD_BYTES;
+        if (LNF) {
+            const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float s1 = xor32_sum(xor16_sum(sum1[mi])), s2 = xor32_sum(xor16_sum(sum2[mi]));
+                const float mean = s1 * inv_k;
+                const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_k), 0.f);
+                ln_rs[mi] = rsqrtf(var + p.ln_eps);
+                ln_nrm[mi] = -ln_rs[mi] * mean;
+            }
+            fold_par ^= 1;
+        }
+        // x = rstd * acc + (t - rstd * mean * s) for the 4 columns 16*ni + 4*fq .. +3 of fragment ni
+        auto ln_fold4 = [&](f32x4& v, int ni, int mi) {
+            const float4 sv = *(const float4*)(fscr + (ni * 16 + fq * 4) * 4);
+            const float4 tv = *(const float4*)(fscr + BN * 4 + (ni * 16 + fq * 4) * 4);
+            v[0] = __builtin_fmaf(ln_rs[mi], v[0], __builtin_fmaf(ln_nrm[mi], sv.x, tv.x));
+            v[1] = __builtin_fmaf(ln_rs[mi], v[1], __builtin_fmaf(ln_nrm[mi], sv.y, tv.y));
+            v[2] = __builtin_fmaf(ln_rs[mi], v[2], __builtin_fmaf(ln_nrm[mi], sv.z, tv.z));
+            v[3] = __builtin_fmaf(ln_rs[mi], v[3], __builtin_fmaf(ln_nrm[mi], sv.w, tv.w));
+        };
 
         // ---- epilogue, part 2 (per wave, no block barrier)
         if (staged) {
@@ -619,6 +678,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #pragma unroll
                     for (int ni = 0; ni < 10; ++ni) {
                         f32x4 v = acc[mi][ni];
+                        if (LNF) ln_fold4(v, ni, mi);
                         if (scale_acc) { v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha; }
                         uint2 pk;
                         pk.x = pack2bf(v[0], v[1]);
@@ -701,7 +761,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #pragma unroll
                     for (int ni = 0; ni < 5; ++ni) {
                         f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
-                        if (p.bias) {
+                        if (LNF) {          // t carries the bias
+                            ln_fold4(v, ni, mi);
+                            ln_fold4(g, ni + 5, mi);
+                        } else if (p.bias) {
                             v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
                             g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
                         }
@@ -839,16 +902,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const WiwGemmArgs p)
     }
 }
 
-template <int MODE, int NW, int STAGES, bool GE>
+template <int MODE, int NW, int STAGES, bool GE, bool LNF = false>
 int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     constexpr int BM = NW * 32;
-    constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES);
+    constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES) + (LNF ? 2 * 2 * BN * 4 : 0);   // + two parities of s | t
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
     static std::once_flag once;
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -863,7 +926,7 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     if (tiles < grid) grid = tiles >= 64 ? (tiles / 8) * 8 : tiles;   // keep the per-XCD super-tile schedule usable
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     const int stagger = stg_env ? atoi(stg_env) : 0;
-    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE, LNF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16");
 }
 
@@ -895,6 +958,17 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
         return wiw_check_launch("wiw_gemm_bf16 (split-K reduce)");
     }
     static const char* force = getenv("WIW_GEMM_TILE");   // tuning knob: "huge" / "big" / "small" overrides the heuristic
+    if (a.epilogue & WIW_EPI_LNFOLD) {   // whole rows of x per wave: the 256x160 / 128x160 tiles only (dense mode)
+        if constexpr (MODE == WIW_A_DENSE) {
+            const bool big_l = force ? (force[0] != 's') : use_big_tile(a);
+            if (a.epilogue & WIW_EPI_GEGLU)
+                return big_l ? launch_cfg<WIW_A_DENSE, 8, 3, true, true>(s, a, 1) : launch_cfg<WIW_A_DENSE, 4, 2, true, true>(s, a, 2);
+            return big_l ? launch_cfg<WIW_A_DENSE, 8, 3, false, true>(s, a, 1) : launch_cfg<WIW_A_DENSE, 4, 2, false, true>(s, a, 2);
+        } else {
+            wiw_set_error("gemm: the LayerNorm fold is a dense-mode epilogue");
+            return WIW_EINVAL;
+        }
+    }
     if ((!force || force[0] == 'h') && wiw_gemm_huge_ok(a)) return wiw_gemm_huge_launch(s, a);   // gemm_huge.hip
     const bool big = force ? (force[0] != 's') : use_big_tile(a);
     if (MODE == WIW_A_DENSE && (a.epilogue & WIW_EPI_GEGLU))
@@ -938,6 +1012,19 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
         WIW_REQUIRE(a.rowvec == nullptr && a.res1 == nullptr && a.res2 == nullptr, "gemm: GEGLU takes bias only");
         WIW_REQUIRE((((uintptr_t)a.bias) & 15) == 0, "gemm: GEGLU bias must be 16-byte aligned");
         WIW_REQUIRE(a.mode == WIW_A_DENSE, "gemm: GEGLU only in dense mode");
+    }
+    if (a.epilogue & WIW_EPI_LNFOLD) {
+        WIW_REQUIRE(a.mode == WIW_A_DENSE && a.C2 == 0 && a.K == a.C1, "gemm: LayerNorm fold needs dense mode over one source (K = C1)");
+        WIW_REQUIRE(a.lnfold != nullptr && (((uintptr_t)a.lnfold) & 15) == 0 && a.N % 160 == 0,
+                    "gemm: LayerNorm fold needs lnfold = [s | t] (16-byte aligned) and N % 160 == 0");
+        WIW_REQUIRE(a.bias == nullptr && a.alpha == 1.0f, "gemm: LayerNorm fold carries the bias in t and takes alpha = 1");
+        WIW_REQUIRE(!(a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_SILU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)) && a.splitk <= 1,
+                    "gemm: LayerNorm fold goes with the staged 16-bit epilogue only");
+        const int nv = (a.epilogue & WIW_EPI_GEGLU) ? a.n_out : a.N;
+        WIW_REQUIRE(nv % 8 == 0 && a.ldo % 8 == 0 && (a.res1 == nullptr || a.ldr1 % 8 == 0) && (a.res2 == nullptr || a.ldr2 % 8 == 0) &&
+                    (((uintptr_t)a.rowvec) & 15) == 0 && a.rowvec_ld % 4 == 0,
+                    "gemm: LayerNorm fold needs the aligned (staged) output layout");
+        WIW_REQUIRE(a.ln_eps > 0.0f, "gemm: LayerNorm fold needs ln_eps > 0");
     }
     if (a.splitk > 1) {
         WIW_REQUIRE(a.workspace != nullptr, "gemm: split-K needs a workspace of splitk * M * N floats");

@@ -19,6 +19,7 @@ DTYPE_CODES = {torch.bfloat16: 0, torch.float16: 1}   # wiw_dtype() of the two b
 A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1, 2, 3, 4, 5
 EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
+EPI_LNFOLD = 64  # epilogue bit: A is the raw LayerNorm input, W = W * gamma, lnfold = [s | t] (include/wiw_svd.h)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 
 
@@ -75,6 +76,7 @@ class WiwGemmArgs(C.Structure):
         ("rowvec_ld", C.c_int32), ("rows_per_vec", C.c_int32),
         ("alpha", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
         ("epilogue", C.c_int32), ("splitk", C.c_int32), ("workspace", C.c_void_p),
+        ("lnfold", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 
@@ -151,7 +153,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 5:
+        if self.lib.wiw_abi_version() != 6:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -201,7 +203,9 @@ class Hip:
     # ---- operators
     def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, A3=None, C3=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
              rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,
-             ldo=None, epilogue=0, n_out=0, splitk=1):
+             ldo=None, epilogue=0, n_out=0, splitk=1, lnfold=None, ln_eps=1e-5):
+        """lnfold: fp32 [2, N] = (s | t) — A is then the RAW input of a LayerNorm(eps = ln_eps) whose affine is folded into
+        W (= W * gamma) and t (EPI_LNFOLD, include/wiw_svd.h); no LayerNorm pass runs."""
         a = WiwGemmArgs()
         a.A, a.A2, a.W, a.out = _p(A), _p(A2), _p(W), _p(out)
         a.bias, a.rowvec, a.res1, a.res2 = _p(bias), _p(rowvec), _p(res1), _p(res2)
@@ -214,6 +218,9 @@ class Hip:
         a.rowvec_ld, a.rows_per_vec = rowvec_ld, rows_per_vec
         a.alpha, a.beta1, a.beta2 = alpha, beta1, beta2
         a.epilogue = epilogue | (W_TILED if isinstance(W, TiledW) else 0)
+        if lnfold is not None:
+            a.epilogue |= EPI_LNFOLD
+            a.lnfold, a.ln_eps = lnfold.data_ptr(), ln_eps
         if splitk > 1:   # fp32 partial sums of the K ranges: one grow-only scratch buffer per Hip (stream-ordered reuse)
             need = splitk * M * N
             if self._splitk_ws is None or self._splitk_ws.numel() < need:

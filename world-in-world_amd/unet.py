@@ -87,6 +87,18 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     return (tile_weight(wg) if tiled else wg), fold.contiguous()
 
 
+def fold_layernorm(W: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype):
+    """Operands of a GEMM with WIW_EPI_LNFOLD (include/wiw_svd.h): LayerNorm(x; gamma, beta) . W^T + bias as a GEMM on the
+    RAW x.  Returns (W' = W * gamma rounded to `dtype`, lnfold = [s | t] fp32) with s_n = sum_k W'[n][k] of the ROUNDED
+    rows (so the fold is exact for what the MFMAs multiply) and t_n = sum_k W[n][k] * beta[k] + bias_n."""
+    Wf = W.float()
+    wg = (Wf * gamma.float()[None, :]).to(dtype).contiguous()
+    t = Wf @ beta.float()
+    if bias is not None:
+        t = t + bias.float()
+    return wg, torch.stack([wg.float().sum(dim=1), t]).contiguous()
+
+
 @dataclass
 class RequestCond:
     """Step-invariant conditioning of one request (everything but time_embedding(t))."""
@@ -102,9 +114,12 @@ class RequestCond:
 
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
-                 hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16):
+                 hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None):
         """dtype: 16-bit storage type of weights and activations (bf16, or fp16 = the reference's served default,
-        eval_inference.py:294); with `hip` given, its dtype is used."""
+        eval_inference.py:294); with `hip` given, its dtype is used.
+        fold_layernorm: fold norm1 / norm3 / norm_in into their consumer GEMMs at the widths the 256x160 tile serves
+        (WIW_EPI_LNFOLD).  OFF by default: measured -0.7 % on the rollout (the in-kernel row statistics cost the K = 320
+        GEMMs more than the four LayerNorm passes per block they replace); env WIW_LN_FOLD=1 turns it on."""
         self.cfg = cfg
         self.device = torch.device(device)
         self.hip = hip or Hip(self.device, dtype)
@@ -113,6 +128,7 @@ class UNetHIP:
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
         self.no_splitk = bool(os.environ.get("WIW_NO_SPLITK"))     # A/B knob
+        self.ln_fold = bool(os.environ.get("WIW_LN_FOLD")) if fold_layernorm is None else bool(fold_layernorm)
         self.swapped_vt = bool(os.environ.get("WIW_SWAPPED_VT"))   # A/B knob: V^T by a swapped-operand GEMM (round 1)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         self._prepare(state_dict)
@@ -179,10 +195,20 @@ class UNetHIP:
                 temb_b.append(self._t(sd, q + ".time_emb_proj.bias"))
             self.alpha[p] = float(torch.sigmoid(self._t(sd, p + ".time_mixer.mix_factor")).item())
 
-        def ff(p):
-            wp, bp, n_half = pack_geglu(self._t(sd, p + ".net.0.proj.weight"), self._t(sd, p + ".net.0.proj.bias"))
+        def ff(p, ln=None):
+            """ln: prefix of the LayerNorm that feeds this FeedForward; when its width is served by the 256x160 tile
+            (C < 640: the LayerNorm fold lives in gemm.hip) a second, gamma-folded copy of the packed GEGLU projection
+            and its [s | t] vectors are prepared (both packed in the same row order)."""
+            w0, b0 = self._t(sd, p + ".net.0.proj.weight"), self._t(sd, p + ".net.0.proj.bias")
+            wp, bp, n_half = pack_geglu(w0, b0)
             w[p + ".net.0.proj.weight"] = wp.to(bf).contiguous()
             w[p + ".net.0.proj.bias"] = bp.contiguous()
+            if ln is not None and self._fold_ln(w0.shape[1]):
+                gamma, beta = self._t(sd, ln + ".weight"), self._t(sd, ln + ".bias")
+                wgp, tp, _ = pack_geglu(w0 * gamma[None, :], w0 @ beta + b0)
+                wgp = wgp.to(bf).contiguous()
+                w[p + ".net.0.proj.lnfold.weight"] = wgp
+                w[p + ".net.0.proj.lnfold.st"] = torch.stack([wgp.float().sum(dim=1), tp.float()]).contiguous()
             lin(p + ".net.2")
 
         def transformer(p):
@@ -191,8 +217,12 @@ class UNetHIP:
             norm(b + ".norm1"); norm(b + ".norm3"); norm(t + ".norm_in"); norm(t + ".norm1"); norm(t + ".norm3")
             w[b + ".attn1.to_qk.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"),
                                                       self._t(sd, b + ".attn1.to_k.weight")]).to(bf).contiguous()
-            w[b + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"), self._t(sd, b + ".attn1.to_k.weight"),
-                                                       self._t(sd, b + ".attn1.to_v.weight")]).to(bf).contiguous()
+            wqkv = torch.cat([self._t(sd, b + ".attn1.to_q.weight"), self._t(sd, b + ".attn1.to_k.weight"),
+                              self._t(sd, b + ".attn1.to_v.weight")])
+            w[b + ".attn1.to_qkv.weight"] = wqkv.to(bf).contiguous()
+            if self._fold_ln(wqkv.shape[1]) and wqkv.shape[0] % 160 == 0:   # norm1 folded into the q|k|v projection
+                w[b + ".attn1.to_qkv.lnfold.weight"], w[b + ".attn1.to_qkv.lnfold.st"] = fold_layernorm(
+                    wqkv, None, self._t(sd, b + ".norm1.weight"), self._t(sd, b + ".norm1.bias"), bf)
             lin(b + ".attn1.to_v", bias=False); lin(b + ".attn1.to_out.0")
             w[t + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, t + ".attn1.to_q.weight"),
                                                        self._t(sd, t + ".attn1.to_k.weight"),
@@ -204,7 +234,7 @@ class UNetHIP:
                 dtype=bf)
             for q in (b, t):  # single-key cross-attention: only to_v and to_out matter (§9.3)
                 lin(q + ".attn2.to_v", bias=False); lin(q + ".attn2.to_out.0")
-            ff(b + ".ff"); ff(t + ".ff_in"); ff(t + ".ff")
+            ff(b + ".ff", b + ".norm3"); ff(t + ".ff_in", t + ".norm_in"); ff(t + ".ff", t + ".norm3")
             lin(p + ".time_pos_embed.linear_1"); lin(p + ".time_pos_embed.linear_2")
             self.alpha[p] = float(torch.sigmoid(self._t(sd, p + ".time_mixer.mix_factor")).item())
 
@@ -268,6 +298,11 @@ class UNetHIP:
     def _empty(self, *shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
+    def _fold_ln(self, C: int) -> bool:
+        """LayerNorm folded into its consumer GEMM (WIW_EPI_LNFOLD) where that GEMM runs on the 256x160 / 128x160 tile,
+        i.e. K = C < 640 (the C = 320 level of the served network): decided by the layer width, never by the batch."""
+        return C < 640 and self.ln_fold
+
     def _splitk(self, rows_per_item, N, K):
         """Split-K factor of an implicit-GEMM conv.  At the innermost 1280-channel level one candidate has M = 4032 rows:
         16 x 4 = 64 tiles of 256 x 320 for 256 CUs.  Cutting K into 4 ranges (256 items, fp32 partial slabs, a reduce
@@ -302,12 +337,19 @@ class UNetHIP:
         h = self._linear(x_bf16, p + ".linear_1", M, silu=True)
         return self._linear(h, p + ".linear_2", M, out_f32=True)
 
-    def _geglu_ff(self, a, p, M, Cn, **epi_kw):
-        """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue."""
-        W1 = self.w[p + ".net.0.proj.weight"]
+    def _geglu_ff(self, a, p, M, Cn, ln_input=None, **epi_kw):
+        """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue.
+        ln_input: the RAW input of the LayerNorm in front of this FeedForward — given instead of `a` (= None) where the
+        norm is folded into the projection (`_fold_ln`)."""
         g = self._empty(M, 4 * Cn)
-        self.hip.gemm(a, W1, g, M=M, N=W1.shape[0], K=Cn, C1=Cn, bias=self.w[p + ".net.0.proj.bias"],
-                      epilogue=EPI_GEGLU, n_out=4 * Cn)
+        if ln_input is not None:
+            W1 = self.w[p + ".net.0.proj.lnfold.weight"]
+            self.hip.gemm(ln_input, W1, g, M=M, N=W1.shape[0], K=Cn, C1=Cn, epilogue=EPI_GEGLU, n_out=4 * Cn,
+                          lnfold=self.w[p + ".net.0.proj.lnfold.st"], ln_eps=1e-5)
+        else:
+            W1 = self.w[p + ".net.0.proj.weight"]
+            self.hip.gemm(a, W1, g, M=M, N=W1.shape[0], K=Cn, C1=Cn, bias=self.w[p + ".net.0.proj.bias"],
+                          epilogue=EPI_GEGLU, n_out=4 * Cn)
         W2 = self.w[p + ".net.2.weight"]
         out = self._empty(M, Cn)
         return self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"], **epi_kw)
@@ -401,7 +443,14 @@ class UNetHIP:
         xn = hip.groupnorm(x, Cn, None, 0, M, S, w[p + ".norm.weight"], w[p + ".norm.bias"], 1e-6, False)
         h = self._linear(xn, p + ".proj_in", M)
         # ---- spatial block (attention.py:462-582)
-        a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
+        legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
+        # LayerNorm folded into its consumer GEMM where that GEMM runs on the 256x160 tile (`_fold_ln`): the projection
+        # reads the RAW residual stream, the kernel derives mean / rstd of its rows from the operand fragments
+        fold_qkv = (b + ".attn1.to_qkv.lnfold.weight") in w and not self.swapped_vt
+        fold_ff = (b + ".ff.net.0.proj.lnfold.weight") in w and not legacy
+        a = xn
+        if not fold_qkv:
+            a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
         vt = self._empty(Cn, M)
         o = self._empty(M, Cn)
         if self.swapped_vt:     # A/B knob (round-1 form): V^T = Wv . a^T as a second, operand-swapped GEMM
@@ -413,35 +462,41 @@ class UNetHIP:
             # ONE q|k|v projection (the activation is read once, N = 3C fills the tiles better than the 320-row swapped
             # GEMM did: 200 us -> 45 + 65 us at the C = 320 level), then a 64x64-tiled transpose of the V columns
             qkv = self._empty(M, 3 * Cn)
-            hip.gemm(a, w[b + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
+            if fold_qkv:
+                hip.gemm(h, w[b + ".attn1.to_qkv.lnfold.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn,
+                         lnfold=w[b + ".attn1.to_qkv.lnfold.st"], ln_eps=1e-5)
+            else:
+                hip.gemm(a, w[b + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
             hip.transpose(qkv, 3 * Cn, 2 * Cn, M, Cn, vt, M)
             hip.attn_spatial(qkv, 3 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
         # The adds that follow a GEMM in the reference — the single-key cross-attention output (one vector per CFG item,
         # attention.py:545-551, 740-743) and the frame-position embedding (transformer_temporal.py:352-353) — ride in that
         # GEMM's epilogue as its per-row-group vector, so every LayerNorm below is a plain one-read / one-write pass.
-        legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
         if legacy:
             h = self._linear(o, b + ".attn1.to_out.0", M, res1=h)
             a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=h, out=a)
         else:
             h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S)
-            a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
+            if not fold_ff:
+                a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
         am = self.alpha[p]
         # hs + emb is stored instead of hs; the blend below subtracts am * emb again
         fold_emb = abs(1.0 - am) > 1e-4 and not legacy
+        lnin = h if fold_ff else None         # the FeedForwards below take the RAW stream where their norm is folded
         if fold_emb:
-            hm = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0, rowvec=cond.pos_emb[p], rowvec_ld=Cn,
-                                rows_per_vec=S)
+            hm = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0, rowvec=cond.pos_emb[p],
+                                rowvec_ld=Cn, rows_per_vec=S)
             hs = hm                           # = spatial output + emb
-            a = hip.layernorm(hm, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], out=a)
+            if not fold_ff:
+                a = hip.layernorm(hm, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], out=a)
         else:
-            hs = self._geglu_ff(a, b + ".ff", M, Cn, res1=h, ldr1=Cn, beta1=1.0)
+            hs = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0)
             hm = self._empty(M, Cn)
             a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
                               addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
-        hm = self._geglu_ff(a, t + ".ff_in", M, Cn, res1=hm, ldr1=Cn, beta1=1.0)
+        hm = self._geglu_ff(a, t + ".ff_in", M, Cn, ln_input=hm if (fold_ff and fold_emb) else None, res1=hm, ldr1=Cn, beta1=1.0)
         if T <= 14 and not self.temporal_unfused and M * Cn * 2 < (1 << 32):
             # norm1 + to_q/k/v + the 14x14 attention in ONE kernel (temporal.hip): LayerNorm folded into the projection,
             # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor
@@ -458,15 +513,17 @@ class UNetHIP:
                               rows_per_vec=T * S, sum_out=hm, out=a)
         else:
             hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S)
-            a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
+            if not fold_ff:
+                a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
         # AlphaBlender: am*hs + (1-am)*(hm + ff(a)); with hs' = hs + emb stored: am*hs = am*hs' - am*emb, and the
         # epilogue's vector enters as alpha * rowvec with alpha = 1 - am  ->  rowvec = -am / (1 - am) * emb
+        lnin = hm if fold_ff else None
         if fold_emb:
-            hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
-                                beta2=am, rowvec=cond.pos_emb_blend[p], rowvec_ld=Cn, rows_per_vec=S)
+            hb = self._geglu_ff(a, t + ".ff", M, Cn, ln_input=lnin, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs,
+                                ldr2=Cn, beta2=am, rowvec=cond.pos_emb_blend[p], rowvec_ld=Cn, rows_per_vec=S)
         else:
-            hb = self._geglu_ff(a, t + ".ff", M, Cn, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs, ldr2=Cn,
-                                beta2=am)
+            hb = self._geglu_ff(a, t + ".ff", M, Cn, ln_input=lnin, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs,
+                                ldr2=Cn, beta2=am)
         return self._linear(hb, p + ".proj_out", M, res1=x)
 
     # ------------------------------------------------------------------------------------------
