@@ -291,6 +291,21 @@ int wiw_attn_small_bf16(void* stream, const void* QK, int ldqk, int k_col_off, c
  * dp/models/attention_processor.py:2358-2366 as a single GEMM).  rows, C, c0, ldx, ldy multiples of 8. */
 int wiw_transpose_bf16(void* stream, const void* X, int64_t ldx, int c0, int64_t rows, int C, void* Y, int64_t ldy);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fine-tuning step (FTsvd/train_svd.py:844-970) — first entries of that row; the operators' backward kernels are not built.
+ * wiw_adamw_step: torch.optim.AdamW (train_svd.py:653, 1123-1130) on a flat fp32 range, ONE pass: decoupled weight decay,
+ *   moment updates, bias-corrected step; `p16` (may be NULL) receives the refreshed 16-bit copy the GEMMs read.
+ *   All fp32 pointers 16-byte aligned; step counts from 1.
+ * wiw_edm_loss_grad: the EDM loss of one sample and dL/d(model_pred) (train_svd.py:940-952):
+ *   denoised = v c_out + c_skip noisy, c_out = -s / sqrt(s^2 + 1), c_skip = 1 / (s^2 + 1), w = (1 + s^2) / s^2;
+ *   loss = mean(w (denoised - target)^2) = (1 / n) * sum(partial[0 .. n_partial)) (block sums, fixed order);
+ *   grad = 2 w c_out (denoised - target) / n.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step);
+int wiw_edm_loss_grad(void* stream, const float* pred, const float* noisy, const float* target, int64_t n, float sigma,
+                      float* grad, float* partial, int n_partial);
+
 /* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);
 

@@ -1,0 +1,102 @@
+"""Row f2 (the fine-tuning step, FTsvd/train_svd.py:844-970) — oracle side only, CPU.
+
+`oracle/train_oracle.py` (EDM pre-conditioning, conditioning dropout, loss, autograd through the oracle UNet, AdamW) against
+`tests/golden/train_step_tiny.npz`, which `oracle/make_train_golden.py` produced by running the REFERENCE UNet class, its
+`get_action_ids` / `apply_conditioning_dropout` and `torch.optim.AdamW` under autograd.  This pins the checker of the
+backward kernels before any of them exists (f2 is not built yet).
+
+Tolerances: fp32 summation order only — loss 1e-5 relative, prediction and gradients 2e-4 of the tensor's max."""
+import numpy as np
+import torch
+
+import svd_oracle as O
+import train_oracle as TO
+
+
+def _setup(golden):
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = {k: torch.from_numpy(v) for k, v in random_state_dict(cfg, int(g["weight_seed"])).items()}
+    return g, cfg, sd
+
+
+def test_training_step_matches_reference_autograd(golden):
+    g, cfg, sd = _setup(golden)
+    torch.set_num_threads(8)
+    aid = torch.from_numpy(O.action_ids_idx_encode(g["actions"])).float()
+    assert np.array_equal(aid.numpy(), g["action_ids"])
+    loss, pred, grads = TO.training_step(
+        sd, cfg.as_dict(), torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), torch.from_numpy(g["sigmas"]),
+        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+        float(g["noise_aug_strength"]), aid, dropout_prob=float(g["dropout_prob"]), random_p=torch.from_numpy(g["random_p"]))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    ref = torch.from_numpy(g["model_pred"])
+    assert float((pred - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    # every parameter's gradient norm (a parameter the loss does not reach has norm 0 on both sides)
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    assert set(names) <= set(grads), sorted(set(names) - set(grads))[:5]
+    # The single-key cross-attention makes norm2 and attn2.to_q / to_k DEAD in the backward pass too: the
+    # softmax over one key is identically 1, its gradient identically 0.  The reference's autograd leaves 1e-9-level
+    # round-off there (nine orders below the live gradients); the oracle, which never evaluates them, returns none.
+    live_floor = 1e-5 * float(np.median(norms[norms > 0]))
+    worst, dead = 0.0, []
+    for n, nr in zip(names, norms):
+        gn = 0.0 if grads[n] is None else float(grads[n].double().norm())
+        if nr <= live_floor:
+            assert gn <= live_floor, n
+            dead.append(n)
+        else:
+            worst = max(worst, abs(gn - nr) / nr)
+    # ... and `add_embedding` (fps / motion bucket) is overwritten for micro_cond (unet:482): no gradient either
+    is_dead = lambda n: ("transformer_blocks.0.norm2." in n) or (".attn2.to_q." in n) or (".attn2.to_k." in n) or \
+        n.startswith("add_embedding.")  # noqa: E731
+    assert dead and all(is_dead(n) for n in dead), [n for n in dead if not is_dead(n)][:5]
+    assert all(n in dead for n in names if is_dead(n))
+    print(f"[f2 oracle] {len(names)} gradient norms ({len(dead)} dead cross-attention parameters), worst relative deviation "
+          f"of the live ones {worst:.2e}")
+    assert worst <= 1e-3
+    # full gradients of one tensor per operator class
+    n_full = 0
+    for key in g.files:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            r = torch.from_numpy(g[key])
+            assert float((grads[name] - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-12, name
+            n_full += 1
+    assert n_full >= 15
+
+
+def test_conditioning_dropout_cases():
+    ehs, cl, act = torch.ones(4, 1, 8), torch.ones(4, 4, 2, 2), torch.ones(4, 3, 3)
+    p = torch.tensor([0.05, 0.15, 0.25, 0.9])          # prob 0.1: image-embedding only | both | latents only | none
+    e, c, a = TO.apply_conditioning_dropout(ehs, cl, act, 0.1, p)
+    assert e[:, 0, 0].tolist() == [0.0, 0.0, 1.0, 1.0] and c[:, 0, 0, 0].tolist() == [1.0, 0.0, 0.0, 1.0]
+    assert torch.equal(a, act)
+    assert TO.apply_conditioning_dropout(ehs, cl, act, None, p)[0] is ehs
+
+
+def test_edm_inputs_and_loss_identities():
+    """c_skip * noisy + c_out * v with the exact v-prediction of the clean latents gives zero loss; sigma -> timestep."""
+    g = torch.Generator().manual_seed(0)
+    lat, noise = torch.randn(1, 4, 4, 8, 8, generator=g), torch.randn(1, 4, 4, 8, 8, generator=g)
+    s = TO.rand_log_normal((1,), 0.7, 1.6, generator=g)
+    inp, t, noisy = TO.edm_training_inputs(lat, noise, s, torch.randn(1, 4, 8, 8, generator=g))
+    assert inp.shape == (1, 4, 8, 8, 8) and abs(float(t) - 0.25 * float(s.log())) < 1e-6
+    v_exact = (noisy / (s ** 2 + 1) - lat) * ((s ** 2 + 1) ** 0.5 / s)       # solves denoised == latents
+    assert float(TO.edm_loss(v_exact, noisy, lat, s)) < 1e-10
+    assert float(TO.edm_loss(torch.zeros_like(lat), noisy, lat, s)) > 0
+
+
+def test_adamw_matches_torch_optim(golden):
+    g, cfg, sd = _setup(golden)
+    for name in [str(n) for n in g["adamw_names"]]:
+        key = name.replace(".", "__")
+        before, after = torch.from_numpy(g["adamw_before__" + key]), torch.from_numpy(g["adamw_after__" + key])
+        grad = torch.from_numpy(g["grad__" + key])
+        p, m, v = TO.adamw_step(before, grad, torch.zeros_like(before), torch.zeros_like(before), 1, float(g["adamw_lr"]))
+        assert float((p - after).abs().max()) <= 1e-6 * float(after.abs().max()) + 1e-9, name
+        assert torch.equal(before, sd[name])

@@ -115,6 +115,10 @@ EXPORTS = {
     "wiw_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_float, C.c_float]),
     "wiw_transpose_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
+    "wiw_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
+    "wiw_edm_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                    C.c_void_p, C.c_int]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -348,6 +352,23 @@ class Hip:
         self._timed("transpose", 0.0, 4.0 * rows * Cn, lambda: self._ck(
             self.lib.wiw_transpose_bf16(self._stream(), _p(X), ldx, c0, rows, Cn, _p(Y), ldy), "wiw_transpose_bf16"))
         return Y
+
+    def adamw_step(self, p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, p16=None):
+        """torch.optim.AdamW on flat fp32 tensors, in place; `p16` (this Hip's 16-bit dtype) receives the refreshed copy."""
+        assert p.dtype == g.dtype == m.dtype == v.dtype == torch.float32 and p.numel() == g.numel() == m.numel() == v.numel()
+        assert p16 is None or (p16.dtype == self.dtype and p16.numel() == p.numel())
+        self._ck(self.lib.wiw_adamw_step(self._stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), lr, beta1, beta2,
+                                         eps, weight_decay, step), "wiw_adamw_step")
+
+    def edm_loss_grad(self, pred, noisy, target, sigma):
+        """EDM loss of one sample (fp32 tensors of equal shape) and its gradient w.r.t. `pred`: returns (loss 0-d tensor, grad)."""
+        n = pred.numel()
+        grad = torch.empty_like(pred)
+        nb = min(1024, (n + 255) // 256)
+        partial = torch.empty(nb, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_edm_loss_grad(self._stream(), _p(pred), _p(noisy), _p(target), n, float(sigma), _p(grad),
+                                            _p(partial), nb), "wiw_edm_loss_grad")
+        return partial.sum() / n, grad
 
     def emb_combine(self, time, act, noise, Bc, B, T, E, out):
         self._ck(self.lib.wiw_emb_combine(self._stream(), _p(time), _p(act), _p(noise), Bc, B, T, E, _p(out)),

@@ -1,0 +1,81 @@
+"""Fine-tuning step of the action-conditioned SVD UNet — SURVEY.md 8(f) row 2 (`FTsvd/train_svd.py:844-970`).
+
+STATUS: the first layer only.  What exists: the step's host-side preparation (EDM noise level draws, pre-conditioning of
+the UNet input, conditioning dropout — O(latent) elementwise work on 57 k-element tensors, PyTorch as plumbing), the EDM
+loss with its gradient and the AdamW update as HIP kernels (`csrc/train.hip`), and — under `oracle/` — the checker of the
+whole step pinned to the reference's autograd (`oracle/train_oracle.py`, `tests/golden/train_step_tiny.npz`).  What does
+NOT exist: the backward kernels of the UNet operators (dgrad / wgrad GEMM modes, GroupNorm / LayerNorm / GEGLU / attention
+backward) and the gradient reduce-scatter over xGMI; `TrainStep.backward` raises until they do.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from .hip import Hip
+
+
+def rand_log_normal(shape, loc: float = 0.0, scale: float = 1.0, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """train_svd.py:69-72: exp(Normal(loc, scale).icdf(u)), u uniform in [1e-7, 1 - 1e-7]; sigma ~ (0.7, 1.6) for the
+    diffusion noise (:886), (-3.0, 0.5) for the noise on the conditioning image (:876)."""
+    u = torch.rand(shape, generator=generator) * (1 - 2e-7) + 1e-7
+    return torch.distributions.Normal(loc, scale).icdf(u).exp()
+
+
+def apply_conditioning_dropout(ehs: torch.Tensor, cond_latents: torch.Tensor, action_ids: torch.Tensor, prob: Optional[float],
+                               random_p: torch.Tensor):
+    """utils/svd_utils.py:176-241 (micro_cond): image embedding zeroed where p < 2 prob, conditioning latents where
+    prob <= p < 3 prob, actions untouched; `random_p` (bsz,) is the uniform draw."""
+    if prob is None:
+        return ehs, cond_latents, action_ids
+    bsz = ehs.shape[0]
+    ehs = torch.where((random_p < 2 * prob).reshape(bsz, 1, 1), torch.zeros_like(ehs), ehs)
+    keep = 1.0 - ((random_p >= prob).to(cond_latents.dtype) * (random_p < 3 * prob).to(cond_latents.dtype))
+    return ehs, keep.reshape(bsz, 1, 1, 1) * cond_latents, action_ids
+
+
+@dataclass
+class StepInputs:
+    """What one step feeds the UNet and the loss (one sample per GPU, as the reference: train_svd.py:877)."""
+    unet_input: torch.Tensor      # (1,T,8,h,w) fp32: noisy / sqrt(sigma^2 + 1) | conditioning latents
+    timestep: float               # 0.25 ln sigma
+    noisy: torch.Tensor           # (1,T,4,h,w)
+    target: torch.Tensor          # the clean latents
+    sigma: float
+    added_time_ids: torch.Tensor  # (1,3) = (7, 127, noise_aug_strength)
+    ehs: torch.Tensor
+    action_ids: torch.Tensor
+
+
+def prepare_step(latents: torch.Tensor, noise: torch.Tensor, sigma: float, cond_latents: torch.Tensor, ehs: torch.Tensor,
+                 noise_aug_strength: float, action_ids: torch.Tensor, dropout_prob: Optional[float] = None,
+                 random_p: Optional[torch.Tensor] = None) -> StepInputs:
+    """train_svd.py:888-931 for one sample: noisy = latents + sigma noise; input = noisy / sqrt(sigma^2 + 1) concatenated
+    with the (possibly dropped) conditioning latents on the channel axis; t = 0.25 ln sigma."""
+    assert latents.shape[0] == 1 and latents.shape == noise.shape
+    ehs, cond_latents, action_ids = apply_conditioning_dropout(ehs, cond_latents, action_ids, dropout_prob, random_p)
+    noisy = latents + noise * sigma
+    inp = torch.cat([noisy / (sigma ** 2 + 1) ** 0.5, cond_latents.unsqueeze(1).repeat(1, latents.shape[1], 1, 1, 1)], dim=2)
+    tids = torch.tensor([[7.0, 127.0, float(noise_aug_strength)]])
+    return StepInputs(inp, 0.25 * float(torch.log(torch.tensor(float(sigma)))), noisy, latents, float(sigma), tids, ehs, action_ids)
+
+
+class TrainStep:
+    """Loss / optimiser side of the step on the HIP kernels; the UNet backward between them is not built yet."""
+
+    def __init__(self, hip: Hip):
+        self.hip = hip
+
+    def loss_and_grad(self, model_pred: torch.Tensor, step: StepInputs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """EDM loss (train_svd.py:940-952) and dL/d(model_pred), fp32, on the device."""
+        dev = self.hip.device
+        f = lambda t: t.to(dev, torch.float32).contiguous()  # noqa: E731
+        return self.hip.edm_loss_grad(f(model_pred), f(step.noisy), f(step.target), step.sigma)
+
+    def backward(self, *_a, **_k):
+        raise NotImplementedError("the backward kernels of the UNet operators are not built yet (SURVEY.md 8(f) row 2)")
+
+    def adamw(self, p32, g32, m, v, step, lr, p16=None, **kw):
+        self.hip.adamw_step(p32, g32, m, v, step, lr, p16=p16, **kw)
