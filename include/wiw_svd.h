@@ -306,6 +306,21 @@ int wiw_adamw_step(void* stream, float* p, const float* g, float* m, float* v, v
 int wiw_edm_loss_grad(void* stream, const float* pred, const float* noisy, const float* target, int64_t n, float sigma,
                       float* grad, float* partial, int n_partial);
 
+/* Backward building blocks of the same row (16-bit activations and activation gradients, fp32 parameter gradients; all
+ * deterministic: fixed-order partials, no floating-point atomics).  The GEMM-shaped gradients (dX = dY . W, dW = dY^T . X) are
+ * wiw_gemm_bf16 launches on transposed operands (wiw_transpose_bf16), see world-in-world_amd/train.py.
+ *   wiw_colsum          out[p][c] = sum of rows p, p + parts, ... of X[rows][C] (X 16-bit, or fp32 with is_f32): bias gradients,
+ *                       and (parts = 1 over fp32 partials) the final sum of per-wave partials.
+ *   wiw_layernorm_bwd   nn.LayerNorm backward (dp/models/attention.py:659-694 norms): dX (16-bit) and per-wave partials
+ *                       partial[w][0][C] = sum dy xhat, partial[w][1][C] = sum dy, w < wiw_layernorm_bwd_partials(rows).
+ *   wiw_geglu_bwd       GEGLU backward (activations.py:117-123): P = [v | g] the saved projection output [rows][2 Ch],
+ *                       dH [rows][Ch] -> dP [rows][2 Ch]. */
+int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out);
+int64_t wiw_layernorm_bwd_partials(int64_t rows);
+int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps, void* dX,
+                      float* partial);
+int wiw_geglu_bwd(void* stream, const void* P, const void* dH, int64_t rows, int Ch, void* dP);
+
 /* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);
 

@@ -84,3 +84,84 @@ def test_adamw_kernel(golden, dtype):
         opt.step()
         hip.adamw_step(p, gr.to(DEV), m, v, step, 3e-3, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.05)
     assert float((p.cpu() - ref.detach()).abs().max()) <= 5e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# backward building blocks vs torch autograd (fp32 reference on the same 16-bit-rounded inputs)
+# ----------------------------------------------------------------------------------------------
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30)), float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(512, 320, 320), (4032, 1280, 320), (448, 64, 128)])
+def test_linear_backward(M, N, K):
+    import math
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x, w, dy = bf(_rnd(M, K, seed=1)), bf(_rnd(N, K, seed=2) / math.sqrt(K)), bf(_rnd(M, N, seed=3))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    b = torch.zeros(N, requires_grad=True)
+    (xr @ wr.t() + b).backward(dy)
+    d16 = lambda t: t.to(DEV, torch.bfloat16).contiguous()  # noqa: E731
+    dx, dW, db = T.linear_backward(hip, d16(x), d16(w), d16(dy))
+    mx, rms = _rel(dx, xr.grad)
+    print(f"[f2] linear backward {M}x{N}x{K}: dx max_rel={mx:.2e} rms={rms:.2e}; dW {_rel(dW, wr.grad)}; db {_rel(db, b.grad)}")
+    assert mx <= 1.2e-2 and rms <= 4e-3                       # 16-bit output rounding
+    assert _rel(dW, wr.grad)[0] <= 2e-5 and _rel(db, b.grad)[0] <= 2e-5   # fp32 outputs: summation order only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(777, 320), (100, 64), (2000, 1280)])
+def test_layernorm_backward(rows, C):
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x, dy = bf(_rnd(rows, C, seed=1) * 1.5 + 0.3), bf(_rnd(rows, C, seed=2))
+    gamma, beta = 1 + 0.3 * _rnd(C, seed=3), 0.2 * _rnd(C, seed=4)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), gr, br, 1e-5).backward(dy)
+    dX, dg, db = hip.layernorm_bwd(x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16), gamma.to(DEV), rows, C, 1e-5)
+    mx, rms = _rel(dX, xr.grad)
+    print(f"[f2] layernorm backward {rows}x{C}: dx max_rel={mx:.2e} rms={rms:.2e}; dgamma {_rel(dg, gr.grad)[0]:.1e} dbeta {_rel(db, br.grad)[0]:.1e}")
+    assert mx <= 1.2e-2 and rms <= 4e-3
+    assert _rel(dg, gr.grad)[0] <= 5e-5 and _rel(db, br.grad)[0] <= 5e-5
+    dX2, dg2, db2 = hip.layernorm_bwd(x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16), gamma.to(DEV), rows, C, 1e-5)
+    assert torch.equal(dX, dX2) and torch.equal(dg, dg2) and torch.equal(db, db2)      # deterministic
+
+
+@pytest.mark.gpu
+def test_geglu_backward_and_colsum():
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    rows, Ch = 333, 1280
+    P, dH = bf(_rnd(rows, 2 * Ch, seed=1) * 1.5), bf(_rnd(rows, Ch, seed=2))
+    Pr = P.clone().requires_grad_(True)
+    (Pr[:, :Ch] * F.gelu(Pr[:, Ch:])).backward(dH)
+    dP = hip.geglu_bwd(P.to(DEV, torch.bfloat16), dH.to(DEV, torch.bfloat16), rows, Ch)
+    mx, rms = _rel(dP, Pr.grad)
+    print(f"[f2] GEGLU backward: max_rel={mx:.2e} rms={rms:.2e}")
+    assert mx <= 1.2e-2 and rms <= 4e-3
+    X = bf(_rnd(1001, 192, seed=5))
+    cs = hip.colsum(X.to(DEV, torch.bfloat16), 1001, 192)
+    assert _rel(cs, X.sum(0))[0] <= 1e-5
+    assert _rel(hip.colsum(X.to(DEV), 1001, 192, parts=7), X.sum(0))[0] <= 1e-5      # fp32 input path

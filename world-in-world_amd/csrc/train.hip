@@ -74,7 +74,165 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward building blocks (16-bit activations / gradients, fp32 parameter gradients), all deterministic: per-block
+// partials in a fixed order, no floating-point atomics.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// out[p][c] = sum over rows r = p, p + P, p + 2P, ... of X[r][c]  (X 16-bit [rows][C], out fp32 [P][C]); a second launch with
+// P = 1 over the fp32 partials finishes the column sum.  Bias gradients (db = column sums of dY) and the gamma / beta partials.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t rows, int C, int P, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int pidx = blockIdx.y;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int64_t r = pidx; r < rows; r += P) {
+        if constexpr (sizeof(T) == 2) acc += bf2f(((const uint16_t*)X)[r * C + c]);
+        else acc += ((const float*)X)[r * C + c];
+    }
+    out[(int64_t)pidx * C + c] = acc;
+}
+
+// LayerNorm backward, one wave per row (C <= 2048, C % 8 == 0), statistics recomputed from x (two-pass, fp32):
+//   xhat = (x - mean) rstd;  g = dy gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat))
+// and per-WAVE partials of dgamma = sum_rows dy xhat, dbeta = sum_rows dy (fp32 [n_waves][2][C]; summed by colsum_kernel).
+constexpr int LNB_MAXCH = 4;
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
+                                                             const float* __restrict__ gamma, int64_t rows, int C, float eps,
+                                                             uint16_t* __restrict__ dX, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_waves = gridDim.x * 4;
+    const int chunks = C >> 3;
+    const float inv_c = 1.0f / (float)C;
+    float dg[LNB_MAXCH][8], db[LNB_MAXCH][8], gm[LNB_MAXCH][8];
+#pragma unroll
+    for (int k = 0; k < LNB_MAXCH; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dg[k][e] = 0.f; db[k][e] = 0.f;
+            const int chunk = lane + k * 64;
+            gm[k][e] = chunk < chunks ? gamma[chunk * 8 + e] : 0.f;
+        }
+    for (int64_t row = wave_g; row < rows; row += n_waves) {
+        float x[LNB_MAXCH][8], dy[LNB_MAXCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNB_MAXCH; ++k) {
+            const int chunk = lane + k * 64;
+            if (chunk < chunks) {
+                unpack8(*(const uint4*)(X + row * C + chunk * 8), x[k]);
+                unpack8(*(const uint4*)(dY + row * C + chunk * 8), dy[k]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[k][e] = 0.f; dy[k][e] = 0.f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[k][e];
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNB_MAXCH; ++k) {
+            const bool on = lane + k * 64 < chunks;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = on ? x[k][e] - mean : 0.f; x[k][e] = d; q += d * d; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNB_MAXCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = x[k][e] * rstd;
+                x[k][e] = xh;
+                const float g = dy[k][e] * gm[k][e];
+                s1 += g; s2 += g * xh;
+                dg[k][e] += dy[k][e] * xh; db[k][e] += dy[k][e];
+            }
+        s1 = wave_sum(s1) * inv_c; s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+        for (int k = 0; k < LNB_MAXCH; ++k) {
+            const int chunk = lane + k * 64;
+            if (chunk < chunks) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[k][e] * gm[k][e] - s1 - x[k][e] * s2);
+                *(uint4*)(dX + row * C + chunk * 8) = pack8(o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LNB_MAXCH; ++k) {
+        const int chunk = lane + k * 64;
+        if (chunk < chunks) {
+            float* pg = partial + ((int64_t)wave_g * 2) * C + chunk * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pg[e] = dg[k][e]; pg[C + e] = db[k][e]; }
+        }
+    }
+}
+
+// GEGLU backward (activations.py:117-123): forward h = v * gelu_erf(g) with the projection output P = [v | g] ([rows][2 Ch]);
+//   dP[:, :Ch] = dh * gelu(g);   dP[:, Ch:] = dh * v * (Phi(g) + g phi(g))
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restrict__ P, const uint16_t* __restrict__ dH,
+                                                         int64_t rows, int Ch, uint16_t* __restrict__ dP) {
+    const int64_t n = rows * (Ch >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (Ch >> 3);
+        const int c = (int)(i - r * (Ch >> 3)) * 8;
+        float v[8], g[8], dh[8], dv[8], dgt[8];
+        unpack8(*(const uint4*)(P + r * 2 * Ch + c), v);
+        unpack8(*(const uint4*)(P + r * 2 * Ch + Ch + c), g);
+        unpack8(*(const uint4*)(dH + r * Ch + c), dh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = gelu_erf_f(g[e]);                                 // g * Phi(g)
+            const float phi = 0.3989422804014327f * __expf(-0.5f * g[e] * g[e]);
+            const float Phi = fabsf(g[e]) > 1e-6f ? ge / g[e] : 0.5f;
+            dv[e] = dh[e] * ge;
+            dgt[e] = dh[e] * v[e] * (Phi + g[e] * phi);
+        }
+        *(uint4*)(dP + r * 2 * Ch + c) = pack8(dv);
+        *(uint4*)(dP + r * 2 * Ch + Ch + c) = pack8(dgt);
+    }
+}
+
 }  // namespace
+
+extern "C" int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out) {
+    WIW_REQUIRE(X && out && rows > 0 && C > 0 && parts > 0 && parts <= 65535, "colsum: bad arguments");
+    const dim3 grid((unsigned)((C + 255) / 256), (unsigned)parts);
+    if (is_f32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, rows, C, parts, out);
+    else hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, parts, out);
+    return wiw_check_launch("wiw_colsum");
+}
+
+extern "C" int64_t wiw_layernorm_bwd_partials(int64_t rows) {   // number of [2][C] fp32 partial slabs the kernel writes
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    return blocks * 4;
+}
+
+extern "C" int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps,
+                                 void* dX, float* partial) {
+    WIW_REQUIRE(X && dY && gamma && dX && partial, "layernorm_bwd: null pointer");
+    WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LNB_MAXCH * 512, "layernorm_bwd: C must be %8 and <= 2048");
+    const int64_t blocks = wiw_layernorm_bwd_partials(rows) / 4;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                       (const uint16_t*)dY, gamma, rows, C, eps, (uint16_t*)dX, partial);
+    return wiw_check_launch("wiw_layernorm_bwd");
+}
+
+extern "C" int wiw_geglu_bwd(void* stream, const void* P, const void* dH, int64_t rows, int Ch, void* dP) {
+    WIW_REQUIRE(P && dH && dP && rows > 0 && Ch > 0 && Ch % 8 == 0, "geglu_bwd: bad arguments");
+    int64_t blocks = (rows * (Ch >> 3) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)P,
+                       (const uint16_t*)dH, rows, Ch, (uint16_t*)dP);
+    return wiw_check_launch("wiw_geglu_bwd");
+}
 
 extern "C" int wiw_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step) {

@@ -119,6 +119,11 @@ EXPORTS = {
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     "wiw_edm_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_int]),
+    "wiw_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "wiw_layernorm_bwd_partials": (C.c_int64, [C.c_int64]),
+    "wiw_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
+    "wiw_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -369,6 +374,33 @@ class Hip:
         self._ck(self.lib.wiw_edm_loss_grad(self._stream(), _p(pred), _p(noisy), _p(target), n, float(sigma), _p(grad),
                                             _p(partial), nb), "wiw_edm_loss_grad")
         return partial.sum() / n, grad
+
+    # ---- backward building blocks (row f2; csrc/train.hip)
+    def colsum(self, X, rows, Cn, parts=64):
+        """fp32 [Cn] column sums of X [rows, Cn] (16-bit or fp32): two fixed-order launches (partials, then their sum)."""
+        parts = max(1, min(parts, rows))
+        part = torch.empty(parts, Cn, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_colsum(self._stream(), _p(X), int(X.dtype == torch.float32), rows, Cn, parts, _p(part)), "wiw_colsum")
+        if parts == 1:
+            return part[0]
+        out = torch.empty(1, Cn, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_colsum(self._stream(), _p(part), 1, parts, Cn, 1, _p(out)), "wiw_colsum")
+        return out[0]
+
+    def layernorm_bwd(self, X, dY, gamma, rows, Cn, eps=1e-5):
+        """-> (dX 16-bit [rows, Cn], dgamma fp32 [Cn], dbeta fp32 [Cn])."""
+        nw = int(self.lib.wiw_layernorm_bwd_partials(rows))
+        part = torch.empty(nw, 2 * Cn, dtype=torch.float32, device=self.device)
+        dX = torch.empty(rows, Cn, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_layernorm_bwd(self._stream(), _p(X), _p(dY), _p(gamma), rows, Cn, eps, _p(dX), _p(part)),
+                 "wiw_layernorm_bwd")
+        s = self.colsum(part, nw, 2 * Cn, parts=1)
+        return dX, s[:Cn], s[Cn:]
+
+    def geglu_bwd(self, P, dH, rows, Ch):
+        dP = torch.empty(rows, 2 * Ch, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_geglu_bwd(self._stream(), _p(P), _p(dH), rows, Ch, _p(dP)), "wiw_geglu_bwd")
+        return dP
 
     def emb_combine(self, time, act, noise, Bc, B, T, E, out):
         self._ck(self.lib.wiw_emb_combine(self._stream(), _p(time), _p(act), _p(noise), Bc, B, T, E, _p(out)),

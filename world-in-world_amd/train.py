@@ -62,6 +62,38 @@ def prepare_step(latents: torch.Tensor, noise: torch.Tensor, sigma: float, cond_
     return StepInputs(inp, 0.25 * float(torch.log(torch.tensor(float(sigma)))), noisy, latents, float(sigma), tids, ehs, action_ids)
 
 
+# ------------------------------------------------------------------------------------------------
+# backward building blocks on the existing kernels (no new GEMM code: the gradients of a GEMM are GEMMs on transposed operands)
+# ------------------------------------------------------------------------------------------------
+def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True):
+    """Backward of y = x . W^T (+ b) with x [M, K], W [N, K], dy [M, N] in the Hip's 16-bit type (M, N, K % 64 == 0):
+         dx [M, K] (16-bit)  = dy . W              -> wiw_gemm_bf16(A = dy, W = W^T)
+         dW [N, K] (fp32)    = dy^T . x            -> wiw_gemm_bf16(A = dy^T, W = x^T, fp32 output): K loop over the M rows
+         db [N]   (fp32)     = column sums of dy   -> wiw_colsum
+       (`nn.Linear` backward, attention_processor.py:2358-2391 / attention.py:1185-1243 call sites).  The transposes are
+       wiw_transpose_bf16 passes; fp32 accumulation over all M rows inside the MFMA K loop."""
+    from .hip import EPI_OUT_F32
+
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape == (N, K) and dy.shape == (M, N) and M % 64 == 0 and N % 64 == 0 and K % 64 == 0
+    dev, dt = hip.device, hip.dtype
+    dx = None
+    if need_dx:
+        Wt = torch.empty(K, N, dtype=dt, device=dev)
+        hip.transpose(W, K, 0, N, K, Wt, N)
+        dx = torch.empty(M, K, dtype=dt, device=dev)
+        hip.gemm(dy, Wt, dx, M=M, N=K, K=N, C1=N)
+    dyT = torch.empty(N, M, dtype=dt, device=dev)
+    hip.transpose(dy, N, 0, M, N, dyT, M)
+    xT = torch.empty(K, M, dtype=dt, device=dev)
+    hip.transpose(x, K, 0, M, K, xT, M)
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    hip.gemm(dyT, xT, dW, M=N, N=K, K=M, C1=M, epilogue=EPI_OUT_F32)
+    db = hip.colsum(dy, M, N) if need_db else None
+    return dx, dW, db
+
+
 class TrainStep:
     """Loss / optimiser side of the step on the HIP kernels; the UNet backward between them is not built yet."""
 
