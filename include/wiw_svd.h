@@ -320,6 +320,17 @@ int64_t wiw_layernorm_bwd_partials(int64_t rows);
 int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps, void* dX,
                       float* partial);
 int wiw_geglu_bwd(void* stream, const void* P, const void* dH, int64_t rows, int Ch, void* dP);
+/*   wiw_groupnorm_bwd   GroupNorm(32)(+SiLU) backward (dp/models/resnet.py:320-373, 594-631 norms) on [rows][C], units of
+ *                       rows_per_unit rows, stats = (mean, variance) per (unit, group) from wiw_groupnorm_stats:
+ *                       dX (16-bit); unit_cs[unit][0][C] = sum dz, unit_cs[unit][1][C] = sum dz xhat (dbeta / dgamma = their sums
+ *                       over the units: wiw_colsum); scratch: AB [units][32][2], partial [units][splits][2][C] floats with
+ *                       splits = ceil(rows_per_unit / rows_per_block). */
+/*   wiw_gather_taps_bf16  im2col rows for the weight gradient of the implicit-GEMM convolutions: Xcol[m][tap*C + c] = X[src(m, tap)][c]
+ *                       (zeros outside the image / clip); 9 taps (3x3, pad 1 over (H, Wd)) or, with temporal != 0, 3 taps over T. */
+int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol);
+int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, const float* stats, const float* gamma, const float* beta,
+                      int64_t rows, int C, int rows_per_unit, float eps, int silu, void* dX, float* unit_cs, float* AB,
+                      float* partial, int rows_per_block);
 
 /* Utility: fill fp32 buffer. */
 int wiw_fill_f32(void* stream, float* p, int64_t n, float value);

@@ -165,3 +165,71 @@ def test_geglu_backward_and_colsum():
     cs = hip.colsum(X.to(DEV, torch.bfloat16), 1001, 192)
     assert _rel(cs, X.sum(0))[0] <= 1e-5
     assert _rel(hip.colsum(X.to(DEV), 1001, 192, parts=7), X.sum(0))[0] <= 1e-5      # fp32 input path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,C,h,w,unit_frames,silu", [(4, 320, 6, 8, 1, True), (4, 64, 4, 8, 2, True), (2, 1280, 3, 4, 1, False)])
+def test_groupnorm_backward(n, C, h, w, unit_frames, silu):
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x, dy = bf(_rnd(n, C, h, w, seed=1) * 1.7 + 0.5), bf(_rnd(n, C, h, w, seed=2))
+    gamma, beta = 1 + 0.3 * _rnd(C, seed=3), 0.2 * _rnd(C, seed=4)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    # units of `unit_frames` frames: statistics over (frames, H, W) of the unit = GroupNorm on a (units, C, frames*H, W) view
+    xv = xr.reshape(n // unit_frames, unit_frames, C, h, w).permute(0, 2, 1, 3, 4).reshape(n // unit_frames, C, unit_frames * h, w)
+    y = F.group_norm(xv, 32, gr, br, 1e-5)
+    y = F.silu(y) if silu else y
+    y = y.reshape(n // unit_frames, C, unit_frames, h, w).permute(0, 2, 1, 3, 4).reshape(n, C, h, w)
+    y.backward(dy)
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, C).to(DEV, torch.bfloat16).contiguous()  # noqa: E731
+    rows = n * h * w
+    dX, dg, db = hip.groupnorm_bwd(tok(x), tok(dy), gamma.to(DEV), beta.to(DEV), rows, C, unit_frames * h * w, 1e-5, silu)
+    ref = xr.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    mx, rms = _rel(dX, ref)
+    print(f"[f2] groupnorm backward C={C} unit={unit_frames} silu={silu}: dx max_rel={mx:.2e} rms={rms:.2e}; "
+          f"dgamma {_rel(dg, gr.grad)[0]:.1e} dbeta {_rel(db, br.grad)[0]:.1e}")
+    assert mx <= 1.2e-2 and rms <= 4e-3
+    assert _rel(dg, gr.grad)[0] <= 1e-4 and _rel(db, br.grad)[0] <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("temporal", [False, True])
+def test_conv_backward(temporal):
+    import math
+
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    B, Tn, cin, cout, h, w = 2, 4, 64, 128, 8, 8
+    x, dy = bf(_rnd(B * Tn, cin, h, w, seed=1)), bf(_rnd(B * Tn, cout, h, w, seed=2))
+    xr = x.clone().requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    if temporal:
+        wt = bf(_rnd(cout, cin, 3, 1, 1, seed=3) / math.sqrt(3 * cin)).requires_grad_(True)
+        x5 = xr.reshape(B, Tn, cin, h, w).permute(0, 2, 1, 3, 4)
+        y = F.conv3d(x5, wt, b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(B * Tn, cout, h, w)
+        wk = wt.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, -1)
+    else:
+        wt = bf(_rnd(cout, cin, 3, 3, seed=3) / math.sqrt(9 * cin)).requires_grad_(True)
+        y = F.conv2d(xr, wt, b, padding=1)
+        wk = wt.detach().permute(0, 2, 3, 1).reshape(cout, -1)
+    y.backward(dy)
+    tok = lambda t, c: t.permute(0, 2, 3, 1).reshape(-1, c).to(DEV, torch.bfloat16).contiguous()  # noqa: E731
+    dx, dW, db = T.conv_backward(hip, tok(x, cin), wk.to(DEV, torch.bfloat16).contiguous(), tok(dy, cout), h, w, T=Tn,
+                                 temporal=temporal)
+    ref_dx = xr.grad.permute(0, 2, 3, 1).reshape(-1, cin)
+    ref_dw = (wt.grad[:, :, :, 0, 0].permute(0, 2, 1) if temporal else wt.grad.permute(0, 2, 3, 1)).reshape(cout, -1)
+    mx, rms = _rel(dx, ref_dx)
+    print(f"[f2] conv backward temporal={temporal}: dx max_rel={mx:.2e} rms={rms:.2e}; dW {_rel(dW, ref_dw)[0]:.1e} db {_rel(db, b.grad)[0]:.1e}")
+    assert mx <= 1.2e-2 and rms <= 4e-3
+    assert _rel(dW, ref_dw)[0] <= 2e-5 and _rel(db, b.grad)[0] <= 2e-5

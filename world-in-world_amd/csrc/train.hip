@@ -199,7 +199,187 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restri
     }
 }
 
+// GroupNorm(32) (+ SiLU) backward on token-major [rows][C] tensors, units of `rows_per_unit` rows (a frame, or a clip for the
+// temporal blocks), statistics (mean, biased variance) per (unit, group) from wiw_groupnorm_stats:
+//   xhat = (x - mean_g) rstd_g;  z = xhat gamma_c + beta_c;  y = silu(z) | z;  dz = dy silu'(z) | dy
+//   dgamma_c = sum dz xhat, dbeta_c = sum dz;  per (unit, group): A = sum dz gamma, B = sum dz gamma xhat, n = rows cg
+//   dx = rstd_g (dz gamma_c - A / n - xhat B / n)
+// Pass 1 (gnb_reduce): per (unit, row split) block partials of sum dz and sum dz xhat per channel, fixed order.
+// Pass 2 (gnb_finish): sums the splits of a unit in split order -> unit_cs[unit][2][C] and AB[unit][32][2].
+// Pass 3 (gnb_apply): elementwise dx.
+constexpr int GNB_GROUPS = 32;
+WIW_DEV float gnb_dz(float dy, float z, int silu) {
+    if (!silu) return dy;
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return dy * sg * (1.0f + z * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void gnb_reduce_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int C, int rows_per_unit,
+                                                          int rows_per_block, float eps, int silu, float* __restrict__ partial) {
+    __shared__ float red[256][17];
+    const int tid = threadIdx.x;
+    const int chunks = C >> 3, cg = C / GNB_GROUPS;
+    const int cpb = chunks < 256 ? chunks : 256, rp = 256 / cpb;
+    const int ci = tid % cpb, rl = tid / cpb;
+    const int unit = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows_per_unit ? r0 + rows_per_block : rows_per_unit;
+    const int64_t base = (int64_t)unit * rows_per_unit;
+    for (int cbase = 0; cbase < chunks; cbase += cpb) {
+        const int chunk = cbase + ci;
+        float a[8], b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+        if (rl < rp && chunk < chunks) {
+            const int c0 = chunk * 8;
+            float mean[8], rstd[8], gm[8], bt[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (c0 + e) / cg;
+                mean[e] = stats[((int64_t)unit * GNB_GROUPS + g) * 2];
+                rstd[e] = rsqrtf(stats[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] + eps);
+                gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e];
+            }
+            for (int r = r0 + rl; r < r1; r += rp) {
+                float x[8], dy[8];
+                unpack8(*(const uint4*)(X + (base + r) * C + c0), x);
+                unpack8(*(const uint4*)(dY + (base + r) * C + c0), dy);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (x[e] - mean[e]) * rstd[e];
+                    const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, gm[e], bt[e]), silu);
+                    a[e] += dz; b[e] = __builtin_fmaf(dz, xh, b[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[tid][e] = a[e]; red[tid][8 + e] = b[e]; }
+        __syncthreads();
+        for (int t = tid; t < cpb * 16; t += 256) {       // (chunk column, value index): row lanes summed in lane order
+            const int cc = t >> 4, e = t & 15;
+            if (cbase + cc < chunks) {
+                float sum = 0.f;
+                for (int j = 0; j < rp; ++j) sum += red[j * cpb + cc][e];
+                float* dst = partial + (((int64_t)unit * gridDim.x + blockIdx.x) * 2 + (e >> 3)) * C + (cbase + cc) * 8 + (e & 7);
+                *dst = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gnb_finish_kernel(const float* __restrict__ partial, int splits, int C,
+                                                          const float* __restrict__ gamma, float* __restrict__ unit_cs,
+                                                          float* __restrict__ AB) {
+    __shared__ float sA[4096], sB[4096];
+    const int unit = blockIdx.x, cg = C / GNB_GROUPS;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int sidx = 0; sidx < splits; ++sidx) {
+            a += partial[(((int64_t)unit * splits + sidx) * 2) * C + c];
+            b += partial[(((int64_t)unit * splits + sidx) * 2 + 1) * C + c];
+        }
+        unit_cs[((int64_t)unit * 2) * C + c] = a;
+        unit_cs[((int64_t)unit * 2 + 1) * C + c] = b;
+        sA[c] = a * gamma[c]; sB[c] = b * gamma[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < GNB_GROUPS) {
+        float a = 0.f, b = 0.f;
+        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { a += sA[c]; b += sB[c]; }
+        AB[((int64_t)unit * GNB_GROUPS + threadIdx.x) * 2] = a;
+        AB[((int64_t)unit * GNB_GROUPS + threadIdx.x) * 2 + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gnb_apply_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
+                                                         const float* __restrict__ stats, const float* __restrict__ AB,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int64_t rows, int C, int rows_per_unit, float eps, int silu,
+                                                         uint16_t* __restrict__ dX) {
+    const int chunks = C >> 3, cg = C / GNB_GROUPS;
+    const float inv_n = 1.0f / ((float)rows_per_unit * (float)cg);
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c0 = (int)(i - r * chunks) * 8;
+        const int unit = (int)(r / rows_per_unit);
+        float x[8], dy[8], o[8];
+        unpack8(*(const uint4*)(X + r * C + c0), x);
+        unpack8(*(const uint4*)(dY + r * C + c0), dy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c0 + e) / cg;
+            const float mean = stats[((int64_t)unit * GNB_GROUPS + g) * 2];
+            const float rstd = rsqrtf(stats[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] + eps);
+            const float A = AB[((int64_t)unit * GNB_GROUPS + g) * 2] * inv_n, B = AB[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] * inv_n;
+            const float xh = (x[e] - mean) * rstd;
+            const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, gamma[c0 + e], beta[c0 + e]), silu);
+            o[e] = rstd * (dz * gamma[c0 + e] - A - xh * B);
+        }
+        *(uint4*)(dX + r * C + c0) = pack8(o);
+    }
+}
+
+// im2col rows for the weight gradient of the implicit-GEMM convolutions: Xcol[m][tap * C + c] = X[src(m, tap)][c] (zeros
+// outside the image / clip), taps = 9 (3x3, pad 1 over (H, W)) or 3 ((3,1,1) over T).  dW = dY^T . Xcol is then ONE GEMM
+// whose K loop runs over the M rows (world-in-world_amd/train.py); 16 bytes per thread and tap.
+__global__ __launch_bounds__(256) void gather_taps_kernel(const uint16_t* __restrict__ X, int64_t M, int C, int H, int W, int T,
+                                                           int temporal, uint16_t* __restrict__ Xcol) {
+    const int chunks = C >> 3, taps = temporal ? 3 : 9;
+    const int HW = H * W;
+    const int64_t total = M * taps * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % chunks);
+        const int64_t mt = i / chunks;
+        const int tap = (int)(mt % taps);
+        const int64_t m = mt / taps;
+        int64_t src = -1;
+        if (temporal) {
+            const int t = (int)((m / HW) % T) + tap - 1;
+            if (t >= 0 && t < T) src = m + (int64_t)(tap - 1) * HW;
+        } else {
+            const int rem = (int)(m % HW), y = rem / W + tap / 3 - 1, x = rem % W + tap % 3 - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) src = m + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1);
+        }
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (src >= 0) v = *(const uint4*)(X + src * C + ch * 8);
+        *(uint4*)(Xcol + (m * taps + tap) * C + ch * 8) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol) {
+    WIW_REQUIRE(X && Xcol && M > 0 && C > 0 && C % 8 == 0 && H > 0 && Wd > 0, "gather_taps: bad arguments");
+    WIW_REQUIRE(M % ((int64_t)H * Wd) == 0 && (!temporal || (T > 0 && (M / ((int64_t)H * Wd)) % T == 0)), "gather_taps: bad geometry");
+    int64_t blocks = (M * (temporal ? 3 : 9) * (C >> 3) + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(gather_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, M, C, H,
+                       Wd, T, temporal, (uint16_t*)Xcol);
+    return wiw_check_launch("wiw_gather_taps_bf16");
+}
+
+extern "C" int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, const float* stats, const float* gamma,
+                                 const float* beta, int64_t rows, int C, int rows_per_unit, float eps, int silu, void* dX,
+                                 float* unit_cs, float* AB, float* partial, int rows_per_block) {
+    WIW_REQUIRE(X && dY && stats && gamma && beta && dX && unit_cs && AB && partial, "groupnorm_bwd: null pointer");
+    WIW_REQUIRE(C > 0 && C % 8 == 0 && C % GNB_GROUPS == 0 && C <= 4096, "groupnorm_bwd: C must be %8, %32 and <= 4096");
+    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0 && rows_per_block > 0, "groupnorm_bwd: bad rows");
+    const int units = (int)(rows / rows_per_unit);
+    const int splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gnb_reduce_kernel, dim3(splits, units), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
+                       gamma, beta, C, rows_per_unit, rows_per_block, eps, silu, partial);
+    hipLaunchKernelGGL(gnb_finish_kernel, dim3(units), dim3(256), 0, s, partial, splits, C, gamma, unit_cs, AB);
+    int64_t blocks = (rows * (C >> 3) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
+                       AB, gamma, beta, rows, C, rows_per_unit, eps, silu, (uint16_t*)dX);
+    return wiw_check_launch("wiw_groupnorm_bwd");
+}
 
 extern "C" int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out) {
     WIW_REQUIRE(X && out && rows > 0 && C > 0 && parts > 0 && parts <= 65535, "colsum: bad arguments");

@@ -124,6 +124,9 @@ EXPORTS = {
     "wiw_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p]),
     "wiw_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "wiw_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "wiw_gather_taps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -396,6 +399,33 @@ class Hip:
                  "wiw_layernorm_bwd")
         s = self.colsum(part, nw, 2 * Cn, parts=1)
         return dX, s[:Cn], s[Cn:]
+
+    def groupnorm_bwd(self, X, dY, gamma, beta, rows, Cn, rows_per_unit, eps, silu, stats=None):
+        """GroupNorm(32)(+SiLU) backward -> (dX 16-bit, dgamma fp32 [Cn], dbeta fp32 [Cn]).  stats: (mean, var) per (unit, group)
+        from the forward; recomputed with wiw_groupnorm_stats when None."""
+        units = rows // rows_per_unit
+        if stats is None:
+            rpb = self.gn_rows_per_block(rows_per_unit, False)
+            stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
+            self._ck(self.lib.wiw_groupnorm_stats(self._stream(), _p(X), Cn, None, 0, rows, rows_per_unit, rpb, stats.data_ptr(),
+                                                  scratch.data_ptr()), "wiw_groupnorm_stats")
+        rpb_b = 256
+        splits = -(-rows_per_unit // rpb_b)
+        dX = torch.empty(rows, Cn, dtype=self.dtype, device=self.device)
+        unit_cs = torch.empty(units, 2 * Cn, dtype=torch.float32, device=self.device)
+        AB = torch.empty(units * 64, dtype=torch.float32, device=self.device)
+        partial = torch.empty(units * splits * 2 * Cn, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_groupnorm_bwd(self._stream(), _p(X), _p(dY), _p(stats), _p(gamma), _p(beta), rows, Cn, rows_per_unit,
+                                            eps, int(bool(silu)), _p(dX), _p(unit_cs), _p(AB), _p(partial), rpb_b),
+                 "wiw_groupnorm_bwd")
+        s = self.colsum(unit_cs, units, 2 * Cn, parts=1)
+        return dX, s[Cn:], s[:Cn]
+
+    def gather_taps(self, X, M, Cn, H, Wd, T=1, temporal=False):
+        """im2col rows [M, taps*Cn] of X [M, Cn] for the conv weight gradients (9 taps, or 3 temporal ones)."""
+        out = torch.empty(M, (3 if temporal else 9) * Cn, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), _p(out)), "wiw_gather_taps_bf16")
+        return out
 
     def geglu_bwd(self, P, dH, rows, Ch):
         dP = torch.empty(rows, 2 * Ch, dtype=self.dtype, device=self.device)

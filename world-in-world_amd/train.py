@@ -94,6 +94,37 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
     return dx, dW, db
 
 
+def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor, H: int, Wd: int, T: int = 1,
+                  temporal: bool = False, need_dx: bool = True):
+    """Backward of the stride-1 implicit-GEMM convolutions of `wiw_gemm_bf16`: 3x3 pad 1 (ResnetBlock2D convs, resnet.py:269,285)
+    or, temporal=True, (3,1,1) pad 1 over T (TemporalResnetBlock, resnet.py:570-592).  x [M, Cin] token-major, Wk [Cout, taps*Cin]
+    in the kernel's layout ([Cout][ky][kx][Cin] / [Cout][kt][Cin]), dy [M, Cout]; Cin, Cout, M % 64 == 0.
+        dx  = the SAME convolution of dy with the taps mirrored and the channel roles swapped (W2[ci][tap'][co] = W[co][tap][ci])
+        dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: wiw_gather_taps_bf16 + two transposes + one GEMM over the M rows)
+        db  = column sums of dy
+    (the stride-2 / upsampling variants are not covered yet)."""
+    from .hip import A_CONV3X3, A_CONV_T3, EPI_OUT_F32
+
+    M, Cin = x.shape
+    Cout = Wk.shape[0]
+    taps = 3 if temporal else 9
+    assert Wk.shape == (Cout, taps * Cin) and dy.shape == (M, Cout) and M % 64 == 0 and Cin % 64 == 0 and Cout % 64 == 0
+    dev, dt = hip.device, hip.dtype
+    dx = None
+    if need_dx:
+        W2 = Wk.reshape(Cout, taps, Cin).flip(1).permute(2, 1, 0).reshape(Cin, taps * Cout).contiguous()   # host re-layout
+        dx = torch.empty(M, Cin, dtype=dt, device=dev)
+        hip.gemm(dy, W2, dx, M=M, N=Cin, K=taps * Cout, C1=Cout, mode=A_CONV_T3 if temporal else A_CONV3X3, H=H, Wd=Wd, T=T)
+    xcol = hip.gather_taps(x, M, Cin, H, Wd, T, temporal)
+    xcolT = torch.empty(taps * Cin, M, dtype=dt, device=dev)
+    hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, M)
+    dyT = torch.empty(Cout, M, dtype=dt, device=dev)
+    hip.transpose(dy, Cout, 0, M, Cout, dyT, M)
+    dW = torch.empty(Cout, taps * Cin, dtype=torch.float32, device=dev)
+    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=M, C1=M, epilogue=EPI_OUT_F32)
+    return dx, dW, hip.colsum(dy, M, Cout)
+
+
 class TrainStep:
     """Loss / optimiser side of the step on the HIP kernels; the UNet backward between them is not built yet."""
 
