@@ -317,9 +317,12 @@ int wiw_edm_loss_grad(void* stream, const float* pred, const float* noisy, const
  *                       dH [rows][Ch] -> dP [rows][2 Ch]. */
 int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out);
 int64_t wiw_layernorm_bwd_partials(int64_t rows);
-int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps, void* dX,
-                      float* partial);
+int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps,
+                      const void* dRes /* or NULL: gradient of the residual path, added to dX */, void* dX, float* partial);
 int wiw_geglu_bwd(void* stream, const void* P, const void* dH, int64_t rows, int Ch, void* dP);
+/*   wiw_geglu_fwd       H = v * gelu_erf(g) from a SAVED projection output P = [v | g] (the training forward keeps P for
+ *                       wiw_geglu_bwd; inference fuses this into the GEMM epilogue on packed weights). */
+int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H);
 /*   wiw_groupnorm_bwd   GroupNorm(32)(+SiLU) backward (dp/models/resnet.py:320-373, 594-631 norms) on [rows][C], units of
  *                       rows_per_unit rows, stats = (mean, variance) per (unit, group) from wiw_groupnorm_stats:
  *                       dX (16-bit); unit_cs[unit][0][C] = sum dz, unit_cs[unit][1][C] = sum dz xhat (dbeta / dgamma = their sums

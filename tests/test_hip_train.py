@@ -233,3 +233,38 @@ def test_conv_backward(temporal):
     print(f"[f2] conv backward temporal={temporal}: dx max_rel={mx:.2e} rms={rms:.2e}; dW {_rel(dW, ref_dw)[0]:.1e} db {_rel(db, b.grad)[0]:.1e}")
     assert mx <= 1.2e-2 and rms <= 4e-3
     assert _rel(dW, ref_dw)[0] <= 2e-5 and _rel(db, b.grad)[0] <= 2e-5
+
+
+@pytest.mark.gpu
+def test_feedforward_block_forward_backward():
+    """One residual FeedForward sub-block composed from the building blocks: every gradient against torch autograd."""
+    import math
+
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    M, C = 1024, 320
+    x, dy = bf(_rnd(M, C, seed=1) * 1.3 + 0.2), bf(_rnd(M, C, seed=2))
+    prm = dict(gamma=1 + 0.3 * _rnd(C, seed=3), beta=0.2 * _rnd(C, seed=4), W1=bf(_rnd(8 * C, C, seed=5) / math.sqrt(C)),
+               b1=0.1 * _rnd(8 * C, seed=6), W2=bf(_rnd(C, 4 * C, seed=7) / math.sqrt(4 * C)), b2=0.1 * _rnd(C, seed=8))
+    ref = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+    xr = x.clone().requires_grad_(True)
+    pr = F.layer_norm(xr, (C,), ref["gamma"], ref["beta"], 1e-5) @ ref["W1"].t() + ref["b1"]
+    yr = xr + (pr[:, :4 * C] * F.gelu(pr[:, 4 * C:])) @ ref["W2"].t() + ref["b2"]
+    yr.backward(dy)
+    dev16 = lambda t: t.to(DEV, torch.bfloat16).contiguous()  # noqa: E731
+    blk = T.FeedForwardTrain(hip, prm["gamma"].to(DEV), prm["beta"].to(DEV), dev16(prm["W1"]), prm["b1"].to(DEV),
+                             dev16(prm["W2"]), prm["b2"].to(DEV))
+    y = blk.forward(dev16(x))
+    assert _rel(y, yr)[1] <= 4e-3
+    dx, grads = blk.backward(dev16(dy))
+    print(f"[f2] FeedForward block: y rms={_rel(y, yr)[1]:.2e} dx rms={_rel(dx, xr.grad)[1]:.2e} " +
+          " ".join(f"d{k} {_rel(g, ref[k].grad)[1]:.1e}" for k, g in grads.items()))
+    assert _rel(dx, xr.grad)[1] <= 6e-3                      # three 16-bit roundings on the way back
+    for k, g in grads.items():                               # 16-bit activation gradients feed the fp32 sums: rounding-noise class
+        assert _rel(g, ref[k].grad)[1] <= 8e-3, k

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 constexpr int LNB_MAXCH = 4;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
                                                              const float* __restrict__ gamma, int64_t rows, int C, float eps,
-                                                             uint16_t* __restrict__ dX, float* __restrict__ partial) {
+                                                             const uint16_t* __restrict__ dRes, uint16_t* __restrict__ dX,
+                                                             float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n_waves = gridDim.x * 4;
@@ -159,6 +160,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const uint16_t* __re
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rstd * (dy[k][e] * gm[k][e] - s1 - x[k][e] * s2);
+                if (dRes) {   // gradient arriving through the residual connection around the normalised branch
+                    float rr[8];
+                    unpack8(*(const uint4*)(dRes + row * C + chunk * 8), rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += rr[e];
+                }
                 *(uint4*)(dX + row * C + chunk * 8) = pack8(o);
             }
         }
@@ -350,7 +357,32 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const uint16_t* __rest
     }
 }
 
+// GEGLU forward on a SAVED projection output (training keeps P = [v | g] for the backward; inference fuses this into the
+// GEMM epilogue on packed weights): H[r][c] = v * gelu_erf(g)
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ P, int64_t rows, int Ch, uint16_t* __restrict__ Hh) {
+    const int64_t n = rows * (Ch >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (Ch >> 3);
+        const int c = (int)(i - r * (Ch >> 3)) * 8;
+        float v[8], g[8];
+        unpack8(*(const uint4*)(P + r * 2 * Ch + c), v);
+        unpack8(*(const uint4*)(P + r * 2 * Ch + Ch + c), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
+        *(uint4*)(Hh + r * Ch + c) = pack8(v);
+    }
+}
+
 }  // namespace
+
+extern "C" int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H) {
+    WIW_REQUIRE(P && H && rows > 0 && Ch > 0 && Ch % 8 == 0, "geglu_fwd: bad arguments");
+    int64_t blocks = (rows * (Ch >> 3) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)P, rows, Ch,
+                       (uint16_t*)H);
+    return wiw_check_launch("wiw_geglu_fwd");
+}
 
 extern "C" int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol) {
     WIW_REQUIRE(X && Xcol && M > 0 && C > 0 && C % 8 == 0 && H > 0 && Wd > 0, "gather_taps: bad arguments");
@@ -396,12 +428,12 @@ extern "C" int64_t wiw_layernorm_bwd_partials(int64_t rows) {   // number of [2]
 }
 
 extern "C" int wiw_layernorm_bwd(void* stream, const void* X, const void* dY, const float* gamma, int64_t rows, int C, float eps,
-                                 void* dX, float* partial) {
+                                 const void* dRes, void* dX, float* partial) {
     WIW_REQUIRE(X && dY && gamma && dX && partial, "layernorm_bwd: null pointer");
     WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LNB_MAXCH * 512, "layernorm_bwd: C must be %8 and <= 2048");
     const int64_t blocks = wiw_layernorm_bwd_partials(rows) / 4;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
-                       (const uint16_t*)dY, gamma, rows, C, eps, (uint16_t*)dX, partial);
+                       (const uint16_t*)dY, gamma, rows, C, eps, (const uint16_t*)dRes, (uint16_t*)dX, partial);
     return wiw_check_launch("wiw_layernorm_bwd");
 }
 

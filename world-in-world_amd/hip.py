@@ -122,11 +122,12 @@ EXPORTS = {
     "wiw_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wiw_layernorm_bwd_partials": (C.c_int64, [C.c_int64]),
     "wiw_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
-                                    C.c_void_p]),
+                                    C.c_void_p, C.c_void_p]),
     "wiw_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wiw_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "wiw_gather_taps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wiw_geglu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -390,12 +391,12 @@ class Hip:
         self._ck(self.lib.wiw_colsum(self._stream(), _p(part), 1, parts, Cn, 1, _p(out)), "wiw_colsum")
         return out[0]
 
-    def layernorm_bwd(self, X, dY, gamma, rows, Cn, eps=1e-5):
-        """-> (dX 16-bit [rows, Cn], dgamma fp32 [Cn], dbeta fp32 [Cn])."""
+    def layernorm_bwd(self, X, dY, gamma, rows, Cn, eps=1e-5, dres=None):
+        """-> (dX 16-bit [rows, Cn], dgamma fp32 [Cn], dbeta fp32 [Cn]); dres: gradient of a residual path, added to dX."""
         nw = int(self.lib.wiw_layernorm_bwd_partials(rows))
         part = torch.empty(nw, 2 * Cn, dtype=torch.float32, device=self.device)
         dX = torch.empty(rows, Cn, dtype=self.dtype, device=self.device)
-        self._ck(self.lib.wiw_layernorm_bwd(self._stream(), _p(X), _p(dY), _p(gamma), rows, Cn, eps, _p(dX), _p(part)),
+        self._ck(self.lib.wiw_layernorm_bwd(self._stream(), _p(X), _p(dY), _p(gamma), rows, Cn, eps, _p(dres), _p(dX), _p(part)),
                  "wiw_layernorm_bwd")
         s = self.colsum(part, nw, 2 * Cn, parts=1)
         return dX, s[:Cn], s[Cn:]
@@ -426,6 +427,11 @@ class Hip:
         out = torch.empty(M, (3 if temporal else 9) * Cn, dtype=self.dtype, device=self.device)
         self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), _p(out)), "wiw_gather_taps_bf16")
         return out
+
+    def geglu_fwd(self, P, rows, Ch):
+        H = torch.empty(rows, Ch, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_geglu_fwd(self._stream(), _p(P), rows, Ch, _p(H)), "wiw_geglu_fwd")
+        return H
 
     def geglu_bwd(self, P, dH, rows, Ch):
         dP = torch.empty(rows, 2 * Ch, dtype=self.dtype, device=self.device)

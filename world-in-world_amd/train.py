@@ -125,6 +125,41 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     return dx, dW, hip.colsum(dy, M, Cout)
 
 
+class FeedForwardTrain:
+    """Forward-with-saved-activations and backward of ONE residual FeedForward sub-block,
+        y = x + W2 . GEGLU(W1 . LayerNorm(x) + b1) + b2        (BasicTransformerBlock norm3 + ff, attention.py:565-582),
+    composed from the building blocks above: the template for the full-network orchestration that does not exist yet.
+    Weights are 16-bit copies [N, K] (natural row order, no GEGLU packing), gradients fp32."""
+
+    def __init__(self, hip: Hip, gamma, beta, W1, b1, W2, b2, eps: float = 1e-5):
+        self.hip, self.eps = hip, eps
+        self.gamma, self.beta, self.W1, self.b1, self.W2, self.b2 = gamma, beta, W1, b1, W2, b2
+        self.C = W1.shape[1]
+        assert W1.shape == (8 * self.C, self.C) and W2.shape == (self.C, 4 * self.C)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        hip, C = self.hip, self.C
+        M = x.shape[0]
+        self.x = x
+        self.a = hip.layernorm(x, M, C, self.gamma, self.beta, self.eps)
+        self.P = torch.empty(M, 8 * C, dtype=hip.dtype, device=hip.device)
+        hip.gemm(self.a, self.W1, self.P, M=M, N=8 * C, K=C, C1=C, bias=self.b1)          # saved for the GEGLU backward
+        self.h = hip.geglu_fwd(self.P, M, 4 * C)
+        y = torch.empty(M, C, dtype=hip.dtype, device=hip.device)
+        hip.gemm(self.h, self.W2, y, M=M, N=C, K=4 * C, C1=4 * C, bias=self.b2, res1=x, ldr1=C, beta1=1.0)
+        return y
+
+    def backward(self, dy: torch.Tensor):
+        """-> (dx, {name: fp32 gradient})."""
+        hip, C = self.hip, self.C
+        M = dy.shape[0]
+        dh, dW2, db2 = linear_backward(hip, self.h, self.W2, dy)
+        dP = hip.geglu_bwd(self.P, dh, M, 4 * C)
+        da, dW1, db1 = linear_backward(hip, self.a, self.W1, dP)
+        dx, dgamma, dbeta = hip.layernorm_bwd(self.x, da, self.gamma, M, C, self.eps, dres=dy)   # residual join inside the kernel
+        return dx, dict(gamma=dgamma, beta=dbeta, W1=dW1, b1=db1, W2=dW2, b2=db2)
+
+
 class TrainStep:
     """Loss / optimiser side of the step on the HIP kernels; the UNet backward between them is not built yet."""
 
