@@ -181,3 +181,63 @@ def test_sharded_worker_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ShardedAdamW (row f2): reduce-scatter of gradients, sharded AdamW, all-gather of parameters == AdamW on the mean gradient
+# ----------------------------------------------------------------------------------------------------------------
+def _adamw_torch(p, g, m, v, step, lr, b1, b2, eps, wd):      # the update Hip.adamw_step performs on the GPU
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+
+
+def _zero_run(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from wiw_amd.parallel import ShardedAdamW
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes = {"a.weight": (37, 5), "a.bias": (37,), "b.weight": (64, 33), "c": (1,)}       # ragged sizes, 3 buckets
+        g0 = torch.Generator().manual_seed(0)
+        init = {k: torch.randn(*s, generator=g0) for k, s in shapes.items()}
+        opt = ShardedAdamW(shapes, torch.device("cpu"), _adamw_torch, bucket_elems=1024, lr=1e-2, weight_decay=0.05)
+        opt.load(init)
+        assert opt.n_buckets == 3 and opt.master.numel() == 3 * opt.slice
+        ref = {k: v.clone().requires_grad_(True) for k, v in init.items()}
+        ropt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.05)
+        for step in range(3):
+            mean_grads = {}
+            for k, s in shapes.items():
+                per_rank = [torch.randn(*s, generator=torch.Generator().manual_seed(100 * step + 10 * r + len(k))) for r in range(world)]
+                opt.view(opt.grads, k).copy_(per_rank[rank])          # this rank's local gradient
+                mean_grads[k] = sum(per_rank) / world
+            if step == 1:
+                opt.reduce_bucket(opt.n_buckets - 1)                   # a bucket handed over early by the backward
+            opt.step()
+            for k in shapes:
+                ref[k].grad = mean_grads[k]
+            ropt.step()
+        err = max(float((opt.view(opt.params, k) - ref[k].detach()).abs().max()) for k in shapes)
+        full = [None] * world
+        dist.all_gather_object(full, opt.params.clone())
+        if rank == 0:
+            q.put((err, bool(all(torch.equal(full[0], f) for f in full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_adamw_equals_adamw_on_the_mean_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, same = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err <= 2e-6 and same       # every rank holds the same updated parameters
