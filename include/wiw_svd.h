@@ -328,6 +328,16 @@ int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H);
  *                       dX (16-bit); unit_cs[unit][0][C] = sum dz, unit_cs[unit][1][C] = sum dz xhat (dbeta / dgamma = their sums
  *                       over the units: wiw_colsum); scratch: AB [units][32][2], partial [units][splits][2][C] floats with
  *                       splits = ceil(rows_per_unit / rows_per_block). */
+/*   wiw_attn_bwd_bf16   self-attention backward (F.scaled_dot_product_attention, attention_processor.py:2383-2385), head_dim 64,
+ *                       `seqs` sequences of S rows at row stride Sp (Sp % 16 == 0): QKV [seqs*Sp][ld] with Q | K | V of head h at
+ *                       columns h*64, k_off + h*64, v_off + h*64;  Qt, Kt, dOt = transposes [heads*64][ldt] of the Q and K column
+ *                       blocks and of dO (wiw_transpose_bf16);  O, dO [rows][ldo];  dQKV [rows][ldd] receives dQ | dK | dV at the
+ *                       same column offsets;  lse, dsum: fp32 [seqs*heads*Sp] scratch (row log-sum-exp in the log2 domain and
+ *                       D = sum_d dO O, written by the first kernel, read by the second).  FIRST form: one wave per 16-row tile,
+ *                       operands from global memory, scores recomputed; deterministic, not tuned. */
+int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt, const void* dOt,
+                      int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd, float* lse, float* dsum, int seqs,
+                      int S, int Sp, int heads, int head_dim, float scale);
 /*   wiw_gather_taps_bf16  im2col rows for the weight gradient of the implicit-GEMM convolutions: Xcol[m][tap*C + c] = X[src(m, tap)][c]
  *                       (zeros outside the image / clip); 9 taps (3x3, pad 1 over (H, Wd)) or, with temporal != 0, 3 taps over T. */
 int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol);

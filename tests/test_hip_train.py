@@ -268,3 +268,37 @@ def test_feedforward_block_forward_backward():
     assert _rel(dx, xr.grad)[1] <= 6e-3                      # three 16-bit roundings on the way back
     for k, g in grads.items():                               # 16-bit activation gradients feed the fp32 sums: rounding-noise class
         assert _rel(g, ref[k].grad)[1] <= 8e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seqs,S,heads", [(2, 128, 1), (3, 144, 2), (1, 512, 5), (2, 16, 1)])
+def test_attention_backward(seqs, S, heads):
+    """dQ, dK, dV of softmax(Q K^T / 8) V against torch autograd on the same 16-bit-rounded q, k, v, dO (O from the forward
+    kernel).  Probabilities and dS pass through 16 bits inside the kernel: attention-class tolerance 2e-2 / 8e-3."""
+    import torch.nn.functional as F
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    C, M = heads * 64, seqs * S
+    qkv, dO = bf(_rnd(M, 3 * C, seed=1)), bf(_rnd(M, C, seed=2))
+    leaf = qkv.clone().requires_grad_(True)
+
+    def hd(t):
+        return t.reshape(seqs, S, heads, 64).transpose(1, 2)
+
+    o_ref = F.scaled_dot_product_attention(hd(leaf[:, :C]), hd(leaf[:, C:2 * C]), hd(leaf[:, 2 * C:])).transpose(1, 2).reshape(M, C)
+    o_ref.backward(dO)
+    qkv_d, dO_d = qkv.to(DEV, torch.bfloat16), dO.to(DEV, torch.bfloat16)
+    vt = torch.empty(C, M, dtype=torch.bfloat16, device=DEV)
+    hip.transpose(qkv_d, 3 * C, 2 * C, M, C, vt, M)
+    O = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial(qkv_d, 3 * C, C, vt, M, O, C, seqs, S, heads, 0.125)
+    dqkv = hip.attn_backward(qkv_d, O, dO_d, seqs, S, heads, 0.125)
+    for name, sl in (("dQ", slice(0, C)), ("dK", slice(C, 2 * C)), ("dV", slice(2 * C, 3 * C))):
+        mx, rms = _rel(dqkv[:, sl], leaf.grad[:, sl])
+        print(f"[f2] attention backward {seqs}x{S}x{heads} {name}: max_rel={mx:.2e} rms={rms:.2e}")
+        assert mx <= 2e-2 and rms <= 8e-3, name
+    assert torch.equal(dqkv, hip.attn_backward(qkv_d, O, dO_d, seqs, S, heads, 0.125))

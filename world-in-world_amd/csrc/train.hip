@@ -373,7 +373,219 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Self-attention backward (F.scaled_dot_product_attention of attention_processor.py:2383-2385), head_dim D, sequences of S
+// rows at a row stride of Sp (S <= Sp, Sp % 16 == 0).  FIRST, simple form: one wave per (sequence, head, 16-row tile),
+// operands straight from global memory, 16-deep contraction steps on the 16x16x32 MFMA (upper half of its K zero), the
+// scores recomputed from Q, K and the saved row log-sum-exp.  Correct and deterministic; NOT tuned (every wave re-reads
+// all keys / queries of its sequence through L2) — the LDS-tiled version follows the forward kernel's structure.
+//   S = scale Q K^T, P = softmax(S), O = P V;   D_q = sum_d dO O
+//   dS = P (dO V^T - D);   dQ = scale dS K;   dK = scale dS^T Q;   dV = P^T dO
+// Kernel 1 (per query tile): row LSE (log2 domain) + D (written out for kernel 2) and dQ  — contracts over keys, needs K^T.
+// Kernel 2 (per key tile): dK, dV — contracts over queries, needs Q^T and dO^T.  (wiw_transpose_bf16 makes the transposes.)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+                                                           const uint16_t* __restrict__ Kt, int64_t ldt,
+                                                           const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, int ldo,
+                                                           uint16_t* __restrict__ dQKV, int ldd, float* __restrict__ LSE,
+                                                           float* __restrict__ Dsum, int S, int Sp, int heads, int q_tiles,
+                                                           int64_t total, float scale, float scale_log2e) {
+    constexpr int NKK = D / 32, NDB = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= total) return;
+    const int qt = (int)(task % q_tiles);
+    const int h = (int)((task / q_tiles) % heads);
+    const int64_t seq = task / ((int64_t)q_tiles * heads);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t row0 = seq * Sp;
+    const int qi = qt * 16 + fr;                     // < Sp (Sp % 16 == 0)
+    bf16x8 qf[NKK], dof[NKK];
+    float dsum = 0.f;
+    {
+        const uint16_t* qs = QKV + (row0 + qi) * ld + h * D;
+        const uint16_t* os = O + (row0 + qi) * ldo + h * D;
+        const uint16_t* ds = dO + (row0 + qi) * ldo + h * D;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            qf[kk] = *(const bf16x8*)(qs + kk * 32 + fq * 8);
+            dof[kk] = *(const bf16x8*)(ds + kk * 32 + fq * 8);
+            float a[8], b[8];
+            unpack8(*(const uint4*)(os + kk * 32 + fq * 8), a);
+            unpack8(*(const uint4*)(ds + kk * 32 + fq * 8), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum = __builtin_fmaf(a[e], b[e], dsum);
+        }
+    }
+    dsum = xor32_sum(xor16_sum(dsum));               // D of query fr (the four fq lanes hold the four quarters of d)
+    const int nkt = (S + 15) / 16;
+    // ---- pass 1: row log-sum-exp (log2 domain)
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const uint16_t* ksrc = QKV + (row0 + kt * 16 + fr) * ld + k_off + h * D;
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) st = WIW_MFMA(*(const bf16x8*)(ksrc + kk * 32 + fq * 8), qf[kk], st);
+        float mx = -INFINITY, sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sv[r] = (kt * 16 + fq * 4 + r) < S ? st[r] * scale_log2e : -INFINITY; mx = fmaxf(mx, sv[r]); }
+        mx = xor32_max(xor16_max(mx));
+        const float m_new = fmaxf(m_run, mx);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(sv[r] - m_new);
+        ls = xor32_sum(xor16_sum(ls));
+        l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + ls;
+        m_run = m_new;
+    }
+    const float lse2 = m_run + __builtin_amdgcn_logf(l_run);     // log2(sum_k 2^(s_k))
+    if (fq == 0) {
+        LSE[(seq * heads + h) * Sp + qi] = lse2;
+        Dsum[(seq * heads + h) * Sp + qi] = dsum;
+    }
+    // ---- pass 2: dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+    f32x4 dq[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+        const uint16_t* ksrc = QKV + (row0 + kt * 16 + fr) * ld + k_off + h * D;
+        const uint16_t* vsrc = QKV + (row0 + kt * 16 + fr) * ld + v_off + h * D;
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            st = WIW_MFMA(*(const bf16x8*)(ksrc + kk * 32 + fq * 8), qf[kk], st);    // lane: query fr, keys 4 fq + r
+            dp = WIW_MFMA(*(const bf16x8*)(vsrc + kk * 32 + fq * 8), dof[kk], dp);   // dP^T = V dO^T, same layout
+        }
+        float dsv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = (kt * 16 + fq * 4 + r) < S;
+            const float pr = ok ? __builtin_amdgcn_exp2f(st[r] * scale_log2e - lse2) : 0.f;
+            dsv[r] = pr * (dp[r] - dsum);
+        }
+        union { uint32_t u[4]; bf16x8 v; } dso;
+        dso.u[0] = pack2bf(dsv[0], dsv[1]); dso.u[1] = pack2bf(dsv[2], dsv[3]); dso.u[2] = 0u; dso.u[3] = 0u;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const uint2 kv = *(const uint2*)(Kt + (int64_t)(h * D + db * 16 + fr) * ldt + row0 + kt * 16 + fq * 4);
+            union { uint32_t u[4]; bf16x8 v; } ko;
+            ko.u[0] = kv.x; ko.u[1] = kv.y; ko.u[2] = 0u; ko.u[3] = 0u;
+            dq[db] = WIW_MFMA(ko.v, dso.v, dq[db]);      // lane: query fr, d = 16 db + 4 fq + r
+        }
+    }
+    uint16_t* dst = dQKV + (row0 + qi) * ldd + h * D + fq * 4;
+    const float sc = qi < S ? scale : 0.f;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        uint2 pk;
+        pk.x = pack2bf(dq[db][0] * sc, dq[db][1] * sc);
+        pk.y = pack2bf(dq[db][2] * sc, dq[db][3] * sc);
+        *(uint2*)(dst + db * 16) = pk;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+                                                            const uint16_t* __restrict__ Qt, const uint16_t* __restrict__ dOt,
+                                                            int64_t ldt, const uint16_t* __restrict__ dO, int ldo,
+                                                            uint16_t* __restrict__ dQKV, int ldd, const float* __restrict__ LSE,
+                                                            const float* __restrict__ Dsum, int S, int Sp, int heads, int k_tiles,
+                                                            int64_t total, float scale, float scale_log2e) {
+    constexpr int NKK = D / 32, NDB = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= total) return;
+    const int kt = (int)(task % k_tiles);
+    const int h = (int)((task / k_tiles) % heads);
+    const int64_t seq = task / ((int64_t)k_tiles * heads);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t row0 = seq * Sp;
+    const int ki = kt * 16 + fr;                      // this lane's key (B operand column)
+    bf16x8 kf[NKK], vf[NKK];
+    {
+        const uint16_t* ks = QKV + (row0 + ki) * ld + k_off + h * D;
+        const uint16_t* vs = QKV + (row0 + ki) * ld + v_off + h * D;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) { kf[kk] = *(const bf16x8*)(ks + kk * 32 + fq * 8); vf[kk] = *(const bf16x8*)(vs + kk * 32 + fq * 8); }
+    }
+    const bool key_ok = ki < S;
+    f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = dk[db]; }
+    const int nqt = (S + 15) / 16;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const uint16_t* qsrc = QKV + (row0 + qt * 16 + fr) * ld + h * D;       // A operand rows = queries
+        const uint16_t* dsrc = dO + (row0 + qt * 16 + fr) * ldo + h * D;
+        f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            sm = WIW_MFMA(*(const bf16x8*)(qsrc + kk * 32 + fq * 8), kf[kk], sm);    // lane: key fr, queries 4 fq + r
+            dp = WIW_MFMA(*(const bf16x8*)(dsrc + kk * 32 + fq * 8), vf[kk], dp);    // dP = dO V^T, same layout
+        }
+        const float4 l4 = *(const float4*)(LSE + (seq * heads + h) * Sp + qt * 16 + fq * 4);
+        const float4 d4 = *(const float4*)(Dsum + (seq * heads + h) * Sp + qt * 16 + fq * 4);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = key_ok && (qt * 16 + fq * 4 + r) < S;
+            pv[r] = ok ? __builtin_amdgcn_exp2f(sm[r] * scale_log2e - lv[r]) : 0.f;
+            dsv[r] = pv[r] * (dp[r] - dd[r]);
+        }
+        union { uint32_t u[4]; bf16x8 v; } po, dso;
+        po.u[0] = pack2bf(pv[0], pv[1]); po.u[1] = pack2bf(pv[2], pv[3]); po.u[2] = 0u; po.u[3] = 0u;
+        dso.u[0] = pack2bf(dsv[0], dsv[1]); dso.u[1] = pack2bf(dsv[2], dsv[3]); dso.u[2] = 0u; dso.u[3] = 0u;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int64_t trow = (int64_t)(h * D + db * 16 + fr) * ldt + row0 + qt * 16 + fq * 4;
+            const uint2 a1 = *(const uint2*)(dOt + trow), a2 = *(const uint2*)(Qt + trow);
+            union { uint32_t u[4]; bf16x8 v; } x1, x2;
+            x1.u[0] = a1.x; x1.u[1] = a1.y; x1.u[2] = 0u; x1.u[3] = 0u;
+            x2.u[0] = a2.x; x2.u[1] = a2.y; x2.u[2] = 0u; x2.u[3] = 0u;
+            dv[db] = WIW_MFMA(x1.v, po.v, dv[db]);       // dV^T[d][key] += dO^T[d][q] P[q][key];  lane: key fr, d = 16 db + 4 fq + r
+            dk[db] = WIW_MFMA(x2.v, dso.v, dk[db]);      // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+    }
+    uint16_t* dkd = dQKV + (row0 + ki) * ldd + k_off + h * D + fq * 4;
+    uint16_t* dvd = dQKV + (row0 + ki) * ldd + v_off + h * D + fq * 4;
+    const float sc = key_ok ? scale : 0.f;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        uint2 pk;
+        pk.x = pack2bf(dk[db][0] * sc, dk[db][1] * sc); pk.y = pack2bf(dk[db][2] * sc, dk[db][3] * sc);
+        *(uint2*)(dkd + db * 16) = pk;
+        pk.x = pack2bf(dv[db][0], dv[db][1]); pk.y = pack2bf(dv[db][2], dv[db][3]);
+        if (!key_ok) pk = uint2{0u, 0u};
+        *(uint2*)(dvd + db * 16) = pk;
+    }
+}
+
 }  // namespace
+
+extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
+                                 const void* dOt, int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd,
+                                 float* lse, float* dsum, int seqs, int S, int Sp, int heads, int head_dim, float scale) {
+    WIW_REQUIRE(QKV && Qt && Kt && dOt && O && dO && dQKV && lse && dsum, "attn_bwd: null pointer");
+    WIW_REQUIRE(seqs > 0 && S > 0 && heads > 0 && Sp >= S && Sp % 16 == 0, "attn_bwd: bad sizes (Sp % 16 == 0)");
+    WIW_REQUIRE(head_dim == 64, "attn_bwd: head_dim 64 only");
+    WIW_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldt % 4 == 0 && ldo % 8 == 0 && ldd % 4 == 0,
+                "attn_bwd: misaligned strides");
+    const int tiles = Sp / 16;
+    const int64_t total = (int64_t)seqs * heads * tiles;
+    WIW_REQUIRE(total < (1ll << 32), "attn_bwd: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    const float LOG2E_ = 1.4426950408889634f;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
+                       v_off, (const uint16_t*)Kt, ldt, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum,
+                       S, Sp, heads, tiles, total, scale, scale * LOG2E_);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<64>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
+                       v_off, (const uint16_t*)Qt, (const uint16_t*)dOt, ldt, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
+                       dsum, S, Sp, heads, tiles, total, scale, scale * LOG2E_);
+    return wiw_check_launch("wiw_attn_bwd_bf16");
+}
 
 extern "C" int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H) {
     WIW_REQUIRE(P && H && rows > 0 && Ch > 0 && Ch % 8 == 0, "geglu_fwd: bad arguments");

@@ -128,6 +128,9 @@ EXPORTS = {
                                     C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "wiw_gather_taps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wiw_geglu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "wiw_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_float]),
     "wiw_fill_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_softmax_rows_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
     "wiw_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -421,6 +424,24 @@ class Hip:
                  "wiw_groupnorm_bwd")
         s = self.colsum(unit_cs, units, 2 * Cn, parts=1)
         return dX, s[Cn:], s[:Cn]
+
+    def attn_backward(self, qkv, O, dO, seqs, S, heads, scale):
+        """Self-attention backward for the fused q|k|v layout of the spatial block: qkv [seqs*S, 3C], O / dO [seqs*S, C]
+        (C = heads*64, S % 16 == 0) -> d_qkv [seqs*S, 3C]."""
+        Cn, M = heads * 64, seqs * S
+        assert S % 16 == 0 and qkv.shape == (M, 3 * Cn) and O.shape == (M, Cn) and dO.shape == (M, Cn)
+        dt, dev = self.dtype, self.device
+        Qt, Kt, dOt = (torch.empty(Cn, M, dtype=dt, device=dev) for _ in range(3))
+        self.transpose(qkv, 3 * Cn, 0, M, Cn, Qt, M)
+        self.transpose(qkv, 3 * Cn, Cn, M, Cn, Kt, M)
+        self.transpose(dO, Cn, 0, M, Cn, dOt, M)
+        dqkv = torch.empty(M, 3 * Cn, dtype=dt, device=dev)
+        lse = torch.empty(seqs * heads * S, dtype=torch.float32, device=dev)
+        dsum = torch.empty_like(lse)
+        self._ck(self.lib.wiw_attn_bwd_bf16(self._stream(), _p(qkv), 3 * Cn, Cn, 2 * Cn, _p(Qt), _p(Kt), _p(dOt), M, _p(O), _p(dO),
+                                            Cn, _p(dqkv), 3 * Cn, _p(lse), _p(dsum), seqs, S, S, heads, 64, scale),
+                 "wiw_attn_bwd_bf16")
+        return dqkv
 
     def gather_taps(self, X, M, Cn, H, Wd, T=1, temporal=False):
         """im2col rows [M, taps*Cn] of X [M, Cn] for the conv weight gradients (9 taps, or 3 temporal ones)."""
