@@ -339,8 +339,19 @@ int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_of
                       int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd, float* lse, float* dsum, int seqs,
                       int S, int Sp, int heads, int head_dim, float scale);
 /*   wiw_gather_taps_bf16  im2col rows for the weight gradient of the implicit-GEMM convolutions: Xcol[m][tap*C + c] = X[src(m, tap)][c]
- *                       (zeros outside the image / clip); 9 taps (3x3, pad 1 over (H, Wd)) or, with temporal != 0, 3 taps over T. */
-int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol);
+ *                       (zeros outside the image / clip); 9 taps (3x3 pad 1 over (H, Wd); stride 2: output (H, Wd), input
+ *                       (2H, 2Wd)) or, with temporal != 0, 3 taps over T.
+ *   wiw_axpby_bf16      out = a x + b y (y may be NULL): residual joins and gradient fan-in.
+ *   wiw_silu_bf16       out = silu(x), or with backward != 0: out = dy silu'(x)  (the embedding MLPs, embeddings.py:804-816).
+ *   wiw_dot_bf16        block partials of sum x (y - z) (z may be NULL): the AlphaBlender mix-factor gradient.
+ *   wiw_row_map_bf16    structured row re-orderings [rows][C]: 0 nearest upsample x2, 1 dilate x2 (gradient of the stride-2
+ *                       conv as a stride-1 conv), 2 sum-pool 2x2 (gradient of the upsample), 3 (b,t,s) -> (b,s,t padded to Tp)
+ *                       and 4 back (temporal attention as per-site sequences). */
+int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, int stride, void* Xcol);
+int wiw_axpby_bf16(void* stream, const void* X, const void* Y, float a, float b, int64_t n, void* out);
+int wiw_silu_bf16(void* stream, const void* X, const void* dY, int backward, int64_t n, void* out);
+int wiw_dot_bf16(void* stream, const void* X, const void* Y, const void* Z, int64_t n, float* partial, int n_partial);
+int wiw_row_map_bf16(void* stream, const void* X, int mode, int64_t out_rows, int C, int H, int Wd, int T, int Tp, int S, void* out);
 int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, const float* stats, const float* gamma, const float* beta,
                       int64_t rows, int C, int rows_per_unit, float eps, int silu, void* dX, float* unit_cs, float* AB,
                       float* partial, int rows_per_block);

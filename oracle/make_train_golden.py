@@ -47,7 +47,7 @@ def main():
 
     torch.set_num_threads(8)
     cfg = UNetConfig.tiny(4)
-    T, h, w = cfg.num_frames, 16, 32
+    T, h, w = cfg.num_frames, 32, 64   # L3 is 4 x 8 = 32 sites: the attention backward kernels need S % 16 == 0
     m = ref_unet(ns, cfg, seed=7).float().train()
     for prm in m.parameters():
         prm.requires_grad_(True)

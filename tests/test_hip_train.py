@@ -302,3 +302,59 @@ def test_attention_backward(seqs, S, heads):
         print(f"[f2] attention backward {seqs}x{S}x{heads} {name}: max_rel={mx:.2e} rms={rms:.2e}")
         assert mx <= 2e-2 and rms <= 8e-3, name
     assert torch.equal(dqkv, hip.attn_backward(qkv_d, O, dO_d, seqs, S, heads, 0.125))
+
+
+@pytest.mark.gpu
+def test_unet_training_step_matches_reference_gradients(golden):
+    """The WHOLE step on the HIP kernels — un-fused training forward of the tiny UNet, EDM loss, backward through every
+    operator — against the reference's own `loss.backward()` (tests/golden/train_step_tiny.npz).  Activations and their
+    gradients are 16-bit: prediction within the forward's parity class, gradient norms within a few percent."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.train_unet import UNetTrain
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    hip = Hip(torch.device(DEV))
+    net = UNetTrain(cfg, random_state_dict(cfg, int(g["weight_seed"])), DEV, hip=hip)
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]),
+                        dropout_prob=float(g["dropout_prob"]), random_p=torch.from_numpy(g["random_p"]))
+    pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
+    mx, rms = _rel(pred, torch.from_numpy(g["model_pred"]))
+    print(f"[f2] training forward vs the reference prediction: max_rel={mx:.2e} rms={rms:.2e}")
+    assert rms <= 3e-2
+    loss, dpred = T.TrainStep(hip).loss_and_grad(pred, st)
+    print(f"[f2] loss {float(loss):.6f} (reference {float(g['loss']):.6f})")
+    assert abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    grads = net.backward(dpred.reshape(pred.shape))
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    is_dead = lambda n: ("transformer_blocks.0.norm2." in n) or (".attn2.to_q." in n) or (".attn2.to_k." in n) or \
+        n.startswith("add_embedding.")  # noqa: E731
+    dev, missing = [], []
+    for n, nr in zip(names, norms):
+        if is_dead(n):
+            assert n not in grads, n
+            continue
+        if n not in grads:
+            missing.append(n)
+            continue
+        assert tuple(grads[n].shape) == tuple(net.master[n].shape), (n, grads[n].shape)
+        dev.append((abs(float(grads[n].double().norm()) - nr) / max(nr, 1e-7), n))
+    assert not missing, missing[:8]
+    dev.sort(reverse=True)
+    print("[f2] gradient norms vs the reference: median rel dev %.2e, 90%% %.2e, worst %s" % (
+        dev[len(dev) // 2][0], dev[len(dev) // 10][0], dev[:3]))
+    full = []
+    for key in g.files:
+        if key.startswith("grad__"):
+            name = key[len("grad__"):].replace("__", ".")
+            full.append((_rel(grads[name], torch.from_numpy(g[key]))[1], name))
+    full.sort(reverse=True)
+    print("[f2] full gradients (rms rel error): " + ", ".join(f"{n.split('.')[-2]}.{n.split('.')[-1]} {e:.1e}" for e, n in full))
+    assert dev[len(dev) // 2][0] <= 2e-2 and dev[len(dev) // 10][0] <= 6e-2
+    assert full[len(full) // 2][0] <= 5e-2 and full[0][0] <= 0.25

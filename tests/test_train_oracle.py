@@ -42,23 +42,23 @@ def test_training_step_matches_reference_autograd(golden):
     # The single-key cross-attention makes norm2 and attn2.to_q / to_k DEAD in the backward pass too: the
     # softmax over one key is identically 1, its gradient identically 0.  The reference's autograd leaves 1e-9-level
     # round-off there (nine orders below the live gradients); the oracle, which never evaluates them, returns none.
-    live_floor = 1e-5 * float(np.median(norms[norms > 0]))
-    worst, dead = 0.0, []
-    for n, nr in zip(names, norms):
-        gn = 0.0 if grads[n] is None else float(grads[n].double().norm())
-        if nr <= live_floor:
-            assert gn <= live_floor, n
-            dead.append(n)
-        else:
-            worst = max(worst, abs(gn - nr) / nr)
     # ... and `add_embedding` (fps / motion bucket) is overwritten for micro_cond (unet:482): no gradient either
     is_dead = lambda n: ("transformer_blocks.0.norm2." in n) or (".attn2.to_q." in n) or (".attn2.to_k." in n) or \
         n.startswith("add_embedding.")  # noqa: E731
-    assert dead and all(is_dead(n) for n in dead), [n for n in dead if not is_dead(n)][:5]
-    assert all(n in dead for n in names if is_dead(n))
-    print(f"[f2 oracle] {len(names)} gradient norms ({len(dead)} dead cross-attention parameters), worst relative deviation "
-          f"of the live ones {worst:.2e}")
-    assert worst <= 1e-3
+    med = float(np.median(norms[norms > 0]))
+    worst, dead = 0.0, 0
+    for n, nr in zip(names, norms):
+        gn = 0.0 if grads[n] is None else float(grads[n].double().norm())
+        if is_dead(n):
+            assert gn == 0.0 and nr <= 1e-3 * med, (n, gn, nr)
+            dead += 1
+        else:
+            assert nr > 0, n
+            # (a scalar mix_factor whose gradient is a cancelling sum of 1e-8 gets an absolute allowance)
+            worst = max(worst, max(abs(gn - nr) - 1e-9, 0.0) / nr)
+    print(f"[f2 oracle] {len(names)} gradient norms ({dead} dead cross-attention / add_embedding parameters), worst relative "
+          f"deviation of the live ones {worst:.2e}")
+    assert dead == 132 and worst <= 1e-3
     # full gradients of one tensor per operator class
     n_full = 0
     for key in g.files:

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const uint16_t* __restri
 // outside the image / clip), taps = 9 (3x3, pad 1 over (H, W)) or 3 ((3,1,1) over T).  dW = dY^T . Xcol is then ONE GEMM
 // whose K loop runs over the M rows (world-in-world_amd/train.py); 16 bytes per thread and tap.
 __global__ __launch_bounds__(256) void gather_taps_kernel(const uint16_t* __restrict__ X, int64_t M, int C, int H, int W, int T,
-                                                           int temporal, uint16_t* __restrict__ Xcol) {
+                                                           int temporal, int stride, uint16_t* __restrict__ Xcol) {
     const int chunks = C >> 3, taps = temporal ? 3 : 9;
     const int HW = H * W;
     const int64_t total = M * taps * chunks;
@@ -348,8 +348,13 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const uint16_t* __rest
             const int t = (int)((m / HW) % T) + tap - 1;
             if (t >= 0 && t < T) src = m + (int64_t)(tap - 1) * HW;
         } else {
-            const int rem = (int)(m % HW), y = rem / W + tap / 3 - 1, x = rem % W + tap % 3 - 1;
-            if (y >= 0 && y < H && x >= 0 && x < W) src = m + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1);
+            if (stride == 1) {
+                const int rem = (int)(m % HW), y = rem / W + tap / 3 - 1, x = rem % W + tap % 3 - 1;
+                if (y >= 0 && y < H && x >= 0 && x < W) src = m + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1);
+            } else {   // stride 2, pad 1: output (H, W), input (2H, 2W)  (Downsample2D, downsampling.py:132-150)
+                const int rem = (int)(m % HW), y = 2 * (rem / W) + tap / 3 - 1, x = 2 * (rem % W) + tap % 3 - 1;
+                if (y >= 0 && y < 2 * H && x >= 0 && x < 2 * W) src = (m / HW) * (4 * HW) + (int64_t)y * (2 * W) + x;
+            }
         }
         uint4 v = uint4{0u, 0u, 0u, 0u};
         if (src >= 0) v = *(const uint4*)(X + src * C + ch * 8);
@@ -563,6 +568,145 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small glue kernels of the training graph (HBM-bound, 16 bytes per thread)
+// ---------------------------------------------------------------------------------------------------------------------
+// out = a x + b y (y may be NULL)
+__global__ __launch_bounds__(256) void axpby_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Y, float a, float b,
+                                                     int64_t n8, uint16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8];
+        unpack8(*(const uint4*)(X + i * 8), x);
+        if (Y) {
+            unpack8(*(const uint4*)(Y + i * 8), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = a * x[e] + b * y[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= a;
+        }
+        *(uint4*)(out + i * 8) = pack8(x);
+    }
+}
+
+// SiLU forward / backward on 16-bit tensors: mode 0: out = silu(x);  mode 1: out = dy * silu'(x)
+__global__ __launch_bounds__(256) void silu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY, int mode,
+                                                    int64_t n8, uint16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8], d[8];
+        unpack8(*(const uint4*)(X + i * 8), x);
+        if (mode) unpack8(*(const uint4*)(dY + i * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = mode ? gnb_dz(d[e], x[e], 1) : silu_f(x[e]);
+        *(uint4*)(out + i * 8) = pack8(x);
+    }
+}
+
+// partial[block] = sum over the block's elements of x * (y - z)   (z may be NULL); fixed order
+__global__ __launch_bounds__(256) void dot_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Y,
+                                                   const uint16_t* __restrict__ Z, int64_t n8, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8], y[8], z[8];
+        unpack8(*(const uint4*)(X + i * 8), x);
+        unpack8(*(const uint4*)(Y + i * 8), y);
+        if (Z) unpack8(*(const uint4*)(Z + i * 8), z);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(x[e], Z ? y[e] - z[e] : y[e], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// Structured row maps on token-major [rows][C] tensors (the training graph's re-orderings; rows that map to nothing are zero):
+//   0 UPSAMPLE2X  out (n, 2H, 2W) <- in (n, H, W), nearest             (Upsample2D before its conv, upsampling.py:142-186)
+//   1 DILATE2X    out (n, 2H, 2W): in (n, H, W) at the even positions   (gradient of the stride-2 conv as a stride-1 conv)
+//   2 SUMPOOL2X2  out (n, H, W)   <- sum of the 2x2 blocks of in (n, 2H, 2W)   (gradient of the nearest upsample)
+//   3 T_TO_SEQ    out ((b, s), Tp, C) <- in ((b, t), s, C), zero rows for t >= T   (temporal attention: one sequence per site)
+//   4 SEQ_TO_T    the inverse (pad rows dropped)
+__global__ __launch_bounds__(256) void row_map_kernel(const uint16_t* __restrict__ X, int mode, int64_t out_rows, int C, int H, int W,
+                                                       int T, int Tp, int S, uint16_t* __restrict__ out) {
+    const int chunks = C >> 3;
+    const int64_t total = out_rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int ch = (int)(i - r * chunks);
+        int64_t src = -1;
+        if (mode == 0 || mode == 1) {
+            const int W2 = 2 * W, HW2 = 4 * H * W;
+            const int64_t n = r / HW2;
+            const int rem = (int)(r - n * HW2), y = rem / W2, x = rem - y * W2;
+            if (mode == 0 || ((y & 1) == 0 && (x & 1) == 0)) src = n * (H * W) + (int64_t)(y >> 1) * W + (x >> 1);
+        } else if (mode == 2) {
+            const int64_t n = r / (H * W);
+            const int rem = (int)(r - n * (H * W)), y = rem / W, x = rem - y * W;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float v[8];
+                unpack8(*(const uint4*)(X + (n * (4 * H * W) + (int64_t)(2 * y + (a >> 1)) * (2 * W) + 2 * x + (a & 1)) * C + ch * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+            *(uint4*)(out + r * C + ch * 8) = pack8(acc);
+            continue;
+        } else if (mode == 3) {
+            const int t = (int)(r % Tp);
+            const int64_t bs = r / Tp, b = bs / S, sidx = bs - b * S;
+            if (t < T) src = (b * T + t) * S + sidx;
+        } else {
+            const int64_t bt = r / S, sidx = r - bt * S, b = bt / T, t = bt - b * T;
+            src = (b * S + sidx) * Tp + t;
+        }
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (src >= 0) v = *(const uint4*)(X + src * C + ch * 8);
+        *(uint4*)(out + r * C + ch * 8) = v;
+    }
+}
+
+}  // namespace
+
+static inline unsigned wiw_ew_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+
+extern "C" int wiw_axpby_bf16(void* stream, const void* X, const void* Y, float a, float b, int64_t n, void* out) {
+    WIW_REQUIRE(X && out && n > 0 && n % 8 == 0, "axpby: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(axpby_kernel, dim3(wiw_ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                       (const uint16_t*)Y, a, b, n / 8, (uint16_t*)out);
+    return wiw_check_launch("wiw_axpby_bf16");
+}
+
+extern "C" int wiw_silu_bf16(void* stream, const void* X, const void* dY, int backward, int64_t n, void* out) {
+    WIW_REQUIRE(X && out && n > 0 && n % 8 == 0 && (!backward || dY), "silu: bad arguments");
+    hipLaunchKernelGGL(silu_kernel, dim3(wiw_ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                       (const uint16_t*)dY, backward, n / 8, (uint16_t*)out);
+    return wiw_check_launch("wiw_silu_bf16");
+}
+
+extern "C" int wiw_dot_bf16(void* stream, const void* X, const void* Y, const void* Z, int64_t n, float* partial, int n_partial) {
+    WIW_REQUIRE(X && Y && partial && n > 0 && n % 8 == 0 && n_partial > 0 && n_partial <= 4096, "dot: bad arguments");
+    hipLaunchKernelGGL(dot_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, (const uint16_t*)Y,
+                       (const uint16_t*)Z, n / 8, partial);
+    return wiw_check_launch("wiw_dot_bf16");
+}
+
+extern "C" int wiw_row_map_bf16(void* stream, const void* X, int mode, int64_t out_rows, int C, int H, int Wd, int T, int Tp, int S,
+                                void* out) {
+    WIW_REQUIRE(X && out && out_rows > 0 && C > 0 && C % 8 == 0 && mode >= 0 && mode <= 4, "row_map: bad arguments");
+    hipLaunchKernelGGL(row_map_kernel, dim3(wiw_ew_blocks(out_rows * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                       mode, out_rows, C, H, Wd, T, Tp, S, (uint16_t*)out);
+    return wiw_check_launch("wiw_row_map_bf16");
+}
+
+namespace {
 }  // namespace
 
 extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
@@ -596,13 +740,15 @@ extern "C" int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, 
     return wiw_check_launch("wiw_geglu_fwd");
 }
 
-extern "C" int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, void* Xcol) {
-    WIW_REQUIRE(X && Xcol && M > 0 && C > 0 && C % 8 == 0 && H > 0 && Wd > 0, "gather_taps: bad arguments");
+extern "C" int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, int stride,
+                                    void* Xcol) {
+    WIW_REQUIRE(X && Xcol && M > 0 && C > 0 && C % 8 == 0 && H > 0 && Wd > 0 && (stride == 1 || (stride == 2 && !temporal)),
+                "gather_taps: bad arguments");
     WIW_REQUIRE(M % ((int64_t)H * Wd) == 0 && (!temporal || (T > 0 && (M / ((int64_t)H * Wd)) % T == 0)), "gather_taps: bad geometry");
     int64_t blocks = (M * (temporal ? 3 : 9) * (C >> 3) + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(gather_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, M, C, H,
-                       Wd, T, temporal, (uint16_t*)Xcol);
+                       Wd, T, temporal, stride, (uint16_t*)Xcol);
     return wiw_check_launch("wiw_gather_taps_bf16");
 }
 

@@ -126,7 +126,13 @@ EXPORTS = {
     "wiw_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wiw_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
-    "wiw_gather_taps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "wiw_gather_taps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "wiw_axpby_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int64, C.c_void_p]),
+    "wiw_silu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "wiw_dot_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    "wiw_row_map_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
     "wiw_geglu_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "wiw_attn_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -425,28 +431,56 @@ class Hip:
         s = self.colsum(unit_cs, units, 2 * Cn, parts=1)
         return dX, s[Cn:], s[:Cn]
 
-    def attn_backward(self, qkv, O, dO, seqs, S, heads, scale):
-        """Self-attention backward for the fused q|k|v layout of the spatial block: qkv [seqs*S, 3C], O / dO [seqs*S, C]
-        (C = heads*64, S % 16 == 0) -> d_qkv [seqs*S, 3C]."""
-        Cn, M = heads * 64, seqs * S
-        assert S % 16 == 0 and qkv.shape == (M, 3 * Cn) and O.shape == (M, Cn) and dO.shape == (M, Cn)
+    def attn_backward(self, qkv, O, dO, seqs, S, heads, scale, Sp=None):
+        """Self-attention backward for the fused q|k|v layout: qkv [seqs*Sp, 3C], O / dO [seqs*Sp, C] (C = heads*64; sequences
+        of S rows at a row stride of Sp, Sp % 16 == 0, default Sp = S) -> d_qkv [seqs*Sp, 3C] (padding rows zero)."""
+        Sp = S if Sp is None else Sp
+        Cn, M = heads * 64, seqs * Sp
+        assert Sp % 16 == 0 and qkv.shape == (M, 3 * Cn) and O.shape == (M, Cn) and dO.shape == (M, Cn)
         dt, dev = self.dtype, self.device
         Qt, Kt, dOt = (torch.empty(Cn, M, dtype=dt, device=dev) for _ in range(3))
         self.transpose(qkv, 3 * Cn, 0, M, Cn, Qt, M)
         self.transpose(qkv, 3 * Cn, Cn, M, Cn, Kt, M)
         self.transpose(dO, Cn, 0, M, Cn, dOt, M)
         dqkv = torch.empty(M, 3 * Cn, dtype=dt, device=dev)
-        lse = torch.empty(seqs * heads * S, dtype=torch.float32, device=dev)
+        lse = torch.empty(seqs * heads * Sp, dtype=torch.float32, device=dev)
         dsum = torch.empty_like(lse)
         self._ck(self.lib.wiw_attn_bwd_bf16(self._stream(), _p(qkv), 3 * Cn, Cn, 2 * Cn, _p(Qt), _p(Kt), _p(dOt), M, _p(O), _p(dO),
-                                            Cn, _p(dqkv), 3 * Cn, _p(lse), _p(dsum), seqs, S, S, heads, 64, scale),
+                                            Cn, _p(dqkv), 3 * Cn, _p(lse), _p(dsum), seqs, S, Sp, heads, 64, scale),
                  "wiw_attn_bwd_bf16")
         return dqkv
 
-    def gather_taps(self, X, M, Cn, H, Wd, T=1, temporal=False):
-        """im2col rows [M, taps*Cn] of X [M, Cn] for the conv weight gradients (9 taps, or 3 temporal ones)."""
+    def gather_taps(self, X, M, Cn, H, Wd, T=1, temporal=False, stride=1):
+        """im2col rows [M, taps*Cn] of X for the conv weight gradients (9 taps, or 3 temporal ones); M = OUTPUT rows,
+        (H, Wd) = output geometry (stride 2: X is the (2H, 2Wd) input)."""
         out = torch.empty(M, (3 if temporal else 9) * Cn, dtype=self.dtype, device=self.device)
-        self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), _p(out)), "wiw_gather_taps_bf16")
+        self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), stride, _p(out)),
+                 "wiw_gather_taps_bf16")
+        return out
+
+    def axpby(self, X, a=1.0, Y=None, b=1.0, out=None):
+        out = torch.empty_like(X) if out is None else out
+        self._ck(self.lib.wiw_axpby_bf16(self._stream(), _p(X), _p(Y), a, b, X.numel(), _p(out)), "wiw_axpby_bf16")
+        return out
+
+    def silu(self, X, dY=None):
+        """silu(X), or with dY: dY * silu'(X)."""
+        out = torch.empty_like(X)
+        self._ck(self.lib.wiw_silu_bf16(self._stream(), _p(X), _p(dY), int(dY is not None), X.numel(), _p(out)), "wiw_silu_bf16")
+        return out
+
+    def dot(self, X, Y, Z=None):
+        """sum X * (Y - Z) as a 0-d fp32 tensor (fixed-order block partials)."""
+        nb = min(256, (X.numel() // 8 + 255) // 256)
+        part = torch.empty(nb, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_dot_bf16(self._stream(), _p(X), _p(Y), _p(Z), X.numel(), _p(part), nb), "wiw_dot_bf16")
+        return part.sum()
+
+    ROW_UPSAMPLE2X, ROW_DILATE2X, ROW_SUMPOOL2X2, ROW_T_TO_SEQ, ROW_SEQ_TO_T = 0, 1, 2, 3, 4
+
+    def row_map(self, X, mode, out_rows, Cn, H=0, Wd=0, T=0, Tp=0, S=0):
+        out = torch.empty(out_rows, Cn, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_row_map_bf16(self._stream(), _p(X), mode, out_rows, Cn, H, Wd, T, Tp, S, _p(out)), "wiw_row_map_bf16")
         return out
 
     def geglu_fwd(self, P, rows, Ch):

@@ -1,0 +1,538 @@
+"""Training graph of the action-conditioned SVD UNet on the HIP kernels — SURVEY.md 8(f) row 2 (`FTsvd/train_svd.py:844-970`).
+
+`UNetTrain.forward` evaluates `UNetSpatioTemporalConditionModel.forward` (unet:402-575, micro_cond, one sample per GPU as the
+reference's loop) in the UN-FUSED order training needs and records every operator on a tape; `backward` replays the tape in
+reverse with the backward building blocks of `train.py` / `csrc/train.hip` and returns fp32 gradients of every live parameter in
+the reference's state-dict layout.  The exactly dead parameters of the inference path (single-key cross-attention `norm2`,
+`attn2.to_q/to_k`; `add_embedding`) are dead here too and get no gradient — as in the reference's autograd.
+
+FIRST, correctness-first form: activations are 16-bit (as the forward kernels produce them), parameter gradients fp32; no
+operator fusion, explicit concat / residual tensors, untuned backward kernels (`csrc/train.hip`).  Tiny host-side pieces
+(sinusoidal features, sums of three [T, E] embedding rows, gradient accumulation of sub-64 k-element tensors, weight
+re-layouts) are PyTorch plumbing.  Pinned by `tests/golden/train_step_tiny*.npz` (the reference's own `loss.backward()`).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .config import UNetConfig
+from .hip import A_CONV3X3, A_CONV3X3_S2, A_CONV_T3, EPI_OUT_F32, Hip
+from .train import conv_backward, linear_backward
+from .unet import CIN_PAD, sinusoid
+
+SMALL = 1 << 16      # gradients of tensors up to this many elements are accumulated in fp32 on the host side of the tape
+
+
+class Tape:
+    """Operators push a backward closure; `run` seeds the output gradient and replays them in reverse.  Gradients of
+    activations are keyed by tensor identity and summed at fan-outs (16-bit `wiw_axpby_bf16`; fp32 for tiny tensors)."""
+
+    def __init__(self, hip: Hip):
+        self.hip, self.ops, self.g = hip, [], {}
+        self.keep: List[torch.Tensor] = []            # tensors whose id() is a key must stay alive
+
+    def add(self, t: torch.Tensor, g: torch.Tensor) -> None:
+        k = id(t)
+        if k not in self.g:
+            self.g[k] = g
+            self.keep.append(t)
+        elif g.numel() <= SMALL or g.dtype == torch.float32:
+            self.g[k] = (self.g[k].float() + g.float())
+        else:
+            self.g[k] = self.hip.axpby(self.g[k], 1.0, g, 1.0)
+
+    def take(self, t: torch.Tensor, dtype=None) -> Optional[torch.Tensor]:
+        g = self.g.pop(id(t), None)
+        if g is not None and dtype is not None and g.dtype != dtype:
+            g = g.to(dtype)
+        return g
+
+    def run(self, out: torch.Tensor, dout: torch.Tensor) -> None:
+        self.add(out, dout)
+        for fn in reversed(self.ops):
+            fn()
+
+
+def _pad_rows(t: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    M = t.shape[0]
+    Mp = -(-M // mult) * mult
+    if Mp == M:
+        return t.contiguous()
+    out = t.new_zeros((Mp, *t.shape[1:]))
+    out[:M] = t
+    return out
+
+
+class UNetTrain:
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0", hip: Optional[Hip] = None,
+                 dtype: torch.dtype = torch.bfloat16):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.hip = hip or Hip(self.device, dtype)
+        self.dt = self.hip.dtype
+        self.master = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
+        self.refresh()
+
+    # ------------------------------------------------------------------------------------------
+    # 16-bit operand copies in the kernels' layouts (re-made after every optimiser step)
+    # ------------------------------------------------------------------------------------------
+    def refresh(self) -> None:
+        m, dt = self.master, self.dt
+        self.W: Dict[str, torch.Tensor] = {}
+        for k, v in m.items():
+            if not k.endswith(".weight") or v.dim() < 2:
+                continue
+            if v.dim() == 2:
+                w = v
+                if w.shape[1] % 64:                                       # add_action_proj.proj: K = 168 -> 192
+                    w = torch.cat([w, w.new_zeros(w.shape[0], -w.shape[1] % 64)], dim=1)
+                self.W[k] = w.to(dt).contiguous()
+            elif v.dim() == 4:                                            # (O, I, 3, 3) | (O, I, 1, 1) -> [O][ky][kx][I]
+                w = v
+                if w.shape[1] % 64:                                       # conv_in: 8 -> 64 input channels
+                    w = torch.cat([w, w.new_zeros(w.shape[0], -w.shape[1] % 64, *w.shape[2:])], dim=1)
+                self.W[k] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+            else:                                                         # (O, I, 3, 1, 1) -> [O][kt][I]
+                self.W[k] = v[:, :, :, 0, 0].permute(0, 2, 1).reshape(v.shape[0], -1).to(dt).contiguous()
+        # fused q | k | v projections of the self-attentions
+        for k in list(m):
+            if k.endswith(".attn1.to_q.weight"):
+                p = k[: -len("to_q.weight")]
+                self.W[p + "to_qkv.weight"] = torch.cat([m[p + "to_q.weight"], m[p + "to_k.weight"], m[p + "to_v.weight"]]).to(dt).contiguous()
+
+    # ------------------------------------------------------------------------------------------
+    # operators (forward + tape entry)
+    # ------------------------------------------------------------------------------------------
+    def _unit_colsum(self, dy: torch.Tensor, units: int, rows_per_unit: int) -> torch.Tensor:
+        C = dy.shape[1]
+        return torch.stack([self.hip.colsum(dy[u * rows_per_unit:(u + 1) * rows_per_unit], rows_per_unit, C) for u in range(units)])
+
+    def linear(self, x, name, M, bias=True, res=None, rowvec=None, rows_per_vec=1, out_f32=False, wkey=None, split=None):
+        """y = x . W^T (+ b) (+ rowvec[row // rows_per_vec]) (+ res).  x [>= M rows, K] 16-bit (extra rows are padding)."""
+        hip, tape = self.hip, self.tape
+        W = self.W[wkey or name + ".weight"]
+        N, K = W.shape
+        b = self.master[name + ".bias"] if bias else None
+        # 16-bit outputs of a handful of rows are allocated with their rows padded to 64 (zeros): they are the A operand of
+        # the next small GEMM and of its weight-gradient GEMM (K loop over rows).  fp32 outputs (per-unit vectors) are exact.
+        Mp = M if (out_f32 or M % 64 == 0) else -(-M // 64) * 64
+        y = torch.zeros(Mp, N, dtype=torch.float32 if out_f32 else self.dt, device=self.device)
+        hip.gemm(x, W, y, M=M, N=N, K=K, C1=K, bias=b, epilogue=EPI_OUT_F32 if out_f32 else 0,
+                 res1=res, ldr1=N if res is not None else 0, beta1=1.0 if res is not None else 0.0,
+                 rowvec=rowvec, rowvec_ld=N if rowvec is not None else 0, rows_per_vec=rows_per_vec)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is None:
+                return
+            if res is not None:
+                tape.add(res, dy)
+            if rowvec is not None:
+                tape.add(rowvec, self._unit_colsum(dy, rowvec.shape[0], rows_per_vec))
+            xp, dyp = _pad_rows(x[:M]), _pad_rows(dy[:M])
+            dx, dW, db = linear_backward(hip, xp, W, dyp, need_db=bias)
+            tape.add(x, dx[:M] if x.shape[0] == M else _pad_like(dx[:M], x))
+            if split is None:
+                self.grads[name + ".weight"] = dW[:, : self.master[name + ".weight"].shape[1]].contiguous()
+            else:                                                        # fused q | k | v: three reference tensors
+                for i, nm in enumerate(split):
+                    self.grads[nm] = dW[i * (N // 3):(i + 1) * (N // 3)].contiguous()
+            if bias:
+                self.grads[name + ".bias"] = db
+        tape.ops.append(bwd)
+        return y
+
+    def conv(self, x, name, M_out, H, W, mode=A_CONV3X3, T=1, res=None, rowvec=None, rows_per_vec=1, alpha=1.0, wkey=None):
+        """3x3 (stride 1 / stride 2) or temporal convolution + bias (+ per-frame vector) (+ residual).  (H, W) = OUTPUT geometry."""
+        hip, tape = self.hip, self.tape
+        Wk = self.W[wkey or name + ".weight"]
+        Cout = Wk.shape[0]
+        taps = 3 if mode == A_CONV_T3 else 9
+        Cin = Wk.shape[1] // taps
+        b = self.master[name + ".bias"]
+        y = torch.empty(M_out, Cout, dtype=self.dt, device=self.device)
+        hip.gemm(x, Wk, y, M=M_out, N=Cout, K=taps * Cin, C1=Cin, mode=mode, H=H, Wd=W, T=T, bias=b,
+                 res1=res, ldr1=Cout if res is not None else 0, beta1=1.0 if res is not None else 0.0,
+                 rowvec=rowvec, rowvec_ld=Cout if rowvec is not None else 0, rows_per_vec=rows_per_vec)
+        ref_w = self.master[name + ".weight"]
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is None:
+                return
+            if res is not None:
+                tape.add(res, dy)
+            if rowvec is not None:
+                tape.add(rowvec, self._unit_colsum(dy, rowvec.shape[0], rows_per_vec))
+            dyp, Wp = dy, Wk
+            if Cout % 64:                                                 # conv_out: 4 output channels -> 64
+                dyp = torch.cat([dy, dy.new_zeros(M_out, 64 - Cout)], dim=1).contiguous()
+                Wp = torch.cat([Wk, Wk.new_zeros(64 - Cout, Wk.shape[1])]).contiguous()
+            if mode == A_CONV3X3_S2:
+                # dx on the (2H, 2W) grid = stride-1 conv of the dilated dy with mirrored taps; dW from stride-2 im2col rows
+                dil = hip.row_map(dyp, hip.ROW_DILATE2X, 4 * M_out, dyp.shape[1], H, W)
+                W2 = Wp.reshape(Wp.shape[0], 9, Cin).flip(1).permute(2, 1, 0).reshape(Cin, 9 * Wp.shape[0]).contiguous()
+                dx = torch.empty(4 * M_out, Cin, dtype=self.dt, device=self.device)
+                hip.gemm(dil, W2, dx, M=4 * M_out, N=Cin, K=9 * Wp.shape[0], C1=Wp.shape[0], mode=A_CONV3X3, H=2 * H, Wd=2 * W)
+                xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
+                xcolT = torch.empty(9 * Cin, M_out, dtype=self.dt, device=self.device)
+                hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, M_out)
+                dyT = torch.empty(dyp.shape[1], M_out, dtype=self.dt, device=self.device)
+                hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, M_out)
+                dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
+                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=M_out, C1=M_out, epilogue=EPI_OUT_F32)
+                db = hip.colsum(dy, M_out, Cout)
+            else:
+                dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3))
+                db = db[:Cout]
+            tape.add(x, dx)
+            dW = dW[:Cout]
+            if mode == A_CONV_T3:
+                g = dW.reshape(Cout, 3, Cin).permute(0, 2, 1)[:, : ref_w.shape[1]].reshape(ref_w.shape)
+            else:
+                g = dW.reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)[:, : ref_w.shape[1]]
+            self.grads[name + ".weight"] = g.contiguous()
+            self.grads[name + ".bias"] = db
+        tape.ops.append(bwd)
+        return y
+
+    def conv1x1(self, x, name, M):
+        """conv_shortcut (1x1) of ResnetBlock2D: a linear layer on tokens; gradient reshaped to (O, I, 1, 1)."""
+        y = self.linear(x, name, M)
+        ref = self.master[name + ".weight"]
+
+        def fix():
+            if name + ".weight" in self.grads and self.grads[name + ".weight"].dim() == 2:
+                self.grads[name + ".weight"] = self.grads[name + ".weight"].reshape(ref.shape)
+        self.tape.ops.insert(len(self.tape.ops) - 1, fix)     # runs AFTER the linear's backward (reverse order)
+        return y
+
+    def groupnorm(self, x, name, M, rows_per_unit, eps, silu):
+        hip, tape = self.hip, self.tape
+        C = x.shape[1]
+        g, b = self.master[name + ".weight"], self.master[name + ".bias"]
+        y = hip.groupnorm(x, C, None, 0, M, rows_per_unit, g, b, eps, silu)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is None:
+                return
+            dx, dg, db = hip.groupnorm_bwd(x, dy, g, b, M, C, rows_per_unit, eps, silu)
+            tape.add(x, dx)
+            self.grads[name + ".weight"], self.grads[name + ".bias"] = dg, db
+        tape.ops.append(bwd)
+        return y
+
+    def layernorm(self, x, name, M):
+        hip, tape = self.hip, self.tape
+        C = x.shape[1]
+        g, b = self.master[name + ".weight"], self.master[name + ".bias"]
+        y = hip.layernorm(x, M, C, g, b, 1e-5)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is None:
+                return
+            dx, dg, db = hip.layernorm_bwd(x, dy, g, M, C, 1e-5)
+            tape.add(x, dx)
+            self.grads[name + ".weight"], self.grads[name + ".bias"] = dg, db
+        tape.ops.append(bwd)
+        return y
+
+    def geglu(self, P, M):
+        hip, tape = self.hip, self.tape
+        Ch = P.shape[1] // 2
+        h = hip.geglu_fwd(P, M, Ch)
+
+        def bwd():
+            dh = tape.take(h, self.dt)
+            if dh is not None:
+                tape.add(P, hip.geglu_bwd(P, dh, M, Ch))
+        tape.ops.append(bwd)
+        return h
+
+    def silu(self, x):
+        hip, tape = self.hip, self.tape
+        y = hip.silu(x)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is not None:
+                tape.add(x, hip.silu(x, dy))
+        tape.ops.append(bwd)
+        return y
+
+    def blend(self, xs, xt, name):
+        """AlphaBlender (resnet.py:784-797): a xs + (1 - a) xt, a = sigmoid(mix_factor)."""
+        hip, tape = self.hip, self.tape
+        a = float(torch.sigmoid(self.master[name + ".mix_factor"]).item())
+        y = hip.axpby(xs, a, xt, 1.0 - a)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is None:
+                return
+            tape.add(xs, hip.axpby(dy, a))
+            tape.add(xt, hip.axpby(dy, 1.0 - a))
+            self.grads[name + ".mix_factor"] = (hip.dot(dy, xs, xt) * (a * (1.0 - a))).reshape(self.master[name + ".mix_factor"].shape)
+        tape.ops.append(bwd)
+        return y
+
+    def concat(self, x1, x2):
+        tape = self.tape
+        y = torch.cat([x1, x2], dim=1).contiguous()                        # a copy (plumbing)
+        C1 = x1.shape[1]
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is not None:
+                tape.add(x1, dy[:, :C1].contiguous())
+                tape.add(x2, dy[:, C1:].contiguous())
+        tape.ops.append(bwd)
+        return y
+
+    def upsample2x(self, x, M, H, W):
+        hip, tape = self.hip, self.tape
+        C = x.shape[1]
+        y = hip.row_map(x, hip.ROW_UPSAMPLE2X, 4 * M, C, H, W)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is not None:
+                tape.add(x, hip.row_map(dy, hip.ROW_SUMPOOL2X2, M, C, H, W))
+        tape.ops.append(bwd)
+        return y
+
+    def self_attention(self, a, p, M, seqs, S, heads, temporal_T=0):
+        """to_q|k|v (one GEMM) -> softmax(Q K^T / 8) V -> returns O [M, C] (the out-projection is the caller's linear).
+        temporal_T > 0: rows are (b, t, s) and the sequences are the T frames of every site: tokens are re-ordered to
+        (b, s, t padded to 16) around the same kernels."""
+        hip, tape = self.hip, self.tape
+        C = heads * 64
+        qkv = self.linear(a, p + ".to_qkv", M, bias=False, wkey=p + ".to_qkv.weight",
+                          split=(p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"))
+        if temporal_T:
+            T, Tp, Ssp = temporal_T, 16, M // (seqs * temporal_T)          # seqs = batch items here
+            nseq = seqs * Ssp
+            q_seq = hip.row_map(qkv, hip.ROW_T_TO_SEQ, nseq * Tp, 3 * C, T=T, Tp=Tp, S=Ssp)
+            Ms = nseq * Tp
+            vt = torch.empty(C, Ms, dtype=self.dt, device=self.device)
+            hip.transpose(q_seq, 3 * C, 2 * C, Ms, C, vt, Ms)
+            o_seq = torch.empty(Ms, C, dtype=self.dt, device=self.device)
+            hip.attn_small(q_seq, 3 * C, C, vt, Ms, o_seq, C, nseq, T, Tp, heads, 64, 0.125)
+            o = hip.row_map(o_seq, hip.ROW_SEQ_TO_T, M, C, T=T, Tp=Tp, S=Ssp)
+
+            def bwd():
+                do = tape.take(o, self.dt)
+                if do is None:
+                    return
+                do_seq = hip.row_map(do, hip.ROW_T_TO_SEQ, Ms, C, T=T, Tp=Tp, S=Ssp)
+                dq_seq = hip.attn_backward(q_seq, o_seq, do_seq, nseq, T, heads, 0.125, Sp=Tp)
+                tape.add(qkv, hip.row_map(dq_seq, hip.ROW_SEQ_TO_T, M, 3 * C, T=T, Tp=Tp, S=Ssp))
+            tape.ops.append(bwd)
+            return o
+        vt = torch.empty(C, M, dtype=self.dt, device=self.device)
+        hip.transpose(qkv, 3 * C, 2 * C, M, C, vt, M)
+        o = torch.empty(M, C, dtype=self.dt, device=self.device)
+        hip.attn_spatial(qkv, 3 * C, C, vt, M, o, C, seqs, S, heads, 0.125)
+
+        def bwd():
+            do = tape.take(o, self.dt)
+            if do is not None:
+                tape.add(qkv, hip.attn_backward(qkv, o, do, seqs, S, heads, 0.125))
+        tape.ops.append(bwd)
+        return o
+
+    # ------------------------------------------------------------------------------------------
+    # small dense paths (a handful of rows): embeddings and the single-key cross-attention vectors
+    # ------------------------------------------------------------------------------------------
+    def mlp(self, x, p, M, out_f32=True):
+        """TimestepEmbedding (embeddings.py:804-816): linear_1 -> SiLU -> linear_2."""
+        h = self.linear(x, p + ".linear_1", M)                 # rows padded to 64 by `linear`
+        return self.linear(self.silu(h), p + ".linear_2", M, out_f32=out_f32)
+
+    def host_sum(self, terms, shape):
+        """fp32 sum of small [T, E] tensors with broadcasting rows (the three embeddings of unet:465-487); plumbing."""
+        tape = self.tape
+        y = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        for t in terms:
+            y = y + t.float()
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            for t in terms:
+                tape.add(t, dy.float().sum(0, keepdim=True) if t.shape[0] == 1 and shape[0] > 1 else dy.float())
+        tape.ops.append(bwd)
+        return y
+
+    def cast16(self, x, rows_pad=64):
+        """fp32 [M, C] -> 16-bit, rows padded to a multiple of 64 (GEMM operand); gradient flows back in fp32."""
+        tape = self.tape
+        M = x.shape[0]
+        y = _pad_rows(x.to(self.dt), rows_pad)
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                tape.add(x, dy[:M].float())
+        tape.ops.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------------------------------
+    # blocks
+    # ------------------------------------------------------------------------------------------
+    def res_block(self, p, x, Cin, Cout, M, H, W, T, emb_silu, eps):
+        """SpatioTemporalResBlock (resnet.py:686-716)."""
+        S = H * W
+        s, t = p + ".spatial_res_block", p + ".temporal_res_block"
+        te_s = self.linear(emb_silu, s + ".time_emb_proj", T, out_f32=True)          # [T, Cout] per-frame vectors
+        h = self.groupnorm(x, s + ".norm1", M, S, eps, True)
+        h = self.conv(h, s + ".conv1", M, H, W, rowvec=te_s, rows_per_vec=S)
+        h = self.groupnorm(h, s + ".norm2", M, S, eps, True)
+        sc = self.conv1x1(x, s + ".conv_shortcut", M) if (s + ".conv_shortcut.weight") in self.master else x
+        xs = self.conv(h, s + ".conv2", M, H, W, res=sc)
+        te_t = self.linear(emb_silu, t + ".time_emb_proj", T, out_f32=True)
+        h = self.groupnorm(xs, t + ".norm1", M, T * S, eps, True)
+        h = self.conv(h, t + ".conv1", M, H, W, mode=A_CONV_T3, T=T, rowvec=te_t, rows_per_vec=S)
+        h = self.groupnorm(h, t + ".norm2", M, T * S, eps, True)
+        xt = self.conv(h, t + ".conv2", M, H, W, mode=A_CONV_T3, T=T, res=xs)
+        return self.blend(xs, xt, p + ".time_mixer")
+
+    def cross_vector(self, q, ehs16):
+        """Single-key cross-attention: softmax over one key == 1, so attn2(x) = to_out(to_v(ctx)), one [1, C]
+        vector; norm2 / to_q / to_k receive no gradient."""
+        v = self.linear(ehs16, q + ".attn2.to_v", 1, bias=False)
+        return self.linear(v, q + ".attn2.to_out.0", 1, out_f32=True)
+
+    def ff(self, a, p, M, **epi):
+        P = self.linear(a, p + ".net.0.proj", M)
+        return self.linear(self.geglu(P, M), p + ".net.2", M, **epi)
+
+    def transformer(self, p, x, C, M, H, W, T, heads, ehs16):
+        """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer, one sample."""
+        S = H * W
+        b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
+        xn = self.groupnorm(x, p + ".norm", M, S, 1e-6, False)
+        h = self.linear(xn, p + ".proj_in", M)
+        # spatial block (attention.py:462-582)
+        o = self.self_attention(self.layernorm(h, b + ".norm1", M), b + ".attn1", M, T, S, heads)
+        h = self.linear(o, b + ".attn1.to_out.0", M, res=h, rowvec=self.cross_vector(b, ehs16), rows_per_vec=M)
+        feat = torch.from_numpy(sinusoid(np.arange(T), C)).to(self.device, self.dt)
+        pos = self.mlp(_pad_rows(feat), p + ".time_pos_embed", T)                 # [T, C] frame-position embedding
+        hs = self.ff(self.layernorm(h, b + ".norm3", M), b + ".ff", M, res=h)
+        # temporal block on hs + emb (attention.py:707-762); rows stay (t, s): every operator but the attention is per token
+        hm0 = self._add_rowvec(hs, pos, S)
+        hm = self.ff(self.layernorm(hm0, t + ".norm_in", M), t + ".ff_in", M, res=hm0)
+        o = self.self_attention(self.layernorm(hm, t + ".norm1", M), t + ".attn1", M, 1, S, heads, temporal_T=T)
+        hm = self.linear(o, t + ".attn1.to_out.0", M, res=hm, rowvec=self.cross_vector(t, ehs16), rows_per_vec=M)
+        ht = self.ff(self.layernorm(hm, t + ".norm3", M), t + ".ff", M, res=hm)
+        hb = self.blend(hs, ht, p + ".time_mixer")
+        return self.linear(hb, p + ".proj_out", M, res=x)
+
+    def _add_rowvec(self, x, vec, rows_per_vec):
+        """x + vec[row // rows_per_vec] (vec fp32 [units, C]): a 1x... broadcast add through the GEMM-free path."""
+        hip, tape = self.hip, self.tape
+        M, C = x.shape
+        rep = vec.to(self.dt).repeat_interleave(rows_per_vec, dim=0).contiguous()      # plumbing: broadcast copy
+        y = hip.axpby(x, 1.0, rep, 1.0)
+
+        def bwd():
+            dy = tape.take(y, self.dt)
+            if dy is not None:
+                tape.add(x, dy)
+                tape.add(vec, self._unit_colsum(dy, vec.shape[0], rows_per_vec))
+        tape.ops.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------------------------------
+    # the network
+    # ------------------------------------------------------------------------------------------
+    def forward(self, sample: torch.Tensor, timestep: float, ehs: torch.Tensor, added_time_ids: torch.Tensor,
+                action_ids: torch.Tensor) -> torch.Tensor:
+        """sample (1,T,8,h,w); ehs (1,1,Dctx); added_time_ids (1,3); action_ids (1,T,Ch).  Returns (1,T,4,h,w) fp32."""
+        cfg, hip, dev, dt = self.cfg, self.hip, self.device, self.dt
+        self.tape, self.grads = Tape(hip), {}
+        T, ch, n, L = cfg.num_frames, cfg.block_out_channels, len(cfg.block_out_channels), cfg.layers_per_block
+        _, _, cin, h, w = sample.shape
+        assert sample.shape[0] == 1 and sample.shape[1] == T
+        E = cfg.time_embed_dim
+        # ---- conditioning embeddings (unet:447-487), a handful of rows
+        t_feat = torch.from_numpy(sinusoid(np.array([timestep], np.float32), ch[0])).to(dev, dt)
+        emb_t = self.mlp(_pad_rows(t_feat), "time_embedding", 1)
+        a = action_ids.float().reshape(T, -1)
+        feats = []
+        for k in (1.0, 2.0, 4.0, 6.0, 8.0, 10.0):
+            feats += [torch.cos(k * a), torch.sin(k * a)]
+        act = torch.stack(feats, dim=-1).reshape(T, -1)
+        Kp = self.W["add_action_proj.proj.weight"].shape[1]
+        act = torch.cat([act, act.new_zeros(T, Kp - act.shape[1])], dim=1).to(dev, dt)
+        emb_a = self.mlp(self.linear(_pad_rows(act), "add_action_proj.proj", T), "add_embedding_action", T)
+        n_feat = torch.from_numpy(sinusoid(added_time_ids[:, -1].float().numpy(), cfg.addition_time_embed_dim)).to(dev, dt)
+        emb_n = self.mlp(_pad_rows(n_feat), "add_embedding_noise", 1)
+        emb = self.host_sum([emb_t, emb_a, emb_n], (T, E))
+        emb_silu = self.silu(self.cast16(emb))                                     # [64, E], rows >= T are silu(0) = 0
+        ehs16 = _pad_rows(ehs.reshape(1, -1).to(dev, dt))
+        # ---- conv_in
+        x0 = torch.zeros(T * h * w, CIN_PAD, dtype=dt, device=dev)
+        x0[:, :cin] = sample[0].permute(0, 2, 3, 1).reshape(-1, cin).to(dev, dt)
+        H, W = h, w
+        M = T * H * W
+        x = self.conv(x0, "conv_in", M, H, W)
+        skips = [(x, ch[0])]
+        C = ch[0]
+        for i in range(n):
+            p = f"down_blocks.{i}"
+            has_attn = i < n - 1
+            eps = 1e-6 if has_attn else 1e-5
+            for j in range(L):
+                x = self.res_block(f"{p}.resnets.{j}", x, C, ch[i], M, H, W, T, emb_silu, eps)
+                C = ch[i]
+                if has_attn:
+                    x = self.transformer(f"{p}.attentions.{j}", x, C, M, H, W, T, cfg.num_attention_heads[i], ehs16)
+                skips.append((x, C))
+            if i < n - 1:
+                H, W = H // 2, W // 2
+                M = T * H * W
+                x = self.conv(x, f"{p}.downsamplers.0.conv", M, H, W, mode=A_CONV3X3_S2)
+                skips.append((x, C))
+        x = self.res_block("mid_block.resnets.0", x, C, C, M, H, W, T, emb_silu, 1e-5)
+        x = self.transformer("mid_block.attentions.0", x, C, M, H, W, T, cfg.num_attention_heads[-1], ehs16)
+        x = self.res_block("mid_block.resnets.1", x, C, C, M, H, W, T, emb_silu, 1e-5)
+        rch = list(reversed(ch))
+        rheads = list(reversed(cfg.num_attention_heads))
+        for i in range(n):
+            p = f"up_blocks.{i}"
+            for j in range(L + 1):
+                sk, Cs = skips.pop()
+                x = self.res_block(f"{p}.resnets.{j}", self.concat(x, sk), C + Cs, rch[i], M, H, W, T, emb_silu, 1e-6)
+                C = rch[i]
+                if i > 0:
+                    x = self.transformer(f"{p}.attentions.{j}", x, C, M, H, W, T, rheads[i], ehs16)
+            if i < n - 1:
+                x = self.upsample2x(x, M, H, W)
+                H, W = 2 * H, 2 * W
+                M = T * H * W
+                x = self.conv(x, f"{p}.upsamplers.0.conv", M, H, W)
+        x = self.groupnorm(x, "conv_norm_out", M, H * W, 1e-5, True)
+        y = self.conv(x, "conv_out", M, H, W)                                       # [M, 4] 16-bit
+        self._out = y
+        return y.float().reshape(T, H, W, -1).permute(0, 3, 1, 2).unsqueeze(0)
+
+    def backward(self, dpred: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """dpred: dL/d(model_pred) (1,T,4,h,w) fp32 -> {reference parameter name: fp32 gradient}."""
+        T = self.cfg.num_frames
+        dy = dpred[0].permute(0, 2, 3, 1).reshape(-1, dpred.shape[2]).to(self.device, self.dt).contiguous()
+        self.tape.run(self._out, dy)
+        return self.grads
+
+
+def _pad_like(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros_like(like, dtype=t.dtype)
+    out[: t.shape[0]] = t
+    return out
