@@ -524,12 +524,62 @@ class UNetTrain:
         self._out = y
         return y.float().reshape(T, H, W, -1).permute(0, 3, 1, 2).unsqueeze(0)
 
-    def backward(self, dpred: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """dpred: dL/d(model_pred) (1,T,4,h,w) fp32 -> {reference parameter name: fp32 gradient}."""
-        T = self.cfg.num_frames
-        dy = dpred[0].permute(0, 2, 3, 1).reshape(-1, dpred.shape[2]).to(self.device, self.dt).contiguous()
+    def backward(self, dpred: torch.Tensor, loss_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+        """dpred: dL/d(model_pred) (1,T,4,h,w) fp32 -> {reference parameter name: fp32 gradient}.
+        loss_scale: the 16-bit activation gradients are computed for loss_scale * L and the fp32 parameter gradients divided
+        by it at the end — fp16's 6e-5 normal range loses the ~1e-5 activation gradients of a mean loss without it (the
+        reference runs fp16 under accelerate's GradScaler, train_svd.py:699, 971-975); bf16 needs none."""
+        dy = (dpred[0].permute(0, 2, 3, 1).reshape(-1, dpred.shape[2]) * loss_scale).to(self.device, self.dt).contiguous()
         self.tape.run(self._out, dy)
+        if loss_scale != 1.0:
+            inv = 1.0 / loss_scale
+            self.grads = {k: v.float() * inv for k, v in self.grads.items()}
         return self.grads
+
+
+class Trainer:
+    """One fine-tuning step of the reference loop (`FTsvd/train_svd.py:844-970`) on one GPU, one sample per step:
+        prepare_step -> UNetTrain.forward -> wiw_edm_loss_grad -> UNetTrain.backward -> AdamW -> refreshed 16-bit operands.
+    Single process: `wiw_adamw_step` over every parameter tensor.  Data parallel: hand `optimizer=parallel.ShardedAdamW(...)`
+    (gradients are copied into its flat buffer, reduced-scattered, the owned slices updated, parameters all-gathered)."""
+
+    def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 optimizer=None, loss_scale: Optional[float] = None):
+        self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
+        # static loss scale for fp16 (halved, and the step skipped, when a gradient comes back non-finite); 1 for bf16
+        self.loss_scale = (2.0 ** 14 if net.dt == torch.float16 else 1.0) if loss_scale is None else loss_scale
+        self.opt = optimizer
+        self.steps = 0
+        self.m = {k: torch.zeros_like(v) for k, v in net.master.items()} if optimizer is None else None
+        self.v = {k: torch.zeros_like(v) for k, v in net.master.items()} if optimizer is None else None
+        if optimizer is not None:
+            optimizer.load(net.master)
+
+    def step(self, st) -> float:
+        """st: `train.StepInputs`.  Returns the loss (host float)."""
+        from .train import TrainStep
+
+        net, hip = self.net, self.net.hip
+        pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
+        loss, dpred = TrainStep(hip).loss_and_grad(pred, st)
+        grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
+        if self.loss_scale != 1.0 and not all(bool(torch.isfinite(g).all()) for g in grads.values()):
+            self.loss_scale *= 0.5                                         # overflow: skip the update, as a GradScaler does
+            return float(loss)
+        self.steps += 1
+        if self.opt is None:
+            for name, g in grads.items():                                  # parameters without a gradient (the dead ones) stay
+                p = net.master[name]
+                hip.adamw_step(p.view(-1), g.reshape(-1).contiguous(), self.m[name].view(-1), self.v[name].view(-1), self.steps,
+                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
+        else:
+            for name, g in grads.items():
+                self.opt.view(self.opt.grads, name).copy_(g)
+            self.opt.step()
+            for name in net.master:
+                net.master[name].copy_(self.opt.view(self.opt.params, name))
+        net.refresh()
+        return float(loss)
 
 
 def _pad_like(t: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
