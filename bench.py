@@ -110,6 +110,12 @@ def main():
                     help="per-launch HIP events are recorded on every n-th Euler step of the timed rollouts (every launch of "
                          "those steps); n = 1 instruments every step and costs 3.4 %% of frames/s (21 k extra events / rollout)")
     ap.add_argument("--dump-shapes", type=str, default="", help="write per-(M,N,K) GEMM timings to this file")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE config 4 instead of the inference loop: one fine-tuning step per 'step' (un-fused training "
+                         "forward, EDM loss, backward through every operator, AdamW), one sample per GPU, data parallel over "
+                         "the ranks (ShardedAdamW: gradient reduce-scatter + parameter all-gather).  Functional, untuned.")
+    ap.add_argument("--train-height", type=int, default=256)
+    ap.add_argument("--train-width", type=int, default=512)
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time whole requests (uint8 panorama in -> uint8 frames out: CLIP + VAE encode, denoise, VAE "
                          "decode, PIL post-processing) through server.worker.SVDWorker; reported as 'end_to_end'")
@@ -132,6 +138,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     import wiw_amd  # noqa: F401
+    if args.train:
+        return train_bench(args, rank, world, device)
     from wiw_amd.config import UNetConfig
     from wiw_amd.parallel import sharded_denoise
     from wiw_amd.pipeline import SVDDenoiser
@@ -317,6 +325,71 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_bench(args, rank, world, device):
+    """BASELINE config 4: FTsvd/train_svd.py step (one sample per GPU; the reference's clips are 256x512, train_svd.py:849-859)
+    on the served architecture with random-init weights and a synthetic latent batch.  metric = training samples / s."""
+    import torch.distributed as dist
+
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.parallel import ShardedAdamW
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import random_state_dict_torch
+
+    cfg = UNetConfig.tiny(14) if args.tiny else UNetConfig()
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    net = UNetTrain(cfg, random_state_dict_torch(cfg, 0, device, torch.float32), device, dtype=dtype)
+    opt = None
+    if world > 1:
+        opt = ShardedAdamW({k: tuple(v.shape) for k, v in net.master.items()}, device,
+                           lambda p, g, m, v, step, lr, b1, b2, eps, wd: net.hip.adamw_step(p, g, m, v, step, lr, b1, b2, eps, wd),
+                           lr=1e-5)
+    tr = Trainer(net, lr=1e-5, optimizer=opt)
+    h, w, Tn = args.train_height // 8, args.train_width // 8, cfg.num_frames
+    gen = torch.Generator().manual_seed(100 + rank)                       # every rank its own sample
+    lat, noise = torch.randn(1, Tn, 4, h, w, generator=gen) * 0.8, torch.randn(1, Tn, 4, h, w, generator=gen)
+    aid = torch.zeros(1, Tn, cfg.action_input_channel)
+    seq = [4] + [[1, 2, 1, 3][i % 4] for i in range(Tn - 1)]
+    for i in range(Tn):
+        aid[0, i, : i + 1] = torch.tensor(seq[: i + 1], dtype=torch.float32)   # utils/svd_utils.py:594-632
+    st = T.prepare_step(lat, noise, 1.3, torch.randn(1, 4, h, w, generator=gen),
+                        torch.randn(1, 1, cfg.cross_attention_dim, generator=gen), 0.04, aid)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        tr.step(st)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank == 0:
+        assert np.isfinite(loss)
+        print(json.dumps({
+            "metric": "fine-tuning samples/sec (train_svd.py step: fwd + bwd + AdamW)", "value": round(world * args.steps / dt, 4),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SVD UNet fine-tuning step {args.train_height}x{args.train_width}x{Tn}, one sample per GPU, "
+                                   "random-init weights; functional first form (un-fused forward, untuned backward kernels)" +
+                                   (" [TINY MODEL - INVALID]" if args.tiny else ""),
+                       "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if world > 1 else "single GPU"},
+            "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}),
+            flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -76,20 +76,22 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
 
     M, K = x.shape
     N = W.shape[0]
-    assert W.shape == (N, K) and dy.shape == (M, N) and M % 64 == 0 and N % 64 == 0 and K % 64 == 0
+    assert W.shape == (N, K) and dy.shape == (M, N) and M % 8 == 0 and N % 64 == 0 and K % 64 == 0
     dev, dt = hip.device, hip.dtype
+    Mp = -(-M // 64) * 64              # the weight-gradient GEMM contracts over the rows: zero columns pad M to its K tile
     dx = None
     if need_dx:
         Wt = torch.empty(K, N, dtype=dt, device=dev)
         hip.transpose(W, K, 0, N, K, Wt, N)
         dx = torch.empty(M, K, dtype=dt, device=dev)
         hip.gemm(dy, Wt, dx, M=M, N=K, K=N, C1=N)
-    dyT = torch.empty(N, M, dtype=dt, device=dev)
-    hip.transpose(dy, N, 0, M, N, dyT, M)
-    xT = torch.empty(K, M, dtype=dt, device=dev)
-    hip.transpose(x, K, 0, M, K, xT, M)
+    alloc = torch.empty if Mp == M else torch.zeros
+    dyT = alloc(N, Mp, dtype=dt, device=dev)
+    hip.transpose(dy, N, 0, M, N, dyT, Mp)
+    xT = alloc(K, Mp, dtype=dt, device=dev)
+    hip.transpose(x, K, 0, M, K, xT, Mp)
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xT, dW, M=N, N=K, K=M, C1=M, epilogue=EPI_OUT_F32)
+    hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
     db = hip.colsum(dy, M, N) if need_db else None
     return dx, dW, db
 
@@ -108,20 +110,22 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     M, Cin = x.shape
     Cout = Wk.shape[0]
     taps = 3 if temporal else 9
-    assert Wk.shape == (Cout, taps * Cin) and dy.shape == (M, Cout) and M % 64 == 0 and Cin % 64 == 0 and Cout % 64 == 0
+    assert Wk.shape == (Cout, taps * Cin) and dy.shape == (M, Cout) and M % 8 == 0 and Cin % 64 == 0 and Cout % 64 == 0
     dev, dt = hip.device, hip.dtype
+    Mp = -(-M // 64) * 64
+    alloc = torch.empty if Mp == M else torch.zeros
     dx = None
     if need_dx:
         W2 = Wk.reshape(Cout, taps, Cin).flip(1).permute(2, 1, 0).reshape(Cin, taps * Cout).contiguous()   # host re-layout
         dx = torch.empty(M, Cin, dtype=dt, device=dev)
         hip.gemm(dy, W2, dx, M=M, N=Cin, K=taps * Cout, C1=Cout, mode=A_CONV_T3 if temporal else A_CONV3X3, H=H, Wd=Wd, T=T)
     xcol = hip.gather_taps(x, M, Cin, H, Wd, T, temporal)
-    xcolT = torch.empty(taps * Cin, M, dtype=dt, device=dev)
-    hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, M)
-    dyT = torch.empty(Cout, M, dtype=dt, device=dev)
-    hip.transpose(dy, Cout, 0, M, Cout, dyT, M)
+    xcolT = alloc(taps * Cin, Mp, dtype=dt, device=dev)
+    hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, Mp)
+    dyT = alloc(Cout, Mp, dtype=dt, device=dev)
+    hip.transpose(dy, Cout, 0, M, Cout, dyT, Mp)
     dW = torch.empty(Cout, taps * Cin, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=M, C1=M, epilogue=EPI_OUT_F32)
+    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
     return dx, dW, hip.colsum(dy, M, Cout)
 
 

@@ -119,7 +119,7 @@ class UNetTrain:
         b = self.master[name + ".bias"] if bias else None
         # 16-bit outputs of a handful of rows are allocated with their rows padded to 64 (zeros): they are the A operand of
         # the next small GEMM and of its weight-gradient GEMM (K loop over rows).  fp32 outputs (per-unit vectors) are exact.
-        Mp = M if (out_f32 or M % 64 == 0) else -(-M // 64) * 64
+        Mp = 64 if (M < 64 and not out_f32) else M
         y = torch.zeros(Mp, N, dtype=torch.float32 if out_f32 else self.dt, device=self.device)
         hip.gemm(x, W, y, M=M, N=N, K=K, C1=K, bias=b, epilogue=EPI_OUT_F32 if out_f32 else 0,
                  res1=res, ldr1=N if res is not None else 0, beta1=1.0 if res is not None else 0.0,
@@ -179,12 +179,13 @@ class UNetTrain:
                 dx = torch.empty(4 * M_out, Cin, dtype=self.dt, device=self.device)
                 hip.gemm(dil, W2, dx, M=4 * M_out, N=Cin, K=9 * Wp.shape[0], C1=Wp.shape[0], mode=A_CONV3X3, H=2 * H, Wd=2 * W)
                 xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
-                xcolT = torch.empty(9 * Cin, M_out, dtype=self.dt, device=self.device)
-                hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, M_out)
-                dyT = torch.empty(dyp.shape[1], M_out, dtype=self.dt, device=self.device)
-                hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, M_out)
+                Mp = -(-M_out // 64) * 64
+                xcolT = torch.zeros(9 * Cin, Mp, dtype=self.dt, device=self.device)
+                hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
+                dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
+                hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
                 dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
-                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=M_out, C1=M_out, epilogue=EPI_OUT_F32)
+                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
                 db = hip.colsum(dy, M_out, Cout)
             else:
                 dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3))
