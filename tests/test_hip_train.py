@@ -404,6 +404,12 @@ def test_trainer_steps_reduce_the_loss_and_follow_adamw(golden):
     # dead parameters (no gradient) are untouched
     dead = "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_q.weight"
     assert torch.equal(net.master[dead].cpu(), torch.from_numpy(np.asarray(sd[dead])))
+    # --train_param_type new (train_svd.py:658-659): only the action / noise-level embedding parameters move
+    net2 = UNetTrain(cfg, sd, DEV, hip=hip)
+    Trainer(net2, lr=lr, train_param_type="new").step(st)
+    moved = [k for k in sd if not torch.equal(net2.master[k].cpu(), torch.from_numpy(np.asarray(sd[k])))]
+    assert moved and all(("action" in k) or ("noise" in k) for k in moved), moved[:5]
+    assert "add_action_proj.proj.weight" in moved and "add_embedding_noise.linear_1.weight" in moved
 
 
 @pytest.mark.gpu

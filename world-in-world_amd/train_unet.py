@@ -545,8 +545,13 @@ class Trainer:
     (gradients are copied into its flat buffer, reduced-scattered, the owned slices updated, parameters all-gathered)."""
 
     def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 optimizer=None, loss_scale: Optional[float] = None):
+                 optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full"):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
+        # which parameters are updated — the reference's `--train_param_type` (train_svd.py:655-663)
+        self.trainable = {"full": lambda n: True,
+                          "new": lambda n: ("action" in n) or ("noise" in n),
+                          "new+temp_layer": lambda n: ("temporal_transformer_block" in n) or ("action" in n) or ("noise" in n),
+                          }[train_param_type]
         # static loss scale for fp16 (halved, and the step skipped, when a gradient comes back non-finite); 1 for bf16
         self.loss_scale = (2.0 ** 14 if net.dt == torch.float16 else 1.0) if loss_scale is None else loss_scale
         self.opt = optimizer
@@ -570,12 +575,15 @@ class Trainer:
         self.steps += 1
         if self.opt is None:
             for name, g in grads.items():                                  # parameters without a gradient (the dead ones) stay
+                if not self.trainable(name):
+                    continue
                 p = net.master[name]
                 hip.adamw_step(p.view(-1), g.reshape(-1).contiguous(), self.m[name].view(-1), self.v[name].view(-1), self.steps,
                                self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
         else:
             for name, g in grads.items():
-                self.opt.view(self.opt.grads, name).copy_(g)
+                if self.trainable(name):
+                    self.opt.view(self.opt.grads, name).copy_(g)
             self.opt.step()
             for name in net.master:
                 net.master[name].copy_(self.opt.view(self.opt.params, name))
