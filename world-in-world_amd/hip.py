@@ -389,9 +389,10 @@ class Hip:
         return partial.sum() / n, grad
 
     # ---- backward building blocks (row f2; csrc/train.hip)
-    def colsum(self, X, rows, Cn, parts=64):
-        """fp32 [Cn] column sums of X [rows, Cn] (16-bit or fp32): two fixed-order launches (partials, then their sum)."""
-        parts = max(1, min(parts, rows))
+    def colsum(self, X, rows, Cn, parts=None):
+        """fp32 [Cn] column sums of X [rows, Cn] (16-bit or fp32): two fixed-order launches (partials, then their sum).
+        parts (default: ~128 rows per partial, at most 512): the row classes summed in parallel by the first launch."""
+        parts = max(1, min(512, rows // 128)) if parts is None else max(1, min(parts, rows))
         part = torch.empty(parts, Cn, dtype=torch.float32, device=self.device)
         self._ck(self.lib.wiw_colsum(self._stream(), _p(X), int(X.dtype == torch.float32), rows, Cn, parts, _p(part)), "wiw_colsum")
         if parts == 1:

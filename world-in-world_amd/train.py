@@ -65,6 +65,20 @@ def prepare_step(latents: torch.Tensor, noise: torch.Tensor, sigma: float, cond_
 # ------------------------------------------------------------------------------------------------
 # backward building blocks on the existing kernels (no new GEMM code: the gradients of a GEMM are GEMMs on transposed operands)
 # ------------------------------------------------------------------------------------------------
+def wgrad_splitk(n_rows_out: int, n_cols_out: int, k_rows: int) -> int:
+    """Split-K factor of a weight-gradient GEMM dW [n_rows_out, n_cols_out] = A^T B whose K loop runs over k_rows (the M rows
+    of the layer: up to 129 024) while the output has a handful of tiles (dW of a 320 x 320 projection: 2 x 2 tiles of 256 x 160
+    for 256 CUs).  The K loop is cut into S ranges (WiwGemmArgs.splitk: fp32 slabs + a deterministic reduce): the largest
+    divisor of the K-tile count that keeps >= 8 K tiles per range and the item count around two per CU."""
+    nk = k_rows // 64
+    tiles = -(-n_rows_out // 256) * -(-n_cols_out // 160)
+    best = 1
+    for s in range(2, 129):
+        if nk % s == 0 and nk // s >= 8 and tiles * s <= 640:
+            best = s
+    return best
+
+
 def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True):
     """Backward of y = x . W^T (+ b) with x [M, K], W [N, K], dy [M, N] in the Hip's 16-bit type (M, N, K % 64 == 0):
          dx [M, K] (16-bit)  = dy . W              -> wiw_gemm_bf16(A = dy, W = W^T)
@@ -91,7 +105,7 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
     xT = alloc(K, Mp, dtype=dt, device=dev)
     hip.transpose(x, K, 0, M, K, xT, Mp)
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
+    hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(N, K, Mp))
     db = hip.colsum(dy, M, N) if need_db else None
     return dx, dW, db
 
@@ -125,7 +139,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     dyT = alloc(Cout, Mp, dtype=dt, device=dev)
     hip.transpose(dy, Cout, 0, M, Cout, dyT, Mp)
     dW = torch.empty(Cout, taps * Cin, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
+    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(Cout, taps * Cin, Mp))
     return dx, dW, hip.colsum(dy, M, Cout)
 
 

@@ -53,8 +53,16 @@ class Tape:
 
     def run(self, out: torch.Tensor, dout: torch.Tensor) -> None:
         self.add(out, dout)
-        for fn in reversed(self.ops):
-            fn()
+        while self.ops:                                # each closure (and the activations it holds) is dropped once it has run
+            self.ops.pop()()
+        self.release()
+
+    def release(self) -> None:
+        """Break the tape <-> closure reference cycles NOW: the saved activations of a step (55 GiB at 576x1024x14) must not
+        wait for Python's cyclic garbage collector."""
+        self.ops.clear()
+        self.g.clear()
+        self.keep.clear()
 
 
 def _pad_rows(t: torch.Tensor, mult: int = 64) -> torch.Tensor:
@@ -185,7 +193,9 @@ class UNetTrain:
                 dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
                 hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
                 dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
-                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32)
+                from .train import wgrad_splitk
+                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32,
+                         splitk=wgrad_splitk(dyp.shape[1], 9 * Cin, Mp))
                 db = hip.colsum(dy, M_out, Cout)
             else:
                 dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3))
@@ -458,6 +468,8 @@ class UNetTrain:
                 action_ids: torch.Tensor) -> torch.Tensor:
         """sample (1,T,8,h,w); ehs (1,1,Dctx); added_time_ids (1,3); action_ids (1,T,Ch).  Returns (1,T,4,h,w) fp32."""
         cfg, hip, dev, dt = self.cfg, self.hip, self.device, self.dt
+        if getattr(self, "tape", None) is not None:
+            self.tape.release()                         # a forward without a backward (evaluation) leaves its tape behind
         self.tape, self.grads = Tape(hip), {}
         T, ch, n, L = cfg.num_frames, cfg.block_out_channels, len(cfg.block_out_channels), cfg.layers_per_block
         _, _, cin, h, w = sample.shape
@@ -532,6 +544,7 @@ class UNetTrain:
         reference runs fp16 under accelerate's GradScaler, train_svd.py:699, 971-975); bf16 needs none."""
         dy = (dpred[0].permute(0, 2, 3, 1).reshape(-1, dpred.shape[2]) * loss_scale).to(self.device, self.dt).contiguous()
         self.tape.run(self._out, dy)
+        self._out = None
         if loss_scale != 1.0:
             inv = 1.0 / loss_scale
             self.grads = {k: v.float() * inv for k, v in self.grads.items()}
