@@ -443,3 +443,50 @@ def test_full_width_training_step_runs(golden):
     assert not bad, bad[:5]
     print(f"[f2] full-width step at 32x64x14: loss {float(loss):.4f}, {len(grads)} gradients, peak memory "
           f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
+@pytest.mark.gpu
+def test_trainer_with_sharded_adamw_over_rccl_single_rank(golden):
+    """Trainer + parallel.ShardedAdamW on a one-rank `nccl` group (the box has one GPU): reduce_scatter_tensor / all_gather_into_tensor
+    on device buffers, the flat bucket layout and `wiw_adamw_step` on the owned slices give the SAME parameters, bit for bit, as
+    the per-tensor single-process update."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.parallel import ShardedAdamW
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    hip = Hip(torch.device(DEV))
+    sd = random_state_dict(cfg, int(g["weight_seed"]))
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]))
+    solo = UNetTrain(cfg, sd, DEV, hip=hip)
+    Trainer(solo, lr=1e-3).step(st)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(torch.device(DEV))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        net = UNetTrain(cfg, sd, DEV, hip=hip)
+        opt = ShardedAdamW({k: tuple(v.shape) for k, v in net.master.items()}, torch.device(DEV),
+                           lambda p, gr, m, v, step, lr, b1, b2, eps, wd: hip.adamw_step(p, gr, m, v, step, lr, b1, b2, eps, wd),
+                           bucket_elems=1 << 20, lr=1e-3)
+        assert opt.n_buckets > 3
+        Trainer(net, lr=1e-3, optimizer=opt).step(st)
+        live = [k for k in sd if not torch.equal(solo.master[k].cpu(), torch.from_numpy(np.asarray(sd[k])))]
+        assert len(live) > 1000
+        # weight decay also touches the parameters without a gradient in the flat update; compare the ones the step trains
+        diff = max(float((net.master[k] - solo.master[k]).abs().max()) for k in live)
+        assert diff == 0.0, diff
+    finally:
+        dist.destroy_process_group()

@@ -598,8 +598,9 @@ class Trainer:
                 if self.trainable(name):
                     self.opt.view(self.opt.grads, name).copy_(g)
             self.opt.step()
-            for name in net.master:
-                net.master[name].copy_(self.opt.view(self.opt.params, name))
+            for name in grads:                                           # parameters without a gradient / frozen ones are not
+                if self.trainable(name):                                 # read back (torch.optim.AdamW skips them too)
+                    net.master[name].copy_(self.opt.view(self.opt.params, name))
         net.refresh()
         return float(loss)
 
