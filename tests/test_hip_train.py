@@ -271,10 +271,12 @@ def test_feedforward_block_forward_backward():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seqs,S,heads", [(2, 128, 1), (3, 144, 2), (1, 512, 5), (2, 16, 1)])
+@pytest.mark.parametrize("seqs,S,heads", [(2, 128, 1), (3, 144, 2), (1, 512, 5), (2, 16, 1), (2, 160, 2), (1, 2304, 2), (2, 96, 1)])
 def test_attention_backward(seqs, S, heads):
     """dQ, dK, dV of softmax(Q K^T / 8) V against torch autograd on the same 16-bit-rounded q, k, v, dO (O from the forward
-    kernel).  Probabilities and dS pass through 16 bits inside the kernel: attention-class tolerance 2e-2 / 8e-3."""
+    kernel).  Probabilities and dS pass through 16 bits inside the kernel: attention-class tolerance 2e-2 / 8e-3.
+    S >= 128 with S % 32 == 0 takes the LDS-tiled kernels (160: a workgroup with idle waves; 2304: 18 workgroups per head),
+    the others the one-wave-per-tile form."""
     import torch.nn.functional as F
 
     import wiw_amd  # noqa: F401
@@ -449,7 +451,8 @@ def test_full_width_training_step_runs(golden):
 def test_trainer_with_sharded_adamw_over_rccl_single_rank(golden):
     """Trainer + parallel.ShardedAdamW on a one-rank `nccl` group (the box has one GPU): reduce_scatter_tensor / all_gather_into_tensor
     on device buffers, the flat bucket layout and `wiw_adamw_step` on the owned slices give the SAME parameters, bit for bit, as
-    the per-tensor single-process update."""
+    the per-tensor single-process update — over two steps, the second with the buckets reduced asynchronously while the
+    backward still runs."""
     import os
     import socket
 
@@ -471,7 +474,9 @@ def test_trainer_with_sharded_adamw_over_rccl_single_rank(golden):
                         torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
                         float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]))
     solo = UNetTrain(cfg, sd, DEV, hip=hip)
-    Trainer(solo, lr=1e-3).step(st)
+    solo_tr = Trainer(solo, lr=1e-3)
+    solo_tr.step(st)
+    solo_tr.step(st)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(torch.device(DEV))
@@ -482,7 +487,11 @@ def test_trainer_with_sharded_adamw_over_rccl_single_rank(golden):
                            lambda p, gr, m, v, step, lr, b1, b2, eps, wd: hip.adamw_step(p, gr, m, v, step, lr, b1, b2, eps, wd),
                            bucket_elems=1 << 20, lr=1e-3)
         assert opt.n_buckets > 3
-        Trainer(net, lr=1e-3, optimizer=opt).step(st)
+        tr = Trainer(net, lr=1e-3, optimizer=opt)
+        tr.step(st)                                  # step 1 learns which parameters get a gradient (synchronous buckets)
+        assert opt.async_launched == 0
+        tr.step(st)                                  # step 2 hands buckets to the reduce-scatter DURING the backward
+        assert opt.async_launched >= opt.n_buckets - 1, (opt.async_launched, opt.n_buckets)
         live = [k for k in sd if not torch.equal(solo.master[k].cpu(), torch.from_numpy(np.asarray(sd[k])))]
         assert len(live) > 1000
         # weight decay also touches the parameters without a gradient in the flat update; compare the ones the step trains

@@ -208,19 +208,34 @@ def _zero_run(rank, world, port, q):
         assert opt.n_buckets == 3 and opt.master.numel() == 3 * opt.slice
         ref = {k: v.clone().requires_grad_(True) for k, v in init.items()}
         ropt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.05)
-        for step in range(3):
+        for step in range(4):
             mean_grads = {}
-            for k, s in shapes.items():
+            for k, s in reversed(list(shapes.items())):               # a backward produces the last parameters first
                 per_rank = [torch.randn(*s, generator=torch.Generator().manual_seed(100 * step + 10 * r + len(k))) for r in range(world)]
-                opt.view(opt.grads, k).copy_(per_rank[rank])          # this rank's local gradient
+                if step >= 2:                                          # gradients handed over as they complete: a bucket goes
+                    opt.notify(k, per_rank[rank].reshape(-1) if step == 3 else per_rank[rank], set(shapes))   # out asynchronously
+                else:
+                    opt.view(opt.grads, k).copy_(per_rank[rank])      # this rank's local gradient
                 mean_grads[k] = sum(per_rank) / world
             if step == 1:
-                opt.reduce_bucket(opt.n_buckets - 1)                   # a bucket handed over early by the backward
+                opt.reduce_bucket(opt.n_buckets - 1)                   # a bucket handed over early, synchronously
+            if step >= 2:
+                assert opt.async_launched == (step - 1) * opt.n_buckets and all(opt._reduced)
             opt.step()
             for k in shapes:
                 ref[k].grad = mean_grads[k]
             ropt.step()
         err = max(float((opt.view(opt.params, k) - ref[k].detach()).abs().max()) for k in shapes)
+        # a gradient that was NOT announced and arrives after its bucket went out is an error, not a silent drop
+        for k in ("b.weight", "a.bias", "a.weight"):
+            opt.notify(k, torch.zeros(shapes[k]), set(shapes) - {"c"})
+        try:
+            opt.notify("c", torch.zeros(1), set(shapes) - {"c"})
+            late = False
+        except RuntimeError:
+            late = True
+        opt.step()
+        assert late
         full = [None] * world
         dist.all_gather_object(full, opt.params.clone())
         if rank == 0:

@@ -569,6 +569,302 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// LDS-tiled forms of the two kernels above for the spatial attention's long sequences (S == Sp, S % 32 == 0, S >= 128).
+// One workgroup = 4 waves = 128 rows of one (sequence, head); every wave keeps ITS 32 rows' fragments and accumulators in
+// registers and the four share each 32-row tile of the other side through LDS (loaded once per workgroup, the next tile's
+// global loads in flight behind the MFMAs) — the simple form re-read every tile per wave through L1, which bounded it.
+// The contraction of the second GEMMs runs over 32 rows per MFMA (both halves of the 16x16x32 K used): the two score tiles
+// of a step are packed into ONE B operand under the k permutation  e < 4 -> row 4 fq + e,  e >= 4 -> row 16 + 4 fq + e - 4,
+// and the transposed A operand is read from LDS under the same permutation (two 8-byte reads).
+// Per step and wave: 32 MFMAs (dK/dV), 24 + 8 (dQ + its log-sum-exp pass), 16 KB of LDS reads.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int ATB_ROW = 72;    // elements per LDS row of a [32 rows][64 d] tile (144 B: 16-byte reads of 16 rows spread over the banks)
+constexpr int ATB_TROW = 40;   // elements per LDS row of a [64 d][32 rows] transposed tile (80 B)
+
+__device__ __forceinline__ bf16x8 atb_tr_frag(const uint16_t* base) {     // rows 4 fq .. +3 and 16 + 4 fq .. +3 of one d
+    const uint2 lo = *(const uint2*)base, hi = *(const uint2*)(base + 16);
+    union { uint32_t u[4]; bf16x8 v; } x;
+    x.u[0] = lo.x; x.u[1] = lo.y; x.u[2] = hi.x; x.u[3] = hi.y;
+    return x.v;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+                                                                  const uint16_t* __restrict__ Qt, const uint16_t* __restrict__ dOt,
+                                                                  int64_t ldt, const uint16_t* __restrict__ dO, int ldo,
+                                                                  uint16_t* __restrict__ dQKV, int ldd, const float* __restrict__ LSE,
+                                                                  const float* __restrict__ Dsum, int S, int heads, int k_blocks,
+                                                                  float scale, float scale_log2e) {
+    static_assert(D == 64, "head_dim 64");
+    __shared__ __attribute__((aligned(16))) uint16_t Qs[32 * ATB_ROW];
+    __shared__ __attribute__((aligned(16))) uint16_t dOs[32 * ATB_ROW];
+    __shared__ __attribute__((aligned(16))) uint16_t Qts[64 * ATB_TROW];
+    __shared__ __attribute__((aligned(16))) uint16_t dOts[64 * ATB_TROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kb = (int)(blockIdx.x % k_blocks);
+    const int h = (int)((blockIdx.x / k_blocks) % heads);
+    const int64_t seq = blockIdx.x / ((int64_t)k_blocks * heads);
+    const int64_t row0 = seq * S;
+    const int key0 = kb * 128 + wave * 32;
+    const bool active = key0 < S;                      // wave-uniform: S % 32 == 0
+    bf16x8 kf[2][2], vf[2][2];
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int64_t krow = row0 + (active ? key0 + kt * 16 + fr : 0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[kt][kk] = *(const bf16x8*)(QKV + krow * ld + k_off + h * D + kk * 32 + fq * 8);
+            vf[kt][kk] = *(const bf16x8*)(QKV + krow * ld + v_off + h * D + kk * 32 + fq * 8);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { dk[kt][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][db] = dk[kt][db]; }
+    }
+    const int lr = tid >> 3, lc = (tid & 7) * 8;       // loader: [32][64] tiles, 16 bytes per thread
+    const int tr = tid >> 2, tc = (tid & 3) * 8;       //         [64][32] transposed tiles
+    const uint16_t* gq = QKV + (row0 + lr) * ld + h * D + lc;
+    const uint16_t* gdo = dO + (row0 + lr) * ldo + h * D + lc;
+    const uint16_t* gqt = Qt + (int64_t)(h * D + tr) * ldt + row0 + tc;
+    const uint16_t* gdot = dOt + (int64_t)(h * D + tr) * ldt + row0 + tc;
+    uint4 r0 = *(const uint4*)gq, r1 = *(const uint4*)gdo, r2 = *(const uint4*)gqt, r3 = *(const uint4*)gdot;
+    const float* lse_p = LSE + (seq * heads + h) * S;
+    const float* dsum_p = Dsum + (seq * heads + h) * S;
+    const int nq = S / 32;
+    for (int qt = 0; qt < nq; ++qt) {
+        __syncthreads();                               // every wave is done with the previous tile
+        *(uint4*)(Qs + lr * ATB_ROW + lc) = r0;
+        *(uint4*)(dOs + lr * ATB_ROW + lc) = r1;
+        *(uint4*)(Qts + tr * ATB_TROW + tc) = r2;
+        *(uint4*)(dOts + tr * ATB_TROW + tc) = r3;
+        __syncthreads();
+        if (qt + 1 < nq) {                             // next tile: in flight behind this tile's MFMAs
+            r0 = *(const uint4*)(gq + (int64_t)(qt + 1) * 32 * ld);
+            r1 = *(const uint4*)(gdo + (int64_t)(qt + 1) * 32 * ldo);
+            r2 = *(const uint4*)(gqt + (qt + 1) * 32);
+            r3 = *(const uint4*)(gdot + (qt + 1) * 32);
+        }
+        if (!active) continue;
+        union { uint32_t u[4]; bf16x8 v; } po[2], dso[2];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            bf16x8 aq[2], ado[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                aq[kk] = *(const bf16x8*)(Qs + (qs * 16 + fr) * ATB_ROW + kk * 32 + fq * 8);
+                ado[kk] = *(const bf16x8*)(dOs + (qs * 16 + fr) * ATB_ROW + kk * 32 + fq * 8);
+            }
+            const float4 l4 = *(const float4*)(lse_p + qt * 32 + qs * 16 + fq * 4);
+            const float4 d4 = *(const float4*)(dsum_p + qt * 32 + qs * 16 + fq * 4);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    sm = WIW_MFMA(aq[kk], kf[kt][kk], sm);       // lane: key fr of tile kt, queries 16 qs + 4 fq + r
+                    dp = WIW_MFMA(ado[kk], vf[kt][kk], dp);
+                }
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(sm[r] * scale_log2e - lv[r]);
+                    dsv[r] = pv[r] * (dp[r] - dd[r]);
+                }
+                po[kt].u[2 * qs] = pack2bf(pv[0], pv[1]);   po[kt].u[2 * qs + 1] = pack2bf(pv[2], pv[3]);
+                dso[kt].u[2 * qs] = pack2bf(dsv[0], dsv[1]); dso[kt].u[2 * qs + 1] = pack2bf(dsv[2], dsv[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 x1 = atb_tr_frag(dOts + (db * 16 + fr) * ATB_TROW + fq * 4);
+            const bf16x8 x2 = atb_tr_frag(Qts + (db * 16 + fr) * ATB_TROW + fq * 4);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                dv[kt][db] = WIW_MFMA(x1, po[kt].v, dv[kt][db]);     // dV^T[d][key] += dO^T[d][q] P[q][key], 32 queries deep
+                dk[kt][db] = WIW_MFMA(x2, dso[kt].v, dk[kt][db]);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        uint16_t* dkd = dQKV + (row0 + key0 + kt * 16 + fr) * ldd + k_off + h * D + fq * 4;   // lane: key fr, d = 16 db + 4 fq + r
+        uint16_t* dvd = dQKV + (row0 + key0 + kt * 16 + fr) * ldd + v_off + h * D + fq * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 pk;
+            pk.x = pack2bf(dk[kt][db][0] * scale, dk[kt][db][1] * scale); pk.y = pack2bf(dk[kt][db][2] * scale, dk[kt][db][3] * scale);
+            *(uint2*)(dkd + db * 16) = pk;
+            pk.x = pack2bf(dv[kt][db][0], dv[kt][db][1]); pk.y = pack2bf(dv[kt][db][2], dv[kt][db][3]);
+            *(uint2*)(dvd + db * 16) = pk;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+                                                                 const uint16_t* __restrict__ Kt, int64_t ldt,
+                                                                 const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, int ldo,
+                                                                 uint16_t* __restrict__ dQKV, int ldd, float* __restrict__ LSE,
+                                                                 float* __restrict__ Dsum, int S, int heads, int q_blocks, float scale,
+                                                                 float scale_log2e) {
+    static_assert(D == 64, "head_dim 64");
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[32 * ATB_ROW];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[32 * ATB_ROW];
+    __shared__ __attribute__((aligned(16))) uint16_t Kts[64 * ATB_TROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int qb = (int)(blockIdx.x % q_blocks);
+    const int h = (int)((blockIdx.x / q_blocks) % heads);
+    const int64_t seq = blockIdx.x / ((int64_t)q_blocks * heads);
+    const int64_t row0 = seq * S;
+    const int q0 = qb * 128 + wave * 32;
+    const bool active = q0 < S;
+    bf16x8 qf[2][2], dof[2][2];
+    float dsum[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int64_t qrow = row0 + (active ? q0 + qt * 16 + fr : 0);
+        const uint16_t* qs = QKV + qrow * ld + h * D;
+        const uint16_t* os = O + qrow * ldo + h * D;
+        const uint16_t* ds = dO + qrow * ldo + h * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[qt][kk] = *(const bf16x8*)(qs + kk * 32 + fq * 8);
+            dof[qt][kk] = *(const bf16x8*)(ds + kk * 32 + fq * 8);
+            float a[8], b[8];
+            unpack8(*(const uint4*)(os + kk * 32 + fq * 8), a);
+            unpack8(*(const uint4*)(ds + kk * 32 + fq * 8), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(a[e], b[e], acc);
+        }
+        dsum[qt] = xor32_sum(xor16_sum(acc));          // D of query fr of tile qt (same summation order as the simple form)
+    }
+    const int lr = tid >> 3, lc = (tid & 7) * 8;
+    const int tr = tid >> 2, tc = (tid & 3) * 8;
+    const uint16_t* gk = QKV + (row0 + lr) * ld + k_off + h * D + lc;
+    const uint16_t* gv = QKV + (row0 + lr) * ld + v_off + h * D + lc;
+    const uint16_t* gkt = Kt + (int64_t)(h * D + tr) * ldt + row0 + tc;
+    const int nk = S / 32;
+    // ---- pass 1: row log-sum-exp (log2 domain) over all keys
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    uint4 r0 = *(const uint4*)gk, r1, r2;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        *(uint4*)(Ks + lr * ATB_ROW + lc) = r0;
+        __syncthreads();
+        if (kt + 1 < nk) r0 = *(const uint4*)(gk + (int64_t)(kt + 1) * 32 * ld);
+        if (!active) continue;
+        f32x4 st[2][2];                                // [key half ks][query tile qt]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ak[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ak[kk] = *(const bf16x8*)(Ks + (ks * 16 + fr) * ATB_ROW + kk * 32 + fq * 8);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                st[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) st[ks][qt] = WIW_MFMA(ak[kk], qf[qt][kk], st[ks][qt]);   // lane: query fr, keys 16 ks + 4 fq + r
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[ks][qt][r] * scale_log2e);
+            mx = xor32_max(xor16_max(mx));
+            const float m_new = fmaxf(m_run[qt], mx);
+            float ls = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ls += __builtin_amdgcn_exp2f(st[ks][qt][r] * scale_log2e - m_new);
+            ls = xor32_sum(xor16_sum(ls));
+            l_run[qt] = l_run[qt] * __builtin_amdgcn_exp2f(m_run[qt] - m_new) + ls;
+            m_run[qt] = m_new;
+        }
+    }
+    float lse2[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        lse2[qt] = m_run[qt] + __builtin_amdgcn_logf(l_run[qt]);
+        if (active && fq == 0) {
+            LSE[(seq * heads + h) * S + q0 + qt * 16 + fr] = lse2[qt];
+            Dsum[(seq * heads + h) * S + q0 + qt * 16 + fr] = dsum[qt];
+        }
+    }
+    // ---- pass 2: dQ^T[d][q] += K^T[d][key] dS^T[key][q], 32 keys deep
+    f32x4 dq[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[qt][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r0 = *(const uint4*)gk; r1 = *(const uint4*)gv; r2 = *(const uint4*)gkt;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        *(uint4*)(Ks + lr * ATB_ROW + lc) = r0;
+        *(uint4*)(Vs + lr * ATB_ROW + lc) = r1;
+        *(uint4*)(Kts + tr * ATB_TROW + tc) = r2;
+        __syncthreads();
+        if (kt + 1 < nk) {
+            r0 = *(const uint4*)(gk + (int64_t)(kt + 1) * 32 * ld);
+            r1 = *(const uint4*)(gv + (int64_t)(kt + 1) * 32 * ld);
+            r2 = *(const uint4*)(gkt + (kt + 1) * 32);
+        }
+        if (!active) continue;
+        union { uint32_t u[4]; bf16x8 v; } dso[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ak[2], av[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                ak[kk] = *(const bf16x8*)(Ks + (ks * 16 + fr) * ATB_ROW + kk * 32 + fq * 8);
+                av[kk] = *(const bf16x8*)(Vs + (ks * 16 + fr) * ATB_ROW + kk * 32 + fq * 8);
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    st = WIW_MFMA(ak[kk], qf[qt][kk], st);       // lane: query fr of tile qt, keys 16 ks + 4 fq + r
+                    dp = WIW_MFMA(av[kk], dof[qt][kk], dp);      // dP^T = V dO^T
+                }
+                float dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsv[r] = __builtin_amdgcn_exp2f(st[r] * scale_log2e - lse2[qt]) * (dp[r] - dsum[qt]);
+                dso[qt].u[2 * ks] = pack2bf(dsv[0], dsv[1]);
+                dso[qt].u[2 * ks + 1] = pack2bf(dsv[2], dsv[3]);
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 x = atb_tr_frag(Kts + (db * 16 + fr) * ATB_TROW + fq * 4);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) dq[qt][db] = WIW_MFMA(x, dso[qt].v, dq[qt][db]);   // lane: query fr, d = 16 db + 4 fq + r
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        uint16_t* dst = dQKV + (row0 + q0 + qt * 16 + fr) * ldd + h * D + fq * 4;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 pk;
+            pk.x = pack2bf(dq[qt][db][0] * scale, dq[qt][db][1] * scale);
+            pk.y = pack2bf(dq[qt][db][2] * scale, dq[qt][db][3] * scale);
+            *(uint2*)(dst + db * 16) = pk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Small glue kernels of the training graph (HBM-bound, 16 bytes per thread)
 // ---------------------------------------------------------------------------------------------------------------------
 // out = a x + b y (y may be NULL)
@@ -722,6 +1018,18 @@ extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_of
     WIW_REQUIRE(total < (1ll << 32), "attn_bwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float LOG2E_ = 1.4426950408889634f;
+    if (S == Sp && S % 32 == 0 && S >= 128) {          // long (spatial) sequences: the LDS-tiled kernels, 128 rows per workgroup
+        const int blocks128 = (S + 127) / 128;
+        const int64_t grid = (int64_t)seqs * heads * blocks128;
+        WIW_REQUIRE(ld % 8 == 0 && ldt % 8 == 0 && ldd % 4 == 0, "attn_bwd: misaligned strides (tiled form)");
+        hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
+                           v_off, (const uint16_t*)Kt, ldt, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
+                           dsum, S, heads, blocks128, scale, scale * LOG2E_);
+        hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
+                           v_off, (const uint16_t*)Qt, (const uint16_t*)dOt, ldt, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
+                           dsum, S, heads, blocks128, scale, scale * LOG2E_);
+        return wiw_check_launch("wiw_attn_bwd_bf16");
+    }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
                        v_off, (const uint16_t*)Kt, ldt, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum,
                        S, Sp, heads, tiles, total, scale, scale * LOG2E_);

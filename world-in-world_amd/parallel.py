@@ -265,6 +265,30 @@ class ShardedAdamW:
         self.gshard = torch.zeros_like(self.master)
         self.steps = 0
         self._reduced = [False] * self.n_buckets
+        self._work = []                                       # in-flight asynchronous bucket reductions
+        self.async_launched = 0                               # buckets handed over during a backward (tests / logs)
+        # which parameters touch which bucket: a bucket is handed to the reduce-scatter as soon as ALL of them have a gradient
+        self._bucket_names = [set() for _ in range(self.n_buckets)]
+        for name, (o, n, _) in self.offsets.items():
+            for b in range(o // self.bucket, (o + max(n, 1) - 1) // self.bucket + 1):
+                self._bucket_names[b].add(name)
+        self._pending = [set(x) for x in self._bucket_names]
+
+    def notify(self, name: str, grad: torch.Tensor, expected: Optional[set] = None) -> None:
+        """Called by the backward pass as soon as `name`'s gradient is complete: it is copied into the flat buffer, and every
+        bucket whose parameters are now all in is reduce-scattered ASYNCHRONOUSLY while the backward goes on (the collective
+        runs on RCCL's own stream; `step` waits for the handles).  `expected`: the names that will get a gradient this step
+        (dead / frozen parameters are not waited for)."""
+        dst = self.view(self.grads, name)
+        dst.copy_(grad.reshape(dst.shape))
+        o, n, _ = self.offsets[name]
+        for b in range(o // self.bucket, (o + max(n, 1) - 1) // self.bucket + 1):
+            if self._reduced[b]:
+                raise RuntimeError(f"{name}: gradient arrived after its bucket {b} had been reduced (not in `expected`)")
+            self._pending[b].discard(name)
+            left = self._pending[b] if expected is None else (self._pending[b] & expected)
+            if not left and not self._reduced[b]:
+                self.reduce_bucket(b, async_op=True)
 
     def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
         off, n, shp = self.offsets[name]
@@ -278,18 +302,30 @@ class ShardedAdamW:
             lo = b * self.bucket + self.rank * self.slice
             self.master[b * self.slice:(b + 1) * self.slice] = self.params[lo:lo + self.slice]
 
-    def reduce_bucket(self, b: int) -> None:
+    def reduce_bucket(self, b: int, async_op: bool = False) -> None:
         """Average bucket b's gradients over the ranks; this rank keeps its slice."""
         g = self.grads[b * self.bucket:(b + 1) * self.bucket]
         out = self.gshard[b * self.slice:(b + 1) * self.slice]
-        if dist.get_backend() == "nccl":
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.AVG)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            out.copy_(g[self.rank * self.slice:(self.rank + 1) * self.slice] / self.world)
         self._reduced[b] = True
+        self.async_launched += int(async_op)
+        if dist.get_backend() == "nccl":
+            w = dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.AVG, async_op=async_op)
+            if async_op:
+                self._work.append((w, None))
+        else:
+            w = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op)
+            fin = lambda: out.copy_(g[self.rank * self.slice:(self.rank + 1) * self.slice] / self.world)  # noqa: E731
+            if async_op:
+                self._work.append((w, fin))
+            else:
+                fin()
 
     def step(self) -> None:
+        for w, fin in self._work:                             # buckets handed over during the backward
+            w.wait()
+            if fin is not None:
+                fin()
+        self._work = []
         for b in range(self.n_buckets - 1, -1, -1):           # the last parameters' gradients are complete first
             if not self._reduced[b]:
                 self.reduce_bucket(b)
@@ -300,3 +336,4 @@ class ShardedAdamW:
                                         self.master[b * self.slice:(b + 1) * self.slice])
         self.grads.zero_()
         self._reduced = [False] * self.n_buckets
+        self._pending = [set(x) for x in self._bucket_names]

@@ -34,6 +34,7 @@ class Tape:
     def __init__(self, hip: Hip):
         self.hip, self.ops, self.g = hip, [], {}
         self.keep: List[torch.Tensor] = []            # tensors whose id() is a key must stay alive
+        self.after_op = None                          # hook: called after every backward closure (gradient hand-over)
 
     def add(self, t: torch.Tensor, g: torch.Tensor) -> None:
         k = id(t)
@@ -55,6 +56,8 @@ class Tape:
         self.add(out, dout)
         while self.ops:                                # each closure (and the activations it holds) is dropped once it has run
             self.ops.pop()()
+            if self.after_op is not None:
+                self.after_op()
         self.release()
 
     def release(self) -> None:
@@ -571,6 +574,7 @@ class Trainer:
         self.steps = 0
         self.m = {k: torch.zeros_like(v) for k, v in net.master.items()} if optimizer is None else None
         self.v = {k: torch.zeros_like(v) for k, v in net.master.items()} if optimizer is None else None
+        self._seen = None                                      # names that got a gradient in the previous step
         if optimizer is not None:
             optimizer.load(net.master)
 
@@ -581,7 +585,23 @@ class Trainer:
         net, hip = self.net, self.net.hip
         pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
         loss, dpred = TrainStep(hip).loss_and_grad(pred, st)
+        if self.opt is not None and self.loss_scale == 1.0 and self._seen is not None:
+            # hand every finished gradient to the sharded optimiser DURING the backward: its buckets are reduce-scattered
+            # (asynchronously, over all xGMI links) while the remaining operators still run.  Which parameters get a
+            # gradient is learnt from the first step (dead / frozen ones never do and must not be waited for).
+            sent = set()
+            expected = self._seen
+
+            def hand_over():
+                for name in list(net.grads):
+                    if name not in sent and self.trainable(name):
+                        sent.add(name)
+                        self.opt.notify(name, net.grads[name], expected)
+            net.tape.after_op = hand_over
+        overlapped = net.tape.after_op is not None
         grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
+        net.tape.after_op = None
+        self._seen = {n for n in grads if self.trainable(n)}
         if self.loss_scale != 1.0 and not all(bool(torch.isfinite(g).all()) for g in grads.values()):
             self.loss_scale *= 0.5                                         # overflow: skip the update, as a GradScaler does
             return float(loss)
@@ -594,9 +614,10 @@ class Trainer:
                 hip.adamw_step(p.view(-1), g.reshape(-1).contiguous(), self.m[name].view(-1), self.v[name].view(-1), self.steps,
                                self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
         else:
-            for name, g in grads.items():
-                if self.trainable(name):
-                    self.opt.view(self.opt.grads, name).copy_(g)
+            if not overlapped:                                           # first step, or fp16 (un-scaled after the backward)
+                for name, g in grads.items():
+                    if self.trainable(name):
+                        self.opt.view(self.opt.grads, name).copy_(g.reshape(net.master[name].shape))
             self.opt.step()
             for name in grads:                                           # parameters without a gradient / frozen ones are not
                 if self.trainable(name):                                 # read back (torch.optim.AdamW skips them too)
