@@ -309,8 +309,10 @@ int wiw_edm_loss_grad(void* stream, const float* pred, const float* noisy, const
 /* Backward building blocks of the same row (16-bit activations and activation gradients, fp32 parameter gradients; all
  * deterministic: fixed-order partials, no floating-point atomics).  The GEMM-shaped gradients (dX = dY . W, dW = dY^T . X) are
  * wiw_gemm_bf16 launches on transposed operands (wiw_transpose_bf16), see world-in-world_amd/train.py.
- *   wiw_colsum          out[p][c] = sum of rows p, p + parts, ... of X[rows][C] (X 16-bit, or fp32 with is_f32): bias gradients,
- *                       and (parts = 1 over fp32 partials) the final sum of per-wave partials.
+ *   wiw_colsum          out[p][c] = sum of the rows [p rpp, min(rows, (p + 1) rpp)), rpp = ceil(rows / parts), of X[rows][C]
+ *                       (X 16-bit with C % 8 == 0, or fp32 with is_f32 and C % 4 == 0; 16-byte aligned): bias gradients,
+ *                       per-frame sums (parts = frames x k, k | rows per frame, then parts = frames over the partials) and the
+ *                       final sum of per-wave partials.
  *   wiw_layernorm_bwd   nn.LayerNorm backward (dp/models/attention.py:659-694 norms): dX (16-bit) and per-wave partials
  *                       partial[w][0][C] = sum dy xhat, partial[w][1][C] = sum dy, w < wiw_layernorm_bwd_partials(rows).
  *   wiw_geglu_bwd       GEGLU backward (activations.py:117-123): P = [v | g] the saved projection output [rows][2 Ch],
@@ -333,8 +335,10 @@ int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H);
  *                       columns h*64, k_off + h*64, v_off + h*64;  Qt, Kt, dOt = transposes [heads*64][ldt] of the Q and K column
  *                       blocks and of dO (wiw_transpose_bf16);  O, dO [rows][ldo];  dQKV [rows][ldd] receives dQ | dK | dV at the
  *                       same column offsets;  lse, dsum: fp32 [seqs*heads*Sp] scratch (row log-sum-exp in the log2 domain and
- *                       D = sum_d dO O, written by the first kernel, read by the second).  FIRST form: one wave per 16-row tile,
- *                       operands from global memory, scores recomputed; deterministic, not tuned. */
+ *                       D = sum_d dO O, written by the first kernel, read by the second).  Scores are recomputed; deterministic.
+ *                       S == Sp, S % 32 == 0, S >= 128 (the spatial sequences; needs ldt % 8 == 0): LDS-tiled kernels, 128 rows
+ *                       per workgroup, 32-deep contraction steps; otherwise (temporal sequences of 14 padded to 16): one wave
+ *                       per 16-row tile, operands from global memory. */
 int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt, const void* dOt,
                       int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd, float* lse, float* dsum, int seqs,
                       int S, int Sp, int heads, int head_dim, float scale);

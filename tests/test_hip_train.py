@@ -165,6 +165,17 @@ def test_geglu_backward_and_colsum():
     cs = hip.colsum(X.to(DEV, torch.bfloat16), 1001, 192)
     assert _rel(cs, X.sum(0))[0] <= 1e-5
     assert _rel(hip.colsum(X.to(DEV), 1001, 192, parts=7), X.sum(0))[0] <= 1e-5      # fp32 input path
+    # per-frame sums in the same two launches (frames = contiguous row blocks), ragged column panels (C = 320: 1.25 panels of
+    # 256 columns; fp32 C = 644: 5.03 panels of 128), one part and many parts; bit-identical run to run
+    for rows, C, units in ((14 * 144, 320, 14), (3 * 2304, 1280, 3), (7 * 40, 64, 7), (5000, 2560, 1)):
+        X = bf(_rnd(rows, C, seed=rows))
+        ref = X.reshape(units, rows // units, C).sum(1)
+        got = hip.colsum(X.to(DEV, torch.bfloat16), rows, C, units=units).reshape(units, C)
+        assert _rel(got, ref)[0] <= 2e-5, (rows, C, units)
+        assert torch.equal(got, hip.colsum(X.to(DEV, torch.bfloat16), rows, C, units=units).reshape(units, C))
+    Xf = _rnd(777, 644, seed=9)
+    assert _rel(hip.colsum(Xf.to(DEV), 777, 644), Xf.sum(0))[0] <= 1e-5
+    assert _rel(hip.colsum(Xf.to(DEV), 777, 644, parts=1), Xf.sum(0))[0] <= 1e-5
 
 
 @pytest.mark.gpu

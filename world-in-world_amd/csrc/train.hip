@@ -79,19 +79,61 @@ __global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__
 // partials in a fixed order, no floating-point atomics.
 // ---------------------------------------------------------------------------------------------------------------------
 
-// out[p][c] = sum over rows r = p, p + P, p + 2P, ... of X[r][c]  (X 16-bit [rows][C], out fp32 [P][C]); a second launch with
-// P = 1 over the fp32 partials finishes the column sum.  Bias gradients (db = column sums of dY) and the gamma / beta partials.
+// out[p][c] = sum of the rows [p rpp, min(rows, (p + 1) rpp)) of X[rows][C], rpp = ceil(rows / P)  (X 16-bit or fp32, out fp32
+// [P][C]): bias gradients (db = column sums of dY), per-frame sums (P = frames x k, then a second launch over the k partials
+// of each frame) and the gamma / beta partials.  A workgroup sums a [rows of one part] x [32 sixteen-byte column chunks]
+// panel: 8 row lanes x 32 chunk lanes, four independent 16-byte loads in flight per thread, the 8 row lanes combined through
+// LDS in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t rows, int C, int P, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int pidx = blockIdx.y;
-    if (c >= C) return;
-    float acc = 0.f;
-    for (int64_t r = pidx; r < rows; r += P) {
-        if constexpr (sizeof(T) == 2) acc += bf2f(((const uint16_t*)X)[r * C + c]);
-        else acc += ((const float*)X)[r * C + c];
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t rows, int C, int64_t rpp, float* __restrict__ out) {
+    constexpr int CW = 16 / (int)sizeof(T);
+    __shared__ float red[8][32 * CW + 4];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cx) * CW;
+    const int64_t r0 = (int64_t)blockIdx.y * rpp;
+    const int64_t r1 = r0 + rpp < rows ? r0 + rpp : rows;
+    float acc[4][CW];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) acc[u][e] = 0.f;
+    if (col < C) {
+        const T* src = X + col;
+        int64_t r = r0 + ry;
+        for (; r + 24 < r1; r += 32) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(src + (r + 8 * u) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                if constexpr (sizeof(T) == 2) unpack8(v[u], f);
+                else { f[0] = __uint_as_float(v[u].x); f[1] = __uint_as_float(v[u].y); f[2] = __uint_as_float(v[u].z); f[3] = __uint_as_float(v[u].w); }
+#pragma unroll
+                for (int e = 0; e < CW; ++e) acc[u][e] += f[e];
+            }
+        }
+        for (; r < r1; r += 8) {
+            const uint4 v = *(const uint4*)(src + r * C);
+            float f[8];
+            if constexpr (sizeof(T) == 2) unpack8(v, f);
+            else { f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w); }
+#pragma unroll
+            for (int e = 0; e < CW; ++e) acc[0][e] += f[e];
+        }
     }
-    out[(int64_t)pidx * C + c] = acc;
+#pragma unroll
+    for (int e = 0; e < CW; ++e) red[ry][cx * CW + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * CW; t += 256) {
+        const int c = blockIdx.x * 32 * CW + t;
+        if (c < C) {
+            float sum = 0.f;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) sum += red[y][t];
+            out[(int64_t)blockIdx.y * C + c] = sum;
+        }
+    }
 }
 
 // LayerNorm backward, one wave per row (C <= 2048, C % 8 == 0), statistics recomputed from x (two-pass, fp32):
@@ -1081,9 +1123,12 @@ extern "C" int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, co
 
 extern "C" int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out) {
     WIW_REQUIRE(X && out && rows > 0 && C > 0 && parts > 0 && parts <= 65535, "colsum: bad arguments");
-    const dim3 grid((unsigned)((C + 255) / 256), (unsigned)parts);
-    if (is_f32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, rows, C, parts, out);
-    else hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, parts, out);
+    WIW_REQUIRE(C % (is_f32 ? 4 : 8) == 0 && (((uintptr_t)X) & 15) == 0, "colsum: C must be a multiple of 8 (fp32: 4), X 16-byte aligned");
+    const int64_t rpp = (rows + parts - 1) / parts;
+    const int cw = is_f32 ? 4 : 8;
+    const dim3 grid((unsigned)((C + 32 * cw - 1) / (32 * cw)), (unsigned)parts);
+    if (is_f32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, rows, C, rpp, out);
+    else hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, rpp, out);
     return wiw_check_launch("wiw_colsum");
 }
 

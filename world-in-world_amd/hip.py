@@ -389,17 +389,28 @@ class Hip:
         return partial.sum() / n, grad
 
     # ---- backward building blocks (row f2; csrc/train.hip)
-    def colsum(self, X, rows, Cn, parts=None):
-        """fp32 [Cn] column sums of X [rows, Cn] (16-bit or fp32): two fixed-order launches (partials, then their sum).
-        parts (default: ~128 rows per partial, at most 512): the row classes summed in parallel by the first launch."""
-        parts = max(1, min(512, rows // 128)) if parts is None else max(1, min(parts, rows))
-        part = torch.empty(parts, Cn, dtype=torch.float32, device=self.device)
-        self._ck(self.lib.wiw_colsum(self._stream(), _p(X), int(X.dtype == torch.float32), rows, Cn, parts, _p(part)), "wiw_colsum")
-        if parts == 1:
-            return part[0]
-        out = torch.empty(1, Cn, dtype=torch.float32, device=self.device)
-        self._ck(self.lib.wiw_colsum(self._stream(), _p(part), 1, parts, Cn, 1, _p(out)), "wiw_colsum")
-        return out[0]
+    def colsum(self, X, rows, Cn, parts=None, units=1):
+        """fp32 column sums of X [rows, Cn] (16-bit or fp32), fixed summation order.  units == 1: -> [Cn].  units > 1: X is
+        `units` consecutive blocks of rows / units rows (the frames of a clip) and the result is [units, Cn], from the SAME two
+        launches.  Launch 1 sums `units * k` contiguous row ranges (k: `parts`, default enough ranges to fill the chip), launch
+        2 the k partials of every unit."""
+        assert rows % units == 0
+        ur = rows // units
+        cw = 4 if X.dtype == torch.float32 else 8
+        limit = max(1, 2048 // (units * (-(-Cn // (32 * cw)))))
+        if parts is not None:
+            limit = max(1, min(parts, ur))
+        if units == 1:
+            k = max(1, min(limit, ur // 64 if parts is None else limit))
+        else:                                   # the ranges must not straddle units: k divides the rows of a unit
+            k = next(d for d in range(min(limit, max(1, ur // 16)), 0, -1) if ur % d == 0)
+        part = torch.empty(units * k, Cn, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_colsum(self._stream(), _p(X), int(X.dtype == torch.float32), rows, Cn, units * k, _p(part)), "wiw_colsum")
+        if k > 1:
+            out = torch.empty(units, Cn, dtype=torch.float32, device=self.device)
+            self._ck(self.lib.wiw_colsum(self._stream(), _p(part), 1, units * k, Cn, units, _p(out)), "wiw_colsum")
+            part = out
+        return part[0] if units == 1 else part
 
     def layernorm_bwd(self, X, dY, gamma, rows, Cn, eps=1e-5, dres=None):
         """-> (dX 16-bit [rows, Cn], dgamma fp32 [Cn], dbeta fp32 [Cn]); dres: gradient of a residual path, added to dX."""
@@ -408,7 +419,7 @@ class Hip:
         dX = torch.empty(rows, Cn, dtype=self.dtype, device=self.device)
         self._ck(self.lib.wiw_layernorm_bwd(self._stream(), _p(X), _p(dY), _p(gamma), rows, Cn, eps, _p(dres), _p(dX), _p(part)),
                  "wiw_layernorm_bwd")
-        s = self.colsum(part, nw, 2 * Cn, parts=1)
+        s = self.colsum(part, nw, 2 * Cn)
         return dX, s[:Cn], s[Cn:]
 
     def groupnorm_bwd(self, X, dY, gamma, beta, rows, Cn, rows_per_unit, eps, silu, stats=None):

@@ -119,8 +119,7 @@ class UNetTrain:
     # operators (forward + tape entry)
     # ------------------------------------------------------------------------------------------
     def _unit_colsum(self, dy: torch.Tensor, units: int, rows_per_unit: int) -> torch.Tensor:
-        C = dy.shape[1]
-        return torch.stack([self.hip.colsum(dy[u * rows_per_unit:(u + 1) * rows_per_unit], rows_per_unit, C) for u in range(units)])
+        return self.hip.colsum(dy, units * rows_per_unit, dy.shape[1], units=units).reshape(units, dy.shape[1])
 
     def linear(self, x, name, M, bias=True, res=None, rowvec=None, rows_per_vec=1, out_f32=False, wkey=None, split=None):
         """y = x . W^T (+ b) (+ rowvec[row // rows_per_vec]) (+ res).  x [>= M rows, K] 16-bit (extra rows are padding)."""
