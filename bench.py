@@ -114,8 +114,9 @@ def main():
                     help="BASELINE config 4 instead of the inference loop: one fine-tuning step per 'step' (un-fused training "
                          "forward, EDM loss, backward through every operator, AdamW), one sample per GPU, data parallel over "
                          "the ranks (ShardedAdamW: gradient reduce-scatter + parameter all-gather).  Functional, untuned.")
-    ap.add_argument("--train-height", type=int, default=256)
-    ap.add_argument("--train-width", type=int, default=512)
+    ap.add_argument("--train-height", type=int, default=576, help="train_svd.sh:22-23 trains at 576x1024 (the dataset comments "
+                    "of train_svd.py:846-855 show 256x512 clips: pass 256 / 512 for those)")
+    ap.add_argument("--train-width", type=int, default=1024)
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time whole requests (uint8 panorama in -> uint8 frames out: CLIP + VAE encode, denoise, VAE "
                          "decode, PIL post-processing) through server.worker.SVDWorker; reported as 'end_to_end'")
@@ -331,8 +332,9 @@ def main():
 
 
 def train_bench(args, rank, world, device):
-    """BASELINE config 4: FTsvd/train_svd.py step (one sample per GPU; the reference's clips are 256x512, train_svd.py:849-859)
-    on the served architecture with random-init weights and a synthetic latent batch.  metric = training samples / s."""
+    """BASELINE config 4: FTsvd/train_svd.py step (one sample per GPU and micro-batch, train_svd.sh:26; 576x1024x14 as
+    train_svd.sh:22-24) on the served architecture with random-init weights and a synthetic latent batch.
+    metric = training samples / s (one micro-batch per step, the optimiser on every one)."""
     import torch.distributed as dist
 
     from wiw_amd import train as T
@@ -385,7 +387,8 @@ def train_bench(args, rank, world, device):
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SVD UNet fine-tuning step {args.train_height}x{args.train_width}x{Tn}, one sample per GPU, "
-                                   "random-init weights; functional first form (un-fused forward, untuned backward kernels)" +
+                                   "random-init weights; un-fused training forward, GEMM-shaped gradients on the inference GEMM "
+                                   "kernel, LDS-tiled attention backward" +
                                    (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if world > 1 else "single GPU"},
             "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}),

@@ -1,5 +1,7 @@
 """First kernels of row f2 (the fine-tuning step): AdamW and the EDM loss + gradient, against torch / the reference-pinned
 fixture `tests/golden/train_step_tiny.npz`.  The operators' backward kernels do not exist yet."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -423,6 +425,16 @@ def test_trainer_steps_reduce_the_loss_and_follow_adamw(golden):
     moved = [k for k in sd if not torch.equal(net2.master[k].cpu(), torch.from_numpy(np.asarray(sd[k])))]
     assert moved and all(("action" in k) or ("noise" in k) for k in moved), moved[:5]
     assert "add_action_proj.proj.weight" in moved and "add_embedding_noise.linear_1.weight" in moved
+    # ... by the same update as in a full run, and the frozen layers' weight-gradient GEMMs were not even launched
+    net3 = UNetTrain(cfg, sd, DEV, hip=hip)
+    Trainer(net3, lr=lr).step(st)
+    assert all(torch.equal(net2.master[k], net3.master[k]) for k in moved)
+    assert "conv_in.weight" in net3.grads and "conv_in.weight" not in net2.grads
+    assert "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight" not in net2.grads
+    net4 = UNetTrain(cfg, sd, DEV, hip=hip)
+    Trainer(net4, lr=lr, train_param_type="new+temp_layer").step(st)
+    moved4 = [k for k in sd if not torch.equal(net4.master[k].cpu(), torch.from_numpy(np.asarray(sd[k])))]
+    assert any("temporal_transformer_block" in k for k in moved4) and all(torch.equal(net4.master[k], net3.master[k]) for k in moved4)
 
 
 @pytest.mark.gpu
@@ -456,6 +468,69 @@ def test_full_width_training_step_runs(golden):
     assert not bad, bad[:5]
     print(f"[f2] full-width step at 32x64x14: loss {float(loss):.4f}, {len(grads)} gradients, peak memory "
           f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
+@pytest.mark.gpu
+def test_resume_from_checkpoint_continues_bit_for_bit(golden, tmp_path):
+    """save after step 1 -> a NEW Trainer on the initial weights resumes from "latest" -> step 2 == the uninterrupted second
+    step, bit for bit (parameters and both AdamW moments); the saved `unet/` file serves through the inference loader."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd import checkpoint as C
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import load_safetensors, random_state_dict, validate_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    hip = Hip(torch.device(DEV))
+    sd = random_state_dict(cfg, int(g["weight_seed"]))
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]))
+    a = Trainer(UNetTrain(cfg, sd, DEV, hip=hip), lr=1e-3)
+    a.step(st)
+    path = a.save(str(tmp_path), total_limit=1)
+    a.step(st)
+    b = Trainer(UNetTrain(cfg, sd, DEV, hip=hip), lr=1e-3)
+    b.load(C.resolve_resume(str(tmp_path), "latest"))
+    assert b.steps == 1
+    b.step(st)
+    for k in sd:
+        assert torch.equal(a.net.master[k], b.net.master[k]) and torch.equal(a.m[k], b.m[k]) and torch.equal(a.v[k], b.v[k]), k
+    served = load_safetensors(os.path.join(path, C.UNET_FILE))
+    validate_state_dict(cfg, served)
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_is_the_mean_gradient(golden):
+    """`--gradient_accumulation_steps` (train_svd.sh:20): two micro-batches of the SAME sample with grad_accum=2 give g/2 + g/2
+    = g exactly, so the parameters equal those of one plain step bit for bit; no update happens on the first micro-batch."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    hip = Hip(torch.device(DEV))
+    sd = random_state_dict(cfg, int(g["weight_seed"]))
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]))
+    one = UNetTrain(cfg, sd, DEV, hip=hip)
+    Trainer(one, lr=1e-3).step(st)
+    two = UNetTrain(cfg, sd, DEV, hip=hip)
+    tr = Trainer(two, lr=1e-3, grad_accum=2)
+    tr.step(st)
+    key = "conv_in.weight"
+    assert torch.equal(two.master[key].cpu(), torch.from_numpy(np.asarray(sd[key]))) and tr.steps == 0
+    tr.step(st)
+    assert tr.steps == 1
+    assert max(float((two.master[k] - one.master[k]).abs().max()) for k in sd) == 0.0
 
 
 @pytest.mark.gpu

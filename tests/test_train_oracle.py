@@ -100,3 +100,24 @@ def test_adamw_matches_torch_optim(golden):
         p, m, v = TO.adamw_step(before, grad, torch.zeros_like(before), torch.zeros_like(before), 1, float(g["adamw_lr"]))
         assert float((p - after).abs().max()) <= 1e-6 * float(after.abs().max()) + 1e-9, name
         assert torch.equal(before, sd[name])
+
+
+def test_lr_schedules_match_the_published_lambda_schedulers():
+    """`train.lr_at` against `transformers.get_scheduler` — the same LambdaLR multipliers `diffusers.optimization.get_scheduler`
+    applies in train_svd.py:1131-1136 (diffusers is not in this image; its schedule functions are the transformers ones)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import wiw_amd  # noqa: F401
+    from transformers import get_scheduler
+    from wiw_amd.train import lr_at
+
+    for name in ("constant", "constant_with_warmup", "linear", "cosine"):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=2e-5)
+        sch = get_scheduler(name, optimizer=opt, num_warmup_steps=50, num_training_steps=120)
+        for step in range(125):
+            assert abs(opt.param_groups[0]["lr"] - lr_at(step, 2e-5, name, 50, 120)) <= 1e-12, (name, step)
+            opt.step()
+            sch.step()

@@ -65,6 +65,32 @@ def prepare_step(latents: torch.Tensor, noise: torch.Tensor, sigma: float, cond_
 # ------------------------------------------------------------------------------------------------
 # backward building blocks on the existing kernels (no new GEMM code: the gradients of a GEMM are GEMMs on transposed operands)
 # ------------------------------------------------------------------------------------------------
+def lr_at(step: int, base_lr: float, schedule: str = "cosine", warmup_steps: int = 500, total_steps: int = 1002) -> float:
+    """Learning rate of optimiser step `step` (0-based) under the reference's `get_scheduler(args.lr_scheduler, ...)`
+    (train_svd.py:1131-1136; `diffusers.optimization`, a LambdaLR on the base rate; train_svd.sh runs "cosine", warm-up 500
+    (:237-240), 1002 steps).  The published multipliers:
+        constant               1
+        constant_with_warmup   min(1, step / warmup)
+        linear                 step / warmup during warm-up, then max(0, (total - step) / (total - warmup))
+        cosine                 step / warmup during warm-up, then max(0, 0.5 (1 + cos(pi * progress))), progress =
+                               (step - warmup) / max(1, total - warmup)   (num_cycles = 0.5)"""
+    import math
+
+    w = max(1, warmup_steps)
+    if schedule == "constant":
+        return base_lr
+    if step < warmup_steps:
+        return base_lr * step / w
+    if schedule == "constant_with_warmup":
+        return base_lr
+    if schedule == "linear":
+        return base_lr * max(0.0, (total_steps - step) / max(1, total_steps - warmup_steps))
+    if schedule == "cosine":
+        progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+        return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * progress)))
+    raise ValueError(f"unknown lr schedule {schedule!r}")
+
+
 def wgrad_splitk(n_rows_out: int, n_cols_out: int, k_rows: int) -> int:
     """Split-K factor of a weight-gradient GEMM dW [n_rows_out, n_cols_out] = A^T B whose K loop runs over k_rows (the M rows
     of the layer: up to 129 024) while the output has a handful of tiles (dW of a 320 x 320 projection: 2 x 2 tiles of 256 x 160
@@ -79,7 +105,8 @@ def wgrad_splitk(n_rows_out: int, n_cols_out: int, k_rows: int) -> int:
     return best
 
 
-def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True):
+def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True,
+                    need_dw: bool = True):
     """Backward of y = x . W^T (+ b) with x [M, K], W [N, K], dy [M, N] in the Hip's 16-bit type (M, N, K % 64 == 0):
          dx [M, K] (16-bit)  = dy . W              -> wiw_gemm_bf16(A = dy, W = W^T)
          dW [N, K] (fp32)    = dy^T . x            -> wiw_gemm_bf16(A = dy^T, W = x^T, fp32 output): K loop over the M rows
@@ -99,19 +126,21 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
         hip.transpose(W, K, 0, N, K, Wt, N)
         dx = torch.empty(M, K, dtype=dt, device=dev)
         hip.gemm(dy, Wt, dx, M=M, N=K, K=N, C1=N)
-    alloc = torch.empty if Mp == M else torch.zeros
-    dyT = alloc(N, Mp, dtype=dt, device=dev)
-    hip.transpose(dy, N, 0, M, N, dyT, Mp)
-    xT = alloc(K, Mp, dtype=dt, device=dev)
-    hip.transpose(x, K, 0, M, K, xT, Mp)
-    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(N, K, Mp))
+    dW = None
+    if need_dw:                        # frozen weights (`--train_param_type new`): no transposes, no weight-gradient GEMM
+        alloc = torch.empty if Mp == M else torch.zeros
+        dyT = alloc(N, Mp, dtype=dt, device=dev)
+        hip.transpose(dy, N, 0, M, N, dyT, Mp)
+        xT = alloc(K, Mp, dtype=dt, device=dev)
+        hip.transpose(x, K, 0, M, K, xT, Mp)
+        dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+        hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(N, K, Mp))
     db = hip.colsum(dy, M, N) if need_db else None
     return dx, dW, db
 
 
 def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor, H: int, Wd: int, T: int = 1,
-                  temporal: bool = False, need_dx: bool = True):
+                  temporal: bool = False, need_dx: bool = True, need_dw: bool = True):
     """Backward of the stride-1 implicit-GEMM convolutions of `wiw_gemm_bf16`: 3x3 pad 1 (ResnetBlock2D convs, resnet.py:269,285)
     or, temporal=True, (3,1,1) pad 1 over T (TemporalResnetBlock, resnet.py:570-592).  x [M, Cin] token-major, Wk [Cout, taps*Cin]
     in the kernel's layout ([Cout][ky][kx][Cin] / [Cout][kt][Cin]), dy [M, Cout]; Cin, Cout, M % 64 == 0.
@@ -133,6 +162,8 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
         W2 = Wk.reshape(Cout, taps, Cin).flip(1).permute(2, 1, 0).reshape(Cin, taps * Cout).contiguous()   # host re-layout
         dx = torch.empty(M, Cin, dtype=dt, device=dev)
         hip.gemm(dy, W2, dx, M=M, N=Cin, K=taps * Cout, C1=Cout, mode=A_CONV_T3 if temporal else A_CONV3X3, H=H, Wd=Wd, T=T)
+    if not need_dw:
+        return dx, None, None
     xcol = hip.gather_taps(x, M, Cin, H, Wd, T, temporal)
     xcolT = alloc(taps * Cin, Mp, dtype=dt, device=dev)
     hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, Mp)

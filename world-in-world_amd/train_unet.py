@@ -86,6 +86,7 @@ class UNetTrain:
         self.hip = hip or Hip(self.device, dtype)
         self.dt = self.hip.dtype
         self.master = {k: torch.as_tensor(v).to(self.device, torch.float32) for k, v in state_dict.items()}
+        self.wants = lambda name: True                 # which parameters need a gradient (Trainer: `--train_param_type`)
         self.refresh()
 
     # ------------------------------------------------------------------------------------------
@@ -144,14 +145,16 @@ class UNetTrain:
             if rowvec is not None:
                 tape.add(rowvec, self._unit_colsum(dy, rowvec.shape[0], rows_per_vec))
             xp, dyp = _pad_rows(x[:M]), _pad_rows(dy[:M])
-            dx, dW, db = linear_backward(hip, xp, W, dyp, need_db=bias)
+            need_dw = any(self.wants(nm) for nm in (split or [name + ".weight"]))
+            need_db = bias and self.wants(name + ".bias")
+            dx, dW, db = linear_backward(hip, xp, W, dyp, need_db=need_db, need_dw=need_dw)
             tape.add(x, dx[:M] if x.shape[0] == M else _pad_like(dx[:M], x))
-            if split is None:
+            if need_dw and split is None:
                 self.grads[name + ".weight"] = dW[:, : self.master[name + ".weight"].shape[1]].contiguous()
-            else:                                                        # fused q | k | v: three reference tensors
+            elif need_dw:                                                # fused q | k | v: three reference tensors
                 for i, nm in enumerate(split):
                     self.grads[nm] = dW[i * (N // 3):(i + 1) * (N // 3)].contiguous()
-            if bias:
+            if need_db:
                 self.grads[name + ".bias"] = db
         tape.ops.append(bwd)
         return y
@@ -182,27 +185,31 @@ class UNetTrain:
             if Cout % 64:                                                 # conv_out: 4 output channels -> 64
                 dyp = torch.cat([dy, dy.new_zeros(M_out, 64 - Cout)], dim=1).contiguous()
                 Wp = torch.cat([Wk, Wk.new_zeros(64 - Cout, Wk.shape[1])]).contiguous()
+            need_dw = self.wants(name + ".weight") or self.wants(name + ".bias")
             if mode == A_CONV3X3_S2:
                 # dx on the (2H, 2W) grid = stride-1 conv of the dilated dy with mirrored taps; dW from stride-2 im2col rows
                 dil = hip.row_map(dyp, hip.ROW_DILATE2X, 4 * M_out, dyp.shape[1], H, W)
                 W2 = Wp.reshape(Wp.shape[0], 9, Cin).flip(1).permute(2, 1, 0).reshape(Cin, 9 * Wp.shape[0]).contiguous()
                 dx = torch.empty(4 * M_out, Cin, dtype=self.dt, device=self.device)
                 hip.gemm(dil, W2, dx, M=4 * M_out, N=Cin, K=9 * Wp.shape[0], C1=Wp.shape[0], mode=A_CONV3X3, H=2 * H, Wd=2 * W)
-                xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
-                Mp = -(-M_out // 64) * 64
-                xcolT = torch.zeros(9 * Cin, Mp, dtype=self.dt, device=self.device)
-                hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
-                dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
-                hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
-                dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
-                from .train import wgrad_splitk
-                hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32,
-                         splitk=wgrad_splitk(dyp.shape[1], 9 * Cin, Mp))
-                db = hip.colsum(dy, M_out, Cout)
+                if need_dw:
+                    xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
+                    Mp = -(-M_out // 64) * 64
+                    xcolT = torch.zeros(9 * Cin, Mp, dtype=self.dt, device=self.device)
+                    hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
+                    dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
+                    hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
+                    dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
+                    from .train import wgrad_splitk
+                    hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32,
+                             splitk=wgrad_splitk(dyp.shape[1], 9 * Cin, Mp))
+                    db = hip.colsum(dy, M_out, Cout)
             else:
-                dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3))
-                db = db[:Cout]
+                dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3), need_dw=need_dw)
+                db = db[:Cout] if need_dw else None
             tape.add(x, dx)
+            if not need_dw:                                               # frozen convolution: only dx flows on
+                return
             dW = dW[:Cout]
             if mode == A_CONV_T3:
                 g = dW.reshape(Cout, 3, Cin).permute(0, 2, 1)[:, : ref_w.shape[1]].reshape(ref_w.shape)
@@ -560,14 +567,18 @@ class Trainer:
     (gradients are copied into its flat buffer, reduced-scattered, the owned slices updated, parameters all-gathered)."""
 
     def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full"):
+                 optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full", grad_accum: int = 1):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
+        # `--gradient_accumulation_steps` (train_svd.sh:20 runs 4; accelerate averages the micro-batch losses, train_svd.py:
+        # 864, 961-969): `step` is one micro-batch, the optimiser runs on every grad_accum-th call with the mean gradient
+        self.grad_accum, self._micro, self._acc = int(grad_accum), 0, {}
         # which parameters are updated — the reference's `--train_param_type` (train_svd.py:655-663)
         self.trainable = {"full": lambda n: True,
                           "new": lambda n: ("action" in n) or ("noise" in n),
                           "new+temp_layer": lambda n: ("temporal_transformer_block" in n) or ("action" in n) or ("noise" in n),
                           }[train_param_type]
         # static loss scale for fp16 (halved, and the step skipped, when a gradient comes back non-finite); 1 for bf16
+        net.wants = self.trainable                     # frozen weights: their weight-gradient GEMMs are not launched
         self.loss_scale = (2.0 ** 14 if net.dt == torch.float16 else 1.0) if loss_scale is None else loss_scale
         self.opt = optimizer
         self.steps = 0
@@ -577,8 +588,52 @@ class Trainer:
         if optimizer is not None:
             optimizer.load(net.master)
 
+    def save(self, output_dir: str, total_limit: Optional[int] = None) -> str:
+        """`accelerator.save_state(checkpoint-<global_step>)` (train_svd.py:1032-1062): the fp32 parameters in the reference's
+        `unet/` layout, the AdamW moments (this rank's ZeRO-1 slices when sharded), the counters.  See `checkpoint.py`."""
+        from . import checkpoint as C
+
+        meta = {"micro": self._micro, "loss_scale": self.loss_scale, "grad_accum": self.grad_accum, "lr": self.lr}
+        if self.opt is None:
+            optim = {f"exp_avg.{k}": v for k, v in self.m.items()}
+            optim.update({f"exp_avg_sq.{k}": v for k, v in self.v.items()})
+            return C.save_checkpoint(output_dir, self.steps, self.net.master, optim, dict(meta, world=1), total_limit=total_limit)
+        o = self.opt
+        optim = {"master": o.master, "exp_avg": o.m, "exp_avg_sq": o.v}
+        return C.save_checkpoint(output_dir, self.steps, self.net.master if o.rank == 0 else None, optim,
+                                 dict(meta, world=o.world), rank=o.rank, sharded=True, total_limit=total_limit)
+
+    def load(self, path: str) -> None:
+        """Resume from a directory written by `save` (`checkpoint.resolve_resume` maps "latest" to one)."""
+        from . import checkpoint as C
+
+        sharded = self.opt is not None
+        master, optim, meta = C.load_checkpoint(path, rank=self.opt.rank if sharded else 0, sharded=sharded)
+        assert meta["world"] == (self.opt.world if sharded else 1), "the optimizer state was saved for another world size"
+        assert set(master) == set(self.net.master), "checkpoint parameters do not match this architecture"
+        for k, v in master.items():
+            self.net.master[k].copy_(v)
+        if sharded:
+            self.opt.load(self.net.master)
+            self.opt.master.copy_(optim["master"]); self.opt.m.copy_(optim["exp_avg"]); self.opt.v.copy_(optim["exp_avg_sq"])
+            self.opt.steps = int(meta["global_step"])
+        else:
+            for k in self.m:
+                self.m[k].copy_(optim[f"exp_avg.{k}"]); self.v[k].copy_(optim[f"exp_avg_sq.{k}"])
+        self.steps, self._micro, self.loss_scale = int(meta["global_step"]), int(meta["micro"]), float(meta["loss_scale"])
+        self._acc, self._seen = {}, None
+        self.net.refresh()
+
+    def _mean_grad(self, name: str, g: torch.Tensor) -> torch.Tensor:
+        """This micro-batch's share of the mean gradient plus what the earlier micro-batches of the window left."""
+        if self.grad_accum == 1:
+            return g
+        g = g.reshape(self.net.master[name].shape) * (1.0 / self.grad_accum)
+        acc = self._acc.get(name)
+        return g if acc is None else acc + g
+
     def step(self, st) -> float:
-        """st: `train.StepInputs`.  Returns the loss (host float)."""
+        """st: `train.StepInputs` of one micro-batch.  Returns its loss (host float)."""
         from .train import TrainStep
 
         net, hip = self.net, self.net.hip
@@ -595,15 +650,29 @@ class Trainer:
                 for name in list(net.grads):
                     if name not in sent and self.trainable(name):
                         sent.add(name)
-                        self.opt.notify(name, net.grads[name], expected)
-            net.tape.after_op = hand_over
+                        self.opt.notify(name, self._mean_grad(name, net.grads[name]), expected)
+            if (self._micro + 1) % self.grad_accum == 0:                   # earlier micro-batches accumulate locally (no_sync)
+                net.tape.after_op = hand_over
         overlapped = net.tape.after_op is not None
         grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
         net.tape.after_op = None
         self._seen = {n for n in grads if self.trainable(n)}
         if self.loss_scale != 1.0 and not all(bool(torch.isfinite(g).all()) for g in grads.values()):
             self.loss_scale *= 0.5                                         # overflow: skip the update, as a GradScaler does
+            self._micro, self._acc = 0, {}
             return float(loss)
+        self._micro += 1
+        if self._micro % self.grad_accum != 0:                             # not the last micro-batch: accumulate, no update
+            inv = 1.0 / self.grad_accum
+            for name, g in grads.items():
+                if self.trainable(name):
+                    g = g.reshape(net.master[name].shape) * inv
+                    self._acc[name] = g if name not in self._acc else self._acc[name] + g
+            net.grads = {}
+            return float(loss)
+        if not overlapped and self.grad_accum > 1:
+            grads = {name: self._mean_grad(name, g) for name, g in grads.items() if self.trainable(name)}
+        self._acc = {}
         self.steps += 1
         if self.opt is None:
             for name, g in grads.items():                                  # parameters without a gradient (the dead ones) stay
@@ -617,6 +686,7 @@ class Trainer:
                 for name, g in grads.items():
                     if self.trainable(name):
                         self.opt.view(self.opt.grads, name).copy_(g.reshape(net.master[name].shape))
+            self.opt.lr = self.lr                                       # the caller's schedule (`train.lr_at`) sets Trainer.lr
             self.opt.step()
             for name in grads:                                           # parameters without a gradient / frozen ones are not
                 if self.trainable(name):                                 # read back (torch.optim.AdamW skips them too)
