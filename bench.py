@@ -114,6 +114,8 @@ def main():
                     help="BASELINE config 4 instead of the inference loop: one fine-tuning step per 'step' (un-fused training "
                          "forward, EDM loss, backward through every operator, AdamW), one sample per GPU, data parallel over "
                          "the ranks (ShardedAdamW: gradient reduce-scatter + parameter all-gather).  Functional, untuned.")
+    ap.add_argument("--no-autotune", action="store_true", help="--train: the schedule model's weight-gradient GEMM plans instead "
+                    "of the ones measured during warm-up")
     ap.add_argument("--train-height", type=int, default=576, help="train_svd.sh:22-23 trains at 576x1024 (the dataset comments "
                     "of train_svd.py:846-855 show 256x512 clips: pass 256 / 512 for those)")
     ap.add_argument("--train-width", type=int, default=1024)
@@ -351,7 +353,7 @@ def train_bench(args, rank, world, device):
         opt = ShardedAdamW({k: tuple(v.shape) for k, v in net.master.items()}, device,
                            lambda p, g, m, v, step, lr, b1, b2, eps, wd: net.hip.adamw_step(p, g, m, v, step, lr, b1, b2, eps, wd),
                            lr=1e-5)
-    tr = Trainer(net, lr=1e-5, optimizer=opt)
+    tr = Trainer(net, lr=1e-5, optimizer=opt, autotune=not args.no_autotune)
     h, w, Tn = args.train_height // 8, args.train_width // 8, cfg.num_frames
     gen = torch.Generator().manual_seed(100 + rank)                       # every rank its own sample
     lat, noise = torch.randn(1, Tn, 4, h, w, generator=gen) * 0.8, torch.randn(1, Tn, 4, h, w, generator=gen)
@@ -388,7 +390,8 @@ def train_bench(args, rank, world, device):
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SVD UNet fine-tuning step {args.train_height}x{args.train_width}x{Tn}, one sample per GPU, "
                                    "random-init weights; un-fused training forward, GEMM-shaped gradients on the inference GEMM "
-                                   "kernel, LDS-tiled attention backward" +
+                                   "kernel (orientation / split-K per shape " + ("from the schedule model" if args.no_autotune else
+                                   "measured during warm-up") + "), LDS-tiled attention backward" +
                                    (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if world > 1 else "single GPU"},
             "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}),

@@ -471,6 +471,45 @@ def test_full_width_training_step_runs(golden):
 
 
 @pytest.mark.gpu
+def test_weight_gradient_gemm_plans_model_and_measured():
+    """dW = dy^T x through `train.wgrad_gemm`: the schedule model's plan and the MEASURED plan (every orientation / split-K
+    candidate timed once, the fastest kept) both equal the fp32 product of the same 16-bit operands; a measured plan is
+    cached per shape and survives `wgrad_plans` / `load_wgrad_plans` (what `Trainer.save` / `load` carry)."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    T.clear_wgrad_plans()
+    try:
+        for n_out, k_in, rows in ((320, 640, 4032), (64, 2880, 2304), (1280, 320, 8064)):
+            dyT = _rnd(n_out, rows, seed=n_out).to(torch.bfloat16)
+            xT = _rnd(k_in, rows, seed=k_in + 1).to(torch.bfloat16)
+            ref = dyT.float() @ xT.float().t()
+            T.set_wgrad_tuning(False)
+            got = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            assert tuple(got.shape) == (n_out, k_in) and _rel(got, ref)[0] <= 2e-5
+            assert T.wgrad_plans()[f"{n_out},{k_in},{rows}"] == T.wgrad_plan(n_out, k_in, rows)
+            T.clear_wgrad_plans()
+            T.set_wgrad_tuning(True)
+            got = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            assert _rel(got, ref)[0] <= 2e-5
+            plan = T.wgrad_plans()[f"{n_out},{k_in},{rows}"]
+            again = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            assert torch.equal(got, again)                                # the plan is fixed once chosen: same summation order
+            saved = {k: list(v) for k, v in T.wgrad_plans().items()}
+            T.clear_wgrad_plans(); T.set_wgrad_tuning(False)
+            T.load_wgrad_plans(saved)
+            assert T.wgrad_plans()[f"{n_out},{k_in},{rows}"] == plan
+            assert torch.equal(got, T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows))
+            print(f"[f2] wgrad {n_out}x{k_in} over {rows} rows: model plan {T.wgrad_plan(n_out, k_in, rows)}, measured {plan}")
+            T.clear_wgrad_plans()
+    finally:
+        T.set_wgrad_tuning(False)
+        T.clear_wgrad_plans()
+
+
+@pytest.mark.gpu
 def test_resume_from_checkpoint_continues_bit_for_bit(golden, tmp_path):
     """save after step 1 -> a NEW Trainer on the initial weights resumes from "latest" -> step 2 == the uninterrupted second
     step, bit for bit (parameters and both AdamW moments); the saved `unet/` file serves through the inference loader."""

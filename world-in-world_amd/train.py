@@ -91,18 +91,106 @@ def lr_at(step: int, base_lr: float, schedule: str = "cosine", warmup_steps: int
     raise ValueError(f"unknown lr schedule {schedule!r}")
 
 
-def wgrad_splitk(n_rows_out: int, n_cols_out: int, k_rows: int) -> int:
-    """Split-K factor of a weight-gradient GEMM dW [n_rows_out, n_cols_out] = A^T B whose K loop runs over k_rows (the M rows
-    of the layer: up to 129 024) while the output has a handful of tiles (dW of a 320 x 320 projection: 2 x 2 tiles of 256 x 160
-    for 256 CUs).  The K loop is cut into S ranges (WiwGemmArgs.splitk: fp32 slabs + a deterministic reduce): the largest
-    divisor of the K-tile count that keeps >= 8 K tiles per range and the item count around two per CU."""
+def wgrad_plan(n_out: int, k_in: int, k_rows: int, n_cu: int = 256):
+    """(flip, splitk) of a weight-gradient GEMM dW [n_out, k_in] = dy^T x whose K loop runs over k_rows (the M rows of the
+    layer: up to 129 024) while the output is a handful of tiles (dW of a 320 x 320 projection: 2 x 2 tiles of 256 x 160 for
+    256 CUs).  Two choices, priced by a small model of `wiw_gemm_bf16`'s persistent schedule (one block per CU):
+      * orientation: dW (GEMM rows = n_out) or dW^T (flip: GEMM rows = k_in) — rows come in 256-row tiles, so the 320 outputs
+        of a level-0 projection waste 37 % of two row tiles while its 1280 / 2880 inputs fill theirs;
+      * split-K factor S (WiwGemmArgs.splitk: fp32 slabs + a deterministic reduce), a divisor of the K-tile count with >= 8
+        K tiles per range: the items (tiles x S) run in ceil(items / CUs) rounds, so 256 items beat 288; the launch takes
+        the 256 x 320 tile under the same rule as gemm.hip (`launch`), which halves the item count.
+    cost [K-tile units of the 256 x 160 tile] = rounds x (K tiles per range x tile area / efficiency + fixed per item)
+    + slab reduce.  Calibrated on the served shapes (`tools/train_probe.py`, gpurun_out r03q: the plan is within a few
+    percent of the best of an exhaustive sweep; the previous fixed rule was 1.0-1.9x off)."""
     nk = k_rows // 64
-    tiles = -(-n_rows_out // 256) * -(-n_cols_out // 160)
-    best = 1
-    for s in range(2, 129):
-        if nk % s == 0 and nk // s >= 8 and tiles * s <= 640:
-            best = s
-    return best
+    best = None
+    for flip in (0, 1):
+        gm, gn = (k_in, n_out) if flip else (n_out, k_in)
+        mt = -(-gm // 256)
+        for sk in range(1, 129):
+            if nk % sk or (sk > 1 and nk // sk < 8):
+                continue
+            kt = nk // sk
+            items_h = mt * -(-gn // 320) * sk
+            huge = gn % 320 == 0 and kt * 64 >= 640 and (items_h >= 200 or sk == 1)
+            items = items_h if huge else mt * -(-gn // 160) * sk
+            rounds = -(-items // n_cu)
+            per_item = kt * 1.8 + 16.0 if huge else kt + 10.0
+            cost = rounds * per_item + (sk * gm * gn / 1.2e6 if sk > 1 else 0.0)
+            if best is None or cost < best[0] - 1e-9:
+                best = (cost, flip, sk)
+    return best[1], best[2]
+
+
+# Measured plans (key "n_out,k_in,k_rows" -> [flip, splitk]).  The weight-gradient GEMMs stream BOTH operands over a K loop of
+# up to 129 024 rows, so their speed is decided by how the concurrently running items share operand panels in the per-XCD L2s
+# — which the schedule model of `wgrad_plan` does not see (it is 1.0-1.7x off on the convolutions).  With tuning on
+# (`set_wgrad_tuning(True)`, `Trainer(autotune=True)`, `bench.py --train`), the first call of a shape times every candidate
+# with HIP events and keeps the fastest — what MIOpen's find step does for its convolutions.  A plan never changes inside a
+# process once chosen, and `Trainer.save` / `load` carry the table, so a resumed run repeats the same summation orders.
+_WGRAD_PLANS: dict = {}
+_WGRAD_TUNE = False
+
+
+def set_wgrad_tuning(on: bool) -> None:
+    global _WGRAD_TUNE
+    _WGRAD_TUNE = bool(on)
+
+
+def clear_wgrad_plans() -> None:
+    _WGRAD_PLANS.clear()
+
+
+def wgrad_plans() -> dict:
+    return dict(_WGRAD_PLANS)
+
+
+def load_wgrad_plans(plans: dict) -> None:
+    _WGRAD_PLANS.update({k: (int(v[0]), int(v[1])) for k, v in plans.items()})
+
+
+def _wgrad_run(hip: Hip, dyT, xT, n_out, k_in, k_rows, flip, sk):
+    from .hip import EPI_OUT_F32
+
+    if flip:
+        out = torch.empty(k_in, n_out, dtype=torch.float32, device=hip.device)
+        hip.gemm(xT, dyT, out, M=k_in, N=n_out, K=k_rows, C1=k_rows, epilogue=EPI_OUT_F32, splitk=sk)
+        return out.t()
+    out = torch.empty(n_out, k_in, dtype=torch.float32, device=hip.device)
+    hip.gemm(dyT, xT, out, M=n_out, N=k_in, K=k_rows, C1=k_rows, epilogue=EPI_OUT_F32, splitk=sk)
+    return out
+
+
+def _wgrad_tune(hip: Hip, dyT, xT, n_out, k_in, k_rows):
+    nk = k_rows // 64
+    cands = [(f, sk) for f in (0, 1) for sk in range(1, 129)
+             if nk % sk == 0 and (sk == 1 or nk // sk >= 8) and sk * n_out * k_in * 4 <= (1 << 30)]
+    model = wgrad_plan(n_out, k_in, k_rows)
+    best = None
+    for f, sk in cands:
+        _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk)                  # warm (workspace allocation, code load)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(2):
+            _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk)
+        b.record()
+        b.synchronize()
+        t = a.elapsed_time(b)
+        if best is None or t < best[0] * (0.97 if (f, sk) != model else 1.0):  # ties go to the model's deterministic choice
+            best = (t, f, sk)
+    return best[1], best[2]
+
+
+def wgrad_gemm(hip: Hip, dyT: torch.Tensor, xT: torch.Tensor, n_out: int, k_in: int, k_rows: int) -> torch.Tensor:
+    """fp32 dW [n_out, k_in] = dyT [n_out, k_rows] . xT [k_in, k_rows]^T in the orientation / split of the shape's plan (a
+    transposed VIEW when the GEMM produced dW^T)."""
+    key = f"{n_out},{k_in},{k_rows}"
+    plan = _WGRAD_PLANS.get(key)
+    if plan is None:
+        plan = _wgrad_tune(hip, dyT, xT, n_out, k_in, k_rows) if _WGRAD_TUNE else wgrad_plan(n_out, k_in, k_rows)
+        _WGRAD_PLANS[key] = plan
+    return _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, plan[0], plan[1])
 
 
 def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True,
@@ -133,8 +221,7 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
         hip.transpose(dy, N, 0, M, N, dyT, Mp)
         xT = alloc(K, Mp, dtype=dt, device=dev)
         hip.transpose(x, K, 0, M, K, xT, Mp)
-        dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-        hip.gemm(dyT, xT, dW, M=N, N=K, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(N, K, Mp))
+        dW = wgrad_gemm(hip, dyT, xT, N, K, Mp)
     db = hip.colsum(dy, M, N) if need_db else None
     return dx, dW, db
 
@@ -169,8 +256,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, Mp)
     dyT = alloc(Cout, Mp, dtype=dt, device=dev)
     hip.transpose(dy, Cout, 0, M, Cout, dyT, Mp)
-    dW = torch.empty(Cout, taps * Cin, dtype=torch.float32, device=dev)
-    hip.gemm(dyT, xcolT, dW, M=Cout, N=taps * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32, splitk=wgrad_splitk(Cout, taps * Cin, Mp))
+    dW = wgrad_gemm(hip, dyT, xcolT, Cout, taps * Cin, Mp)
     return dx, dW, hip.colsum(dy, M, Cout)
 
 

@@ -199,10 +199,8 @@ class UNetTrain:
                     hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
                     dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
                     hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
-                    dW = torch.empty(dyp.shape[1], 9 * Cin, dtype=torch.float32, device=self.device)
-                    from .train import wgrad_splitk
-                    hip.gemm(dyT, xcolT, dW, M=dyp.shape[1], N=9 * Cin, K=Mp, C1=Mp, epilogue=EPI_OUT_F32,
-                             splitk=wgrad_splitk(dyp.shape[1], 9 * Cin, Mp))
+                    from .train import wgrad_gemm
+                    dW = wgrad_gemm(hip, dyT, xcolT, dyp.shape[1], 9 * Cin, Mp)
                     db = hip.colsum(dy, M_out, Cout)
             else:
                 dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3), need_dw=need_dw)
@@ -567,11 +565,15 @@ class Trainer:
     (gradients are copied into its flat buffer, reduced-scattered, the owned slices updated, parameters all-gathered)."""
 
     def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full", grad_accum: int = 1):
+                 optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full", grad_accum: int = 1,
+                 autotune: bool = False):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
         # `--gradient_accumulation_steps` (train_svd.sh:20 runs 4; accelerate averages the micro-batch losses, train_svd.py:
         # 864, 961-969): `step` is one micro-batch, the optimiser runs on every grad_accum-th call with the mean gradient
         self.grad_accum, self._micro, self._acc = int(grad_accum), 0, {}
+        if autotune:                                   # measured plans for the weight-gradient GEMMs (train.wgrad_gemm)
+            from .train import set_wgrad_tuning
+            set_wgrad_tuning(True)
         # which parameters are updated — the reference's `--train_param_type` (train_svd.py:655-663)
         self.trainable = {"full": lambda n: True,
                           "new": lambda n: ("action" in n) or ("noise" in n),
@@ -593,7 +595,10 @@ class Trainer:
         `unet/` layout, the AdamW moments (this rank's ZeRO-1 slices when sharded), the counters.  See `checkpoint.py`."""
         from . import checkpoint as C
 
-        meta = {"micro": self._micro, "loss_scale": self.loss_scale, "grad_accum": self.grad_accum, "lr": self.lr}
+        from .train import wgrad_plans
+
+        meta = {"micro": self._micro, "loss_scale": self.loss_scale, "grad_accum": self.grad_accum, "lr": self.lr,
+                "wgrad_plans": {k: list(v) for k, v in wgrad_plans().items()}}
         if self.opt is None:
             optim = {f"exp_avg.{k}": v for k, v in self.m.items()}
             optim.update({f"exp_avg_sq.{k}": v for k, v in self.v.items()})
@@ -620,6 +625,9 @@ class Trainer:
         else:
             for k in self.m:
                 self.m[k].copy_(optim[f"exp_avg.{k}"]); self.v[k].copy_(optim[f"exp_avg_sq.{k}"])
+        from .train import load_wgrad_plans
+
+        load_wgrad_plans(meta.get("wgrad_plans", {}))          # the resumed run keeps the saved run's summation orders
         self.steps, self._micro, self.loss_scale = int(meta["global_step"]), int(meta["micro"]), float(meta["loss_scale"])
         self._acc, self._seen = {}, None
         self.net.refresh()
