@@ -181,7 +181,8 @@ def test_geglu_backward_and_colsum():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,C,h,w,unit_frames,silu", [(4, 320, 6, 8, 1, True), (4, 64, 4, 8, 2, True), (2, 1280, 3, 4, 1, False)])
+@pytest.mark.parametrize("n,C,h,w,unit_frames,silu", [(4, 320, 6, 8, 1, True), (4, 64, 4, 8, 2, True), (2, 1280, 3, 4, 1, False),
+                                                        (2, 320, 36, 64, 1, True), (1, 2560, 9, 16, 1, True), (3, 640, 5, 9, 3, False)])
 def test_groupnorm_backward(n, C, h, w, unit_frames, silu):
     import torch.nn.functional as F
 

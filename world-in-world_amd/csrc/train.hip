@@ -263,6 +263,22 @@ WIW_DEV float gnb_dz(float dy, float z, int silu) {
     return dy * sg * (1.0f + z * (1.0f - sg));
 }
 
+// Per-thread constants of one 8-channel chunk of one unit: everything the row loops need, loaded once.
+struct GnbChunk {
+    float mean[8], rstd[8], gm[8], bt[8];
+};
+WIW_DEV void gnb_load_chunk(GnbChunk& k, const float* __restrict__ stats, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, int unit, int c0, int cg, float eps) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / cg;
+        k.mean[e] = stats[((int64_t)unit * GNB_GROUPS + g) * 2];
+        k.rstd[e] = rsqrtf(stats[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] + eps);
+        k.gm[e] = gamma[c0 + e]; k.bt[e] = beta[c0 + e];
+    }
+}
+
+// Blocks (row split, unit); threads = (8-channel chunk, row lane); two rows in flight per thread.
 __global__ __launch_bounds__(256) void gnb_reduce_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C, int rows_per_unit,
@@ -283,23 +299,22 @@ __global__ __launch_bounds__(256) void gnb_reduce_kernel(const uint16_t* __restr
         for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
         if (rl < rp && chunk < chunks) {
             const int c0 = chunk * 8;
-            float mean[8], rstd[8], gm[8], bt[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int g = (c0 + e) / cg;
-                mean[e] = stats[((int64_t)unit * GNB_GROUPS + g) * 2];
-                rstd[e] = rsqrtf(stats[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] + eps);
-                gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e];
-            }
-            for (int r = r0 + rl; r < r1; r += rp) {
-                float x[8], dy[8];
-                unpack8(*(const uint4*)(X + (base + r) * C + c0), x);
-                unpack8(*(const uint4*)(dY + (base + r) * C + c0), dy);
+            GnbChunk k;
+            gnb_load_chunk(k, stats, gamma, beta, unit, c0, cg, eps);
+            for (int r = r0 + rl; r < r1; r += 2 * rp) {
+                const bool two = r + rp < r1;
+                const uint4 xa = *(const uint4*)(X + (base + r) * C + c0), da = *(const uint4*)(dY + (base + r) * C + c0);
+                uint4 xb = xa, db = uint4{0u, 0u, 0u, 0u};
+                if (two) { xb = *(const uint4*)(X + (base + r + rp) * C + c0); db = *(const uint4*)(dY + (base + r + rp) * C + c0); }
+                float x[8], dy[8], x2[8], dy2[8];
+                unpack8(xa, x); unpack8(da, dy); unpack8(xb, x2); unpack8(db, dy2);      // a zero dy row adds exactly 0
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float xh = (x[e] - mean[e]) * rstd[e];
-                    const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, gm[e], bt[e]), silu);
+                    const float xh = (x[e] - k.mean[e]) * k.rstd[e], xh2 = (x2[e] - k.mean[e]) * k.rstd[e];
+                    const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, k.gm[e], k.bt[e]), silu);
+                    const float dz2 = gnb_dz(dy2[e], __builtin_fmaf(xh2, k.gm[e], k.bt[e]), silu);
                     a[e] += dz; b[e] = __builtin_fmaf(dz, xh, b[e]);
+                    a[e] += dz2; b[e] = __builtin_fmaf(dz2, xh2, b[e]);
                 }
             }
         }
@@ -319,56 +334,83 @@ __global__ __launch_bounds__(256) void gnb_reduce_kernel(const uint16_t* __restr
     }
 }
 
+// Blocks (unit, group): the splits of the group's channels summed by 256 / cg split lanes, the lanes combined in lane order.
 __global__ __launch_bounds__(256) void gnb_finish_kernel(const float* __restrict__ partial, int splits, int C,
                                                           const float* __restrict__ gamma, float* __restrict__ unit_cs,
                                                           float* __restrict__ AB) {
-    __shared__ float sA[4096], sB[4096];
-    const int unit = blockIdx.x, cg = C / GNB_GROUPS;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f, b = 0.f;
-        for (int sidx = 0; sidx < splits; ++sidx) {
+    __shared__ float ra[256], rb[256], sA[128], sB[128];
+    const int unit = blockIdx.x, g = blockIdx.y, cg = C / GNB_GROUPS;      // cg <= 128
+    const int lanes = 256 / cg, cl = threadIdx.x % cg, sl = threadIdx.x / cg;
+    const int c = g * cg + cl;
+    float a = 0.f, b = 0.f;
+    if (sl < lanes)
+        for (int sidx = sl; sidx < splits; sidx += lanes) {
             a += partial[(((int64_t)unit * splits + sidx) * 2) * C + c];
             b += partial[(((int64_t)unit * splits + sidx) * 2 + 1) * C + c];
         }
+    ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < cg) {
+        a = 0.f; b = 0.f;
+        for (int j = 0; j < lanes; ++j) { a += ra[j * cg + threadIdx.x]; b += rb[j * cg + threadIdx.x]; }
         unit_cs[((int64_t)unit * 2) * C + c] = a;
         unit_cs[((int64_t)unit * 2 + 1) * C + c] = b;
-        sA[c] = a * gamma[c]; sB[c] = b * gamma[c];
+        sA[threadIdx.x] = a * gamma[c]; sB[threadIdx.x] = b * gamma[c];
     }
     __syncthreads();
-    if (threadIdx.x < GNB_GROUPS) {
-        float a = 0.f, b = 0.f;
-        for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { a += sA[c]; b += sB[c]; }
-        AB[((int64_t)unit * GNB_GROUPS + threadIdx.x) * 2] = a;
-        AB[((int64_t)unit * GNB_GROUPS + threadIdx.x) * 2 + 1] = b;
+    if (threadIdx.x == 0) {
+        a = 0.f; b = 0.f;
+        for (int j = 0; j < cg; ++j) { a += sA[j]; b += sB[j]; }
+        AB[((int64_t)unit * GNB_GROUPS + g) * 2] = a;
+        AB[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] = b;
     }
 }
 
+// Same block / thread map as gnb_reduce: the per-chunk constants are loaded once per thread, two rows in flight.
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ dY,
                                                          const float* __restrict__ stats, const float* __restrict__ AB,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         int64_t rows, int C, int rows_per_unit, float eps, int silu,
+                                                         int C, int rows_per_unit, int rows_per_block, float eps, int silu,
                                                          uint16_t* __restrict__ dX) {
+    const int tid = threadIdx.x;
     const int chunks = C >> 3, cg = C / GNB_GROUPS;
+    const int cpb = chunks < 256 ? chunks : 256, rp = 256 / cpb;
+    const int ci = tid % cpb, rl = tid / cpb;
+    const int unit = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < rows_per_unit ? r0 + rows_per_block : rows_per_unit;
+    const int64_t base = (int64_t)unit * rows_per_unit;
     const float inv_n = 1.0f / ((float)rows_per_unit * (float)cg);
-    const int64_t total = rows * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / chunks;
-        const int c0 = (int)(i - r * chunks) * 8;
-        const int unit = (int)(r / rows_per_unit);
-        float x[8], dy[8], o[8];
-        unpack8(*(const uint4*)(X + r * C + c0), x);
-        unpack8(*(const uint4*)(dY + r * C + c0), dy);
+    if (rl >= rp) return;
+    for (int chunk = ci; chunk < chunks; chunk += cpb) {
+        const int c0 = chunk * 8;
+        GnbChunk k;
+        gnb_load_chunk(k, stats, gamma, beta, unit, c0, cg, eps);
+        float A[8], B[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c0 + e) / cg;
-            const float mean = stats[((int64_t)unit * GNB_GROUPS + g) * 2];
-            const float rstd = rsqrtf(stats[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] + eps);
-            const float A = AB[((int64_t)unit * GNB_GROUPS + g) * 2] * inv_n, B = AB[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] * inv_n;
-            const float xh = (x[e] - mean) * rstd;
-            const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, gamma[c0 + e], beta[c0 + e]), silu);
-            o[e] = rstd * (dz * gamma[c0 + e] - A - xh * B);
+            A[e] = AB[((int64_t)unit * GNB_GROUPS + g) * 2] * inv_n;
+            B[e] = AB[((int64_t)unit * GNB_GROUPS + g) * 2 + 1] * inv_n;
         }
-        *(uint4*)(dX + r * C + c0) = pack8(o);
+        for (int r = r0 + rl; r < r1; r += 2 * rp) {
+            const bool two = r + rp < r1;
+            const uint4 xa = *(const uint4*)(X + (base + r) * C + c0), da = *(const uint4*)(dY + (base + r) * C + c0);
+            uint4 xb = xa, db = da;
+            if (two) { xb = *(const uint4*)(X + (base + r + rp) * C + c0); db = *(const uint4*)(dY + (base + r + rp) * C + c0); }
+            float x[8], dy[8], x2[8], dy2[8], o[8], o2[8];
+            unpack8(xa, x); unpack8(da, dy); unpack8(xb, x2); unpack8(db, dy2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (x[e] - k.mean[e]) * k.rstd[e], xh2 = (x2[e] - k.mean[e]) * k.rstd[e];
+                const float dz = gnb_dz(dy[e], __builtin_fmaf(xh, k.gm[e], k.bt[e]), silu);
+                const float dz2 = gnb_dz(dy2[e], __builtin_fmaf(xh2, k.gm[e], k.bt[e]), silu);
+                o[e] = k.rstd[e] * (dz * k.gm[e] - A[e] - xh * B[e]);
+                o2[e] = k.rstd[e] * (dz2 * k.gm[e] - A[e] - xh2 * B[e]);
+            }
+            *(uint4*)(dX + (base + r) * C + c0) = pack8(o);
+            if (two) *(uint4*)(dX + (base + r + rp) * C + c0) = pack8(o2);
+        }
     }
 }
 
@@ -1110,14 +1152,13 @@ extern "C" int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, co
     WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0 && rows_per_block > 0, "groupnorm_bwd: bad rows");
     const int units = (int)(rows / rows_per_unit);
     const int splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
+    WIW_REQUIRE(splits <= 65535 && units <= 65535, "groupnorm_bwd: too many row splits / units");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gnb_reduce_kernel, dim3(splits, units), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
                        gamma, beta, C, rows_per_unit, rows_per_block, eps, silu, partial);
-    hipLaunchKernelGGL(gnb_finish_kernel, dim3(units), dim3(256), 0, s, partial, splits, C, gamma, unit_cs, AB);
-    int64_t blocks = (rows * (C >> 3) + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(gnb_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
-                       AB, gamma, beta, rows, C, rows_per_unit, eps, silu, (uint16_t*)dX);
+    hipLaunchKernelGGL(gnb_finish_kernel, dim3(units, GNB_GROUPS), dim3(256), 0, s, partial, splits, C, gamma, unit_cs, AB);
+    hipLaunchKernelGGL(gnb_apply_kernel, dim3(splits, units), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
+                       AB, gamma, beta, C, rows_per_unit, rows_per_block, eps, silu, (uint16_t*)dX);
     return wiw_check_launch("wiw_groupnorm_bwd");
 }
 

@@ -431,7 +431,9 @@ class Hip:
             stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
             self._ck(self.lib.wiw_groupnorm_stats(self._stream(), _p(X), Cn, None, 0, rows, rows_per_unit, rpb, stats.data_ptr(),
                                                   scratch.data_ptr()), "wiw_groupnorm_stats")
-        rpb_b = 256
+        # rows per block: enough (row split, unit) blocks for ~4 per CU, at least 64 rows each (the per-chunk constants are
+        # loaded once per thread; the finish pass sums the splits)
+        rpb_b = max(64, min(256, (rows_per_unit * units) // 1024))
         splits = -(-rows_per_unit // rpb_b)
         dX = torch.empty(rows, Cn, dtype=self.dtype, device=self.device)
         unit_cs = torch.empty(units, 2 * Cn, dtype=torch.float32, device=self.device)

@@ -131,7 +131,7 @@ class UNetTrain:
         # 16-bit outputs of a handful of rows are allocated with their rows padded to 64 (zeros): they are the A operand of
         # the next small GEMM and of its weight-gradient GEMM (K loop over rows).  fp32 outputs (per-unit vectors) are exact.
         Mp = 64 if (M < 64 and not out_f32) else M
-        y = torch.zeros(Mp, N, dtype=torch.float32 if out_f32 else self.dt, device=self.device)
+        y = (torch.zeros if Mp != M else torch.empty)(Mp, N, dtype=torch.float32 if out_f32 else self.dt, device=self.device)
         hip.gemm(x, W, y, M=M, N=N, K=K, C1=K, bias=b, epilogue=EPI_OUT_F32 if out_f32 else 0,
                  res1=res, ldr1=N if res is not None else 0, beta1=1.0 if res is not None else 0.0,
                  rowvec=rowvec, rowvec_ld=N if rowvec is not None else 0, rows_per_vec=rows_per_vec)
