@@ -30,8 +30,31 @@ def step_by_operator():
                         torch.zeros(1, Tn, 14))
     T.clear_wgrad_plans()
     T.set_wgrad_tuning(os.environ.get("TUNE", "0") == "1")
+    frecs = []
+
+    def fwrap(obj, name, label):
+        f = getattr(obj, name)
+
+        def g(*a, **k):
+            if not frecs_on[0]:
+                return f(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = f(*a, **k); e1.record()
+            frecs.append((label, e0, e1))
+            return out
+        setattr(obj, name, g)
+    frecs_on = [False]
+    for nm in ("linear", "conv", "groupnorm", "layernorm", "geglu", "silu", "blend", "concat", "upsample2x", "cast16", "_add_rowvec",
+               "host_sum"):
+        fwrap(net, nm, "net." + nm)
+    for nm in ("attn_spatial", "attn_small", "row_map", "transpose"):
+        fwrap(net.hip, nm, "hip." + nm)
     for it in range(3):
+        frecs_on[0] = it == 2
+        torch.cuda.synchronize(); tf0 = time.perf_counter()
         pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
+        torch.cuda.synchronize(); tfw = time.perf_counter() - tf0
+        frecs_on[0] = False
         loss, dpred = T.TrainStep(net.hip).loss_and_grad(pred, st)
         recs = []
 
@@ -49,6 +72,12 @@ def step_by_operator():
     agg = collections.defaultdict(lambda: [0, 0.0])
     for q, a, b in recs:
         agg[q][0] += 1; agg[q][1] += a.elapsed_time(b)
+    fagg = collections.defaultdict(lambda: [0, 0.0])
+    for q, e0, e1 in frecs:
+        fagg[q][0] += 1; fagg[q][1] += e0.elapsed_time(e1)
+    print(f"forward wall {tfw*1e3:.1f} ms (with per-call events; hip.* calls nest inside net.* ones only for attention):")
+    for q, (n, ms) in sorted(fagg.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {q:55s} {n:5d} calls    {ms:8.1f} ms")
     print(f"backward wall {dt*1e3:.1f} ms (with per-closure events); by operator:")
     for q, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"  {q:55s} {n:5d} closures {ms:8.1f} ms")

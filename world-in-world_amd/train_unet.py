@@ -195,9 +195,10 @@ class UNetTrain:
                 if need_dw:
                     xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
                     Mp = -(-M_out // 64) * 64
-                    xcolT = torch.zeros(9 * Cin, Mp, dtype=self.dt, device=self.device)
+                    alloc = torch.empty if Mp == M_out else torch.zeros
+                    xcolT = alloc(9 * Cin, Mp, dtype=self.dt, device=self.device)
                     hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
-                    dyT = torch.zeros(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
+                    dyT = alloc(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
                     hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
                     from .train import wgrad_gemm
                     dW = wgrad_gemm(hip, dyT, xcolT, dyp.shape[1], 9 * Cin, Mp)
