@@ -352,6 +352,11 @@ int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_of
  *                       conv as a stride-1 conv), 2 sum-pool 2x2 (gradient of the upsample), 3 (b,t,s) -> (b,s,t padded to Tp)
  *                       and 4 back (temporal attention as per-site sequences). */
 int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, int stride, void* Xcol);
+/*   wiw_gather_taps_t_bf16  the same im2col rows written TRANSPOSED, XcolT [taps*C][Mp] (zero columns for M <= m < Mp, Mp % 8
+ *                       == 0): directly the K-contiguous operand of the weight-gradient GEMM, without the [M][taps*C]
+ *                       intermediate and its transpose. */
+int wiw_gather_taps_t_bf16(void* stream, const void* X, int64_t M, int64_t Mp, int C, int H, int Wd, int T, int temporal, int stride,
+                           void* XcolT);
 int wiw_axpby_bf16(void* stream, const void* X, const void* Y, float a, float b, int64_t n, void* out);
 int wiw_silu_bf16(void* stream, const void* X, const void* dY, int backward, int64_t n, void* out);
 int wiw_dot_bf16(void* stream, const void* X, const void* Y, const void* Z, int64_t n, float* partial, int n_partial);

@@ -732,3 +732,23 @@ def test_gemm_layernorm_fold_validation(hip):
     with pytest.raises(RuntimeError, match="N % 160"):
         hip.gemm(a, dev_bf(rnd(128, 64, seed=2)), torch.empty(128, 128, dtype=torch.bfloat16, device=DEV), M=128, N=128, K=64,
                  C1=64, lnfold=dev_f(rnd(2, 128)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C,c0,ldx,pad", [(64, 64, 0, 64, 0), (200, 72, 8, 96, 8), (4032, 320, 640, 960, 64), (8, 8, 0, 8, 0),
+                                               (1000, 136, 0, 136, 24)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_transpose_is_exact(rows, C, c0, ldx, pad, dtype):
+    """wiw_transpose_bf16: Y[c][r] = X[r][c0 + c], bit for bit — whole and ragged 64 x 64 tiles, a column window of a wider
+    matrix (the V block of a fused q|k|v projection), a padded output row stride (the zero-padded K of the weight-gradient
+    GEMMs keeps its zeros), both 16-bit types (a 16-bit move: the same kernel serves both)."""
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV), dtype)
+    g = torch.Generator().manual_seed(rows + C)
+    X = torch.randn(rows, ldx, generator=g).to(dtype).to(DEV)
+    ldy = rows + pad
+    Y = torch.full((C, ldy), 7.0, dtype=dtype, device=DEV)
+    hip.transpose(X, ldx, c0, rows, C, Y, ldy)
+    assert torch.equal(Y[:, :rows], X[:, c0:c0 + C].t())
+    assert bool((Y[:, rows:] == 7.0).all())                                    # nothing written past the rows

@@ -212,6 +212,27 @@ def test_groupnorm_backward(n, C, h, w, unit_frames, silu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,C,h,w,T,temporal,stride", [(4, 64, 6, 10, 1, False, 1), (3, 72, 5, 7, 1, False, 2), (6, 128, 4, 6, 3, True, 1),
+                                                        (14, 320, 9, 16, 14, True, 1)])
+def test_transposed_im2col_rows_equal_the_row_major_ones(n, C, h, w, T, temporal, stride):
+    """wiw_gather_taps_t_bf16 == transpose(wiw_gather_taps_bf16), bit for bit, zero columns up to the 64-multiple: 3x3 pad 1,
+    stride-2 (input grid (2h, 2w)), temporal taps; row counts that are not multiples of 64, C = 72 (a ragged channel tile)."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV))
+    M = n * h * w
+    rows_in = M * (4 if stride == 2 else 1)
+    X = _rnd(rows_in, C, seed=M).to(torch.bfloat16).to(DEV)
+    rows = hip.gather_taps(X, M, C, h, w, T, temporal, stride)
+    cols = hip.gather_taps_t(X, M, C, h, w, T, temporal, stride)
+    Mp = -(-M // 64) * 64
+    assert tuple(cols.shape) == ((3 if temporal else 9) * C, Mp)
+    assert torch.equal(cols[:, :M], rows.t()) and bool((cols[:, M:] == 0).all())
+    assert float(rows.float().abs().sum()) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("temporal", [False, True])
 def test_conv_backward(temporal):
     import math

@@ -131,32 +131,40 @@ inline int grid_for(int64_t total, int block) {
     return (int)g;
 }
 
-// Y[c][r] = X[r][c0 + c]  (bf16), 64 x 64 tiles through LDS: 128-byte row segments on both sides.
-// Used to hand the attention kernel V^T from a V that one fused q|k|v projection wrote row-major.
+// Y[c][r] = X[r][c0 + c]  (16-bit), 64 x 64 tiles through LDS: 128-byte row segments on both sides.
+// Hands the attention kernel V^T from a V that one fused q|k|v projection wrote row-major, and the training step the
+// K-contiguous operands of its weight-gradient GEMMs.  A thread loads the same 8 columns of TWO consecutive rows and
+// writes 8 words (X[2p][c] | X[2p+1][c] << 16) into tile[c][p] — the 2 x 2 transposes happen in registers, so LDS sees
+// 32-bit writes (conflict-free at a row stride of 33 words) and 32-bit reads instead of twice as many 16-bit ones.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ X, int64_t ldx, int c0, int64_t rows,
                                                               int C, uint16_t* __restrict__ Y, int64_t ldy) {
-    __shared__ uint16_t tile[64][66];   // +2: the column reads below hit 64 different banks pairs
+    __shared__ uint32_t tile[64][33];
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int cb = blockIdx.y * 64;
     const int tid = threadIdx.x;
-    // load: 64 rows x 128 B; thread -> (row = tid / 4 + 0 / 64 ..., 32-byte piece)
-    for (int i = tid; i < 64 * 8; i += 256) {
-        const int r = i >> 3, ch = i & 7;                       // 8 chunks of 16 B per row
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (r0 + r < rows && cb + ch * 8 < C) v = *(const uint4*)(X + (r0 + r) * ldx + c0 + cb + ch * 8);
-        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+    {
+        const int p = tid >> 3, ch = tid & 7;                     // row pair, 16-byte chunk
+        uint4 a = uint4{0u, 0u, 0u, 0u}, b = a;
+        if (cb + ch * 8 < C && r0 + 2 * p < rows) {               // rows % 8 == 0: the pair is inside or outside together
+            const uint16_t* src = X + (r0 + 2 * p) * ldx + c0 + cb + ch * 8;
+            a = *(const uint4*)src;
+            b = *(const uint4*)(src + ldx);
+        }
+        const uint32_t au[4] = {a.x, a.y, a.z, a.w}, bu[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { tile[r][ch * 8 + 2 * e] = (uint16_t)(u[e] & 0xffffu); tile[r][ch * 8 + 2 * e + 1] = (uint16_t)(u[e] >> 16); }
+        for (int e = 0; e < 4; ++e) {
+            tile[ch * 8 + 2 * e][p] = (au[e] & 0xffffu) | (bu[e] << 16);
+            tile[ch * 8 + 2 * e + 1][p] = (au[e] >> 16) | (bu[e] & 0xffff0000u);
+        }
     }
     __syncthreads();
-    for (int i = tid; i < 64 * 8; i += 256) {
-        const int c = i >> 3, ch = i & 7;                       // output row c, 8 consecutive source rows
-        if (cb + c < C && r0 + ch * 8 < rows) {
-            uint32_t u[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) u[e] = (uint32_t)tile[ch * 8 + 2 * e][c] | ((uint32_t)tile[ch * 8 + 2 * e + 1][c] << 16);
-            *(uint4*)(Y + (int64_t)(cb + c) * ldy + r0 + ch * 8) = uint4{u[0], u[1], u[2], u[3]};
-        }
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * 256;
+        const int c = i >> 3, ch = i & 7;                         // output row c, 8 consecutive source rows = 4 words
+        if (cb + c < C && r0 + ch * 8 < rows)
+            *(uint4*)(Y + (int64_t)(cb + c) * ldy + r0 + ch * 8) =
+                uint4{tile[c][ch * 4], tile[c][ch * 4 + 1], tile[c][ch * 4 + 2], tile[c][ch * 4 + 3]};
     }
 }
 

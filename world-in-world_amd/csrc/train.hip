@@ -446,6 +446,56 @@ __global__ __launch_bounds__(256) void gather_taps_kernel(const uint16_t* __rest
     }
 }
 
+// The same im2col rows written TRANSPOSED: XcolT[tap * C + c][m] = X[src(m, tap)][c], m < M, zero columns for M <= m < Mp —
+// directly the K-contiguous operand of the weight-gradient GEMM (K loop over the M rows), without materialising the
+// [M][taps * C] rows and transposing them (9x the activation, written and read once more).  64 tokens x 64 channels per
+// workgroup and tap through LDS; the 2 x 2 transposes in registers as in wiw_transpose_bf16 (elementwise.hip).
+__global__ __launch_bounds__(256) void gather_taps_t_kernel(const uint16_t* __restrict__ X, int64_t M, int64_t Mp, int C, int H, int W,
+                                                             int T, int temporal, int stride, uint16_t* __restrict__ XcolT) {
+    __shared__ uint32_t tile[64][33];
+    const int cblocks = (C + 63) >> 6;
+    const int tap = blockIdx.y / cblocks, cb = (blockIdx.y % cblocks) * 64;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x, HW = H * W;
+    {
+        const int p = tid >> 3, ch = tid & 7;
+        uint4 v[2] = {uint4{0u, 0u, 0u, 0u}, uint4{0u, 0u, 0u, 0u}};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t m = m0 + 2 * p + q;
+            int64_t src = -1;
+            if (m < M && cb + ch * 8 < C) {
+                if (temporal) {
+                    const int t = (int)((m / HW) % T) + tap - 1;
+                    if (t >= 0 && t < T) src = m + (int64_t)(tap - 1) * HW;
+                } else if (stride == 1) {
+                    const int rem = (int)(m % HW), y = rem / W + tap / 3 - 1, x = rem % W + tap % 3 - 1;
+                    if (y >= 0 && y < H && x >= 0 && x < W) src = m + (int64_t)(tap / 3 - 1) * W + (tap % 3 - 1);
+                } else {
+                    const int rem = (int)(m % HW), y = 2 * (rem / W) + tap / 3 - 1, x = 2 * (rem % W) + tap % 3 - 1;
+                    if (y >= 0 && y < 2 * H && x >= 0 && x < 2 * W) src = (m / HW) * (4 * HW) + (int64_t)y * (2 * W) + x;
+                }
+            }
+            if (src >= 0) v[q] = *(const uint4*)(X + src * C + cb + ch * 8);
+        }
+        const uint32_t au[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, bu[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[ch * 8 + 2 * e][p] = (au[e] & 0xffffu) | (bu[e] << 16);
+            tile[ch * 8 + 2 * e + 1][p] = (au[e] >> 16) | (bu[e] & 0xffff0000u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * 256;
+        const int c = i >> 3, ch = i & 7;
+        if (cb + c < C && m0 + ch * 8 < Mp)
+            *(uint4*)(XcolT + ((int64_t)tap * C + cb + c) * Mp + m0 + ch * 8) =
+                uint4{tile[c][ch * 4], tile[c][ch * 4 + 1], tile[c][ch * 4 + 2], tile[c][ch * 4 + 3]};
+    }
+}
+
 // GEGLU forward on a SAVED projection output (training keeps P = [v | g] for the backward; inference fuses this into the
 // GEMM epilogue on packed weights): H[r][c] = v * gelu_erf(g)
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restrict__ P, int64_t rows, int Ch, uint16_t* __restrict__ Hh) {
@@ -1142,6 +1192,19 @@ extern "C" int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int 
     hipLaunchKernelGGL(gather_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, M, C, H,
                        Wd, T, temporal, stride, (uint16_t*)Xcol);
     return wiw_check_launch("wiw_gather_taps_bf16");
+}
+
+extern "C" int wiw_gather_taps_t_bf16(void* stream, const void* X, int64_t M, int64_t Mp, int C, int H, int Wd, int T, int temporal,
+                                      int stride, void* XcolT) {
+    WIW_REQUIRE(X && XcolT && M > 0 && Mp >= M && Mp % 8 == 0 && C > 0 && C % 8 == 0 && H > 0 && Wd > 0 &&
+                (stride == 1 || (stride == 2 && !temporal)), "gather_taps_t: bad arguments");
+    WIW_REQUIRE(M % ((int64_t)H * Wd) == 0 && (!temporal || (T > 0 && (M / ((int64_t)H * Wd)) % T == 0)), "gather_taps_t: bad geometry");
+    const int taps = temporal ? 3 : 9;
+    const int64_t mblocks = (Mp + 63) / 64;
+    WIW_REQUIRE(mblocks < (1ll << 31) && (int64_t)taps * ((C + 63) / 64) <= 65535, "gather_taps_t: grid too large");
+    hipLaunchKernelGGL(gather_taps_t_kernel, dim3((unsigned)mblocks, (unsigned)(taps * ((C + 63) / 64))), dim3(256), 0,
+                       (hipStream_t)stream, (const uint16_t*)X, M, Mp, C, H, Wd, T, temporal, stride, (uint16_t*)XcolT);
+    return wiw_check_launch("wiw_gather_taps_t_bf16");
 }
 
 extern "C" int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, const float* stats, const float* gamma,

@@ -119,6 +119,8 @@ EXPORTS = {
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     "wiw_edm_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                     C.c_void_p, C.c_int]),
+    "wiw_gather_taps_t_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p]),
     "wiw_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wiw_layernorm_bwd_partials": (C.c_int64, [C.c_int64]),
     "wiw_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
@@ -470,6 +472,15 @@ class Hip:
         out = torch.empty(M, (3 if temporal else 9) * Cn, dtype=self.dtype, device=self.device)
         self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), stride, _p(out)),
                  "wiw_gather_taps_bf16")
+        return out
+
+    def gather_taps_t(self, X, M, Cn, H, Wd, T=1, temporal=False, stride=1):
+        """The im2col rows of `gather_taps`, TRANSPOSED: [taps*Cn, Mp] with Mp = M rounded up to 64 (zero columns) — the
+        K-contiguous operand of the weight-gradient GEMM in one pass over X."""
+        Mp = -(-M // 64) * 64
+        out = torch.empty((3 if temporal else 9) * Cn, Mp, dtype=self.dtype, device=self.device)
+        self._ck(self.lib.wiw_gather_taps_t_bf16(self._stream(), _p(X), M, Mp, Cn, H, Wd, T, int(temporal), stride, _p(out)),
+                 "wiw_gather_taps_t_bf16")
         return out
 
     def axpby(self, X, a=1.0, Y=None, b=1.0, out=None):

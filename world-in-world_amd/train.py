@@ -150,30 +150,32 @@ def load_wgrad_plans(plans: dict) -> None:
     _WGRAD_PLANS.update({k: (int(v[0]), int(v[1])) for k, v in plans.items()})
 
 
-def _wgrad_run(hip: Hip, dyT, xT, n_out, k_in, k_rows, flip, sk):
+def _wgrad_run(hip: Hip, dyT, xT, n_out, k_in, k_rows, flip, sk, view_ok=False):
     from .hip import EPI_OUT_F32
 
     if flip:
         out = torch.empty(k_in, n_out, dtype=torch.float32, device=hip.device)
         hip.gemm(xT, dyT, out, M=k_in, N=n_out, K=k_rows, C1=k_rows, epilogue=EPI_OUT_F32, splitk=sk)
-        return out.t()
+        # the strided copy back is part of a flipped plan's price (and of its timing) unless the caller re-lays the
+        # gradient out anyway (the convolutions: (O, ky, kx, I) -> (O, I, ky, kx) is one copy from either orientation)
+        return out.t() if view_ok else out.t().contiguous()
     out = torch.empty(n_out, k_in, dtype=torch.float32, device=hip.device)
     hip.gemm(dyT, xT, out, M=n_out, N=k_in, K=k_rows, C1=k_rows, epilogue=EPI_OUT_F32, splitk=sk)
     return out
 
 
-def _wgrad_tune(hip: Hip, dyT, xT, n_out, k_in, k_rows):
+def _wgrad_tune(hip: Hip, dyT, xT, n_out, k_in, k_rows, view_ok):
     nk = k_rows // 64
     cands = [(f, sk) for f in (0, 1) for sk in range(1, 129)
              if nk % sk == 0 and (sk == 1 or nk // sk >= 8) and sk * n_out * k_in * 4 <= (1 << 30)]
     model = wgrad_plan(n_out, k_in, k_rows)
     best = None
     for f, sk in cands:
-        _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk)                  # warm (workspace allocation, code load)
+        _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk, view_ok)         # warm (workspace allocation, code load)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(2):
-            _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk)
+            _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk, view_ok)
         b.record()
         b.synchronize()
         t = a.elapsed_time(b)
@@ -182,15 +184,15 @@ def _wgrad_tune(hip: Hip, dyT, xT, n_out, k_in, k_rows):
     return best[1], best[2]
 
 
-def wgrad_gemm(hip: Hip, dyT: torch.Tensor, xT: torch.Tensor, n_out: int, k_in: int, k_rows: int) -> torch.Tensor:
-    """fp32 dW [n_out, k_in] = dyT [n_out, k_rows] . xT [k_in, k_rows]^T in the orientation / split of the shape's plan (a
-    transposed VIEW when the GEMM produced dW^T)."""
-    key = f"{n_out},{k_in},{k_rows}"
+def wgrad_gemm(hip: Hip, dyT: torch.Tensor, xT: torch.Tensor, n_out: int, k_in: int, k_rows: int, view_ok: bool = False) -> torch.Tensor:
+    """fp32 dW [n_out, k_in] = dyT [n_out, k_rows] . xT [k_in, k_rows]^T in the orientation / split of the shape's plan
+    (contiguous — a flipped plan pays for the copy back — unless view_ok: then a flipped plan returns the transposed view)."""
+    key = f"{n_out},{k_in},{k_rows}" + (",v" if view_ok else "")
     plan = _WGRAD_PLANS.get(key)
     if plan is None:
-        plan = _wgrad_tune(hip, dyT, xT, n_out, k_in, k_rows) if _WGRAD_TUNE else wgrad_plan(n_out, k_in, k_rows)
+        plan = _wgrad_tune(hip, dyT, xT, n_out, k_in, k_rows, view_ok) if _WGRAD_TUNE else wgrad_plan(n_out, k_in, k_rows)
         _WGRAD_PLANS[key] = plan
-    return _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, plan[0], plan[1])
+    return _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, plan[0], plan[1], view_ok)
 
 
 def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True,
@@ -232,7 +234,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     or, temporal=True, (3,1,1) pad 1 over T (TemporalResnetBlock, resnet.py:570-592).  x [M, Cin] token-major, Wk [Cout, taps*Cin]
     in the kernel's layout ([Cout][ky][kx][Cin] / [Cout][kt][Cin]), dy [M, Cout]; Cin, Cout, M % 64 == 0.
         dx  = the SAME convolution of dy with the taps mirrored and the channel roles swapped (W2[ci][tap'][co] = W[co][tap][ci])
-        dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: wiw_gather_taps_bf16 + two transposes + one GEMM over the M rows)
+        dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: wiw_gather_taps_t_bf16 = transposed im2col rows in one pass, dy^T, one GEMM over the M rows)
         db  = column sums of dy
     (the stride-2 / upsampling variants are not covered yet)."""
     from .hip import A_CONV3X3, A_CONV_T3, EPI_OUT_F32
@@ -251,12 +253,10 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
         hip.gemm(dy, W2, dx, M=M, N=Cin, K=taps * Cout, C1=Cout, mode=A_CONV_T3 if temporal else A_CONV3X3, H=H, Wd=Wd, T=T)
     if not need_dw:
         return dx, None, None
-    xcol = hip.gather_taps(x, M, Cin, H, Wd, T, temporal)
-    xcolT = alloc(taps * Cin, Mp, dtype=dt, device=dev)
-    hip.transpose(xcol, taps * Cin, 0, M, taps * Cin, xcolT, Mp)
+    xcolT = hip.gather_taps_t(x, M, Cin, H, Wd, T, temporal)              # [taps * Cin, Mp], one pass over x
     dyT = alloc(Cout, Mp, dtype=dt, device=dev)
     hip.transpose(dy, Cout, 0, M, Cout, dyT, Mp)
-    dW = wgrad_gemm(hip, dyT, xcolT, Cout, taps * Cin, Mp)
+    dW = wgrad_gemm(hip, dyT, xcolT, Cout, taps * Cin, Mp, view_ok=True)   # [Cout, taps * Cin], possibly a transposed view
     return dx, dW, hip.colsum(dy, M, Cout)
 
 

@@ -193,15 +193,13 @@ class UNetTrain:
                 dx = torch.empty(4 * M_out, Cin, dtype=self.dt, device=self.device)
                 hip.gemm(dil, W2, dx, M=4 * M_out, N=Cin, K=9 * Wp.shape[0], C1=Wp.shape[0], mode=A_CONV3X3, H=2 * H, Wd=2 * W)
                 if need_dw:
-                    xcol = hip.gather_taps(x, M_out, Cin, H, W, stride=2)
                     Mp = -(-M_out // 64) * 64
                     alloc = torch.empty if Mp == M_out else torch.zeros
-                    xcolT = alloc(9 * Cin, Mp, dtype=self.dt, device=self.device)
-                    hip.transpose(xcol, 9 * Cin, 0, M_out, 9 * Cin, xcolT, Mp)
+                    xcolT = hip.gather_taps_t(x, M_out, Cin, H, W, stride=2)
                     dyT = alloc(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
                     hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
                     from .train import wgrad_gemm
-                    dW = wgrad_gemm(hip, dyT, xcolT, dyp.shape[1], 9 * Cin, Mp)
+                    dW = wgrad_gemm(hip, dyT, xcolT, dyp.shape[1], 9 * Cin, Mp, view_ok=True)
                     db = hip.colsum(dy, M_out, Cout)
             else:
                 dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3), need_dw=need_dw)
@@ -210,10 +208,10 @@ class UNetTrain:
             if not need_dw:                                               # frozen convolution: only dx flows on
                 return
             dW = dW[:Cout]
-            if mode == A_CONV_T3:
-                g = dW.reshape(Cout, 3, Cin).permute(0, 2, 1)[:, : ref_w.shape[1]].reshape(ref_w.shape)
+            if mode == A_CONV_T3:                                         # unflatten: a view of either orientation -> one copy
+                g = dW.unflatten(1, (3, Cin)).permute(0, 2, 1)[:, : ref_w.shape[1]].reshape(ref_w.shape)
             else:
-                g = dW.reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)[:, : ref_w.shape[1]]
+                g = dW.unflatten(1, (3, 3, Cin)).permute(0, 3, 1, 2)[:, : ref_w.shape[1]]
             self.grads[name + ".weight"] = g.contiguous()
             self.grads[name + ".bias"] = db
         tape.ops.append(bwd)
