@@ -664,7 +664,7 @@ class Trainer:
         grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
         net.tape.after_op = None
         self._seen = {n for n in grads if self.trainable(n)}
-        if self.loss_scale != 1.0 and not all(bool(torch.isfinite(g).all()) for g in grads.values()):
+        if self.loss_scale != 1.0 and not bool(torch.stack([torch.isfinite(g).all() for g in grads.values()]).all()):   # one host sync
             self.loss_scale *= 0.5                                         # overflow: skip the update, as a GradScaler does
             self._micro, self._acc = 0, {}
             return float(loss)
