@@ -712,6 +712,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
 // and the transposed A operand is read from LDS under the same permutation (two 8-byte reads).
 // Per step and wave: 32 MFMAs (dK/dV), 24 + 8 (dQ + its log-sum-exp pass), 16 KB of LDS reads.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef WIW_DKV_OCC   // waves per SIMD the register allocator is held to (A/B knob of the build: -DWIW_DKV_OCC= to lift)
+#define WIW_DKV_OCC
+#endif
+#ifndef WIW_DQ_OCC
+#define WIW_DQ_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 constexpr int ATB_ROW = 72;    // elements per LDS row of a [32 rows][64 d] tile (144 B: 16-byte reads of 16 rows spread over the banks)
 constexpr int ATB_TROW = 40;   // elements per LDS row of a [64 d][32 rows] transposed tile (80 B)
 
@@ -723,7 +729,7 @@ __device__ __forceinline__ bf16x8 atb_tr_frag(const uint16_t* base) {     // row
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+__global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
                                                                   const uint16_t* __restrict__ Qt, const uint16_t* __restrict__ dOt,
                                                                   int64_t ldt, const uint16_t* __restrict__ dO, int ldo,
                                                                   uint16_t* __restrict__ dQKV, int ldd, const float* __restrict__ LSE,
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_tiled_kernel(const uint16_t*
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
+__global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
                                                                  const uint16_t* __restrict__ Kt, int64_t ldt,
                                                                  const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, int ldo,
                                                                  uint16_t* __restrict__ dQKV, int ldd, float* __restrict__ LSE,
