@@ -8,7 +8,8 @@ around the reference's own `UNetSpatioTemporalConditionModel` (imported from /ro
 loss, the model prediction and the parameter gradients: every gradient's norm, and the full gradient of a dozen tensors that
 cover every operator class on the path.  `oracle/train_oracle.py` must reproduce them (tests/test_train_oracle.py).
 
-    PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py          # scenario a: tests/golden/train_step_tiny.npz
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py extra    # scenarios b, c: train_step_tiny_bc.npz
 """
 import os
 import sys
@@ -121,5 +122,81 @@ def main():
          **{"adamw_after__" + k.replace(".", "__"): prms[k].detach().numpy() for k in opt_names}, **full)
 
 
+def derived_inputs(g, which: str):
+    """Inputs of the extra scenarios, derived from the stored scenario-a tensors so that no second set of inputs has to be
+    committed (tests rebuild them the same way): flips and rescalings."""
+    lat, noise = torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"])
+    cond, ehs = torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"])
+    if which == "b":
+        return lat.flip(-1) * 0.9, noise.flip(-2), cond * 1.1, ehs.flip(-1)
+    return lat.flip(-2) * 1.1, noise.flip(-1), cond.flip(-1) * 0.8, ehs * 0.7
+
+
+SCENARIOS = {   # sigma, noise_aug_strength, random_p (dropout prob 0.1), actions
+    "b": (0.35, 0.021, 0.25, [[1, 3, 3, 2]]),   # low noise level; prob <= p < 3 prob and p >= 2 prob: conditioning LATENTS zeroed
+    "c": (6.5, 0.090, 0.05, [[2, 2, 4, 1]]),    # high noise level; p < 2 prob and p < prob: image EMBEDDING zeroed, latents kept
+}
+FULL_EXTRA = ["conv_in.weight", "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+              "down_blocks.0.resnets.0.temporal_res_block.conv2.weight"]
+
+
+def extra():
+    """tests/golden/train_step_tiny_bc.npz: two more seeded steps of the reference (other noise levels, the two
+    conditioning-dropout branches that zero a condition, other actions): loss, prediction, every gradient norm, three
+    full gradients.  Same weights (seed 7) and the scenario-a inputs transformed by `derived_inputs`."""
+    ns = import_reference()
+    from utils.svd_utils import apply_conditioning_dropout  # type: ignore  (reference)
+
+    torch.set_num_threads(8)
+    cfg = UNetConfig.tiny(4)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_tiny.npz"))
+    out = {}
+    for which, (sigma, nas, p, actions) in SCENARIOS.items():
+        m = ref_unet(ns, cfg, seed=7).float().train()
+        for prm in m.parameters():
+            prm.requires_grad_(True)
+        latents, noise, conditional_latents, encoder_hidden_states = derived_inputs(g, which)
+        sigmas, random_p, bsz = torch.tensor([sigma], dtype=torch.float32), torch.tensor([p]), 1
+        sig = sigmas[:, None, None, None, None]
+        noisy_latents = latents + noise * sig                                                     # train_svd.py:888-894
+        timesteps = torch.Tensor([0.25 * s_.log() for s_ in sig])
+        inp_noisy_latents = noisy_latents / ((sig ** 2 + 1) ** 0.5)
+        added_time_ids = torch.tensor([[7, 127, nas]], dtype=torch.float32).repeat(bsz, 1)          # :899-907
+        action_ids = ns.get_action_ids(bsz, torch.from_numpy(np.array(actions, dtype=np.int64)), "micro_cond", torch.float32)
+        orig_rand = torch.rand
+        torch.rand = lambda *a, **k: random_p.clone()
+        try:                                                                                       # :911-921
+            ehs_d, cond_d, act_d = apply_conditioning_dropout(
+                encoder_hidden_states=encoder_hidden_states, conditional_latents=conditional_latents,
+                action_conditioning=action_ids, bsz=bsz, conditioning_dropout_prob=0.1, generator=None)
+        finally:
+            torch.rand = orig_rand
+        assert (which == "b") == bool((cond_d == 0).all()) and (which == "c") == bool((ehs_d == 0).all())
+        cond_rep = cond_d.unsqueeze(1).repeat(1, noisy_latents.shape[1], 1, 1, 1)                 # :926-931
+        inp = torch.cat([inp_noisy_latents, cond_rep], dim=2)
+        model_pred = m(inp, timesteps, ehs_d, added_time_ids=added_time_ids, added_action_ids=act_d).sample   # :933-939
+        c_out = -sig / ((sig ** 2 + 1) ** 0.5)                                                    # :941-952
+        c_skip = 1 / (sig ** 2 + 1)
+        denoised_latents = model_pred * c_out + c_skip * noisy_latents
+        weighing = (1 + sig ** 2) * (sig ** -2.0)
+        loss = torch.mean((weighing.float() * (denoised_latents.float() - latents.float()) ** 2).reshape(bsz, -1), dim=1).mean()
+        loss.backward()
+        names, norms = [], []
+        for k, prm in m.named_parameters():
+            names.append(k)
+            norms.append(0.0 if prm.grad is None else float(prm.grad.double().norm()))
+            if k in FULL_EXTRA:
+                out[f"{which}__grad__" + k.replace(".", "__")] = prm.grad.numpy()
+        out.update({f"{which}__sigmas": sigmas.numpy(), f"{which}__noise_aug_strength": np.array(nas), f"{which}__random_p": random_p.numpy(),
+                    f"{which}__action_ids": action_ids.numpy(), f"{which}__loss": np.array(float(loss)),
+                    f"{which}__model_pred": model_pred.detach().numpy(), f"{which}__grad_norms": np.array(norms)})
+        out["grad_names"] = np.array(names)
+        print(which, "loss", float(loss))
+    save("train_step_tiny_bc.npz", dropout_prob=np.array(0.1), weight_seed=np.array(7), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+    else:
+        main()

@@ -7,6 +7,7 @@ backward kernels before any of them exists (f2 is not built yet).
 
 Tolerances: fp32 summation order only — loss 1e-5 relative, prediction and gradients 2e-4 of the tensor's max."""
 import numpy as np
+import pytest
 import torch
 
 import svd_oracle as O
@@ -121,3 +122,46 @@ def test_lr_schedules_match_the_published_lambda_schedulers():
             assert abs(opt.param_groups[0]["lr"] - lr_at(step, 2e-5, name, 50, 120)) <= 1e-12, (name, step)
             opt.step()
             sch.step()
+
+
+def _derived(g, which):
+    """The inputs of scenarios b / c: the stored scenario-a tensors transformed as oracle/make_train_golden.py `derived_inputs`."""
+    lat, noise = torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"])
+    cond, ehs = torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"])
+    if which == "b":
+        return lat.flip(-1) * 0.9, noise.flip(-2), cond * 1.1, ehs.flip(-1)
+    return lat.flip(-2) * 1.1, noise.flip(-1), cond.flip(-1) * 0.8, ehs * 0.7
+
+
+@pytest.mark.parametrize("which", ["b", "c"])
+def test_training_step_other_noise_levels_and_dropout_branches(golden, which):
+    """Two more steps of the REFERENCE (tests/golden/train_step_tiny_bc.npz): sigma 0.35 with the conditioning latents
+    dropped (b), sigma 6.5 with the image embedding dropped (c), other actions — loss, prediction, every gradient norm and
+    three full gradients of the restatement against the reference's autograd."""
+    g, cfg, sd = _setup(golden)
+    e = golden("train_step_tiny_bc.npz")
+    torch.set_num_threads(8)
+    lat, noise, cond, ehs = _derived(g, which)
+    loss, pred, grads = TO.training_step(sd, cfg.as_dict(), lat, noise, torch.from_numpy(e[f"{which}__sigmas"]), cond, ehs,
+                                         float(e[f"{which}__noise_aug_strength"]), torch.from_numpy(e[f"{which}__action_ids"]),
+                                         dropout_prob=float(e["dropout_prob"]), random_p=torch.from_numpy(e[f"{which}__random_p"]))
+    assert abs(float(loss) - float(e[f"{which}__loss"])) <= 1e-5 * float(e[f"{which}__loss"])
+    ref = torch.from_numpy(e[f"{which}__model_pred"])
+    assert float((pred - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    is_dead = lambda n: ("transformer_blocks.0.norm2." in n) or (".attn2.to_q." in n) or (".attn2.to_k." in n) or \
+        n.startswith("add_embedding.")  # noqa: E731
+    worst = 0.0
+    for n, nr in zip((str(n) for n in e["grad_names"]), e[f"{which}__grad_norms"]):
+        if is_dead(n):
+            continue
+        gn = 0.0 if grads[n] is None else float(grads[n].double().norm())
+        if which == "c" and (".attn2." in n or "norm2" in n) and nr == 0.0:
+            assert gn == 0.0, n                        # zeroed image embedding: the cross-attention value path gets no gradient
+            continue
+        worst = max(worst, max(abs(gn - nr) - 1e-9, 0.0) / max(nr, 1e-12))
+    assert worst <= 1e-3, worst
+    for key in e.files:
+        if key.startswith(f"{which}__grad__"):
+            name = key[len(f"{which}__grad__"):].replace("__", ".")
+            r = torch.from_numpy(e[key])
+            assert float((grads[name] - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-12, name
