@@ -336,9 +336,10 @@ int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H);
  *                       blocks and of dO (wiw_transpose_bf16);  O, dO [rows][ldo];  dQKV [rows][ldd] receives dQ | dK | dV at the
  *                       same column offsets;  lse, dsum: fp32 [seqs*heads*Sp] scratch (row log-sum-exp in the log2 domain and
  *                       D = sum_d dO O, written by the first kernel, read by the second).  Scores are recomputed; deterministic.
- *                       S == Sp, S % 32 == 0, S >= 128 (the spatial sequences; needs ldt % 8 == 0): LDS-tiled kernels, 128 rows
- *                       per workgroup, 32-deep contraction steps; otherwise (temporal sequences of 14 padded to 16): one wave
- *                       per 16-row tile, operands from global memory. */
+ *                       S == Sp, S % 32 == 0, S >= 128 (the spatial sequences): LDS-tiled kernels, 128 rows per workgroup,
+ *                       32-deep contraction steps, transposed operands read from the row-major tiles (Qt, Kt, dOt may be
+ *                       NULL); otherwise (temporal sequences of 14 padded to 16): one wave per 16-row tile, operands from
+ *                       global memory incl. the three transposes. */
 int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt, const void* dOt,
                       int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd, float* lse, float* dsum, int seqs,
                       int S, int Sp, int heads, int head_dim, float scale);

@@ -709,37 +709,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
 // global loads in flight behind the MFMAs) — the simple form re-read every tile per wave through L1, which bounded it.
 // The contraction of the second GEMMs runs over 32 rows per MFMA (both halves of the 16x16x32 K used): the two score tiles
 // of a step are packed into ONE B operand under the k permutation  e < 4 -> row 4 fq + e,  e >= 4 -> row 16 + 4 fq + e - 4,
-// and the transposed A operand is read from LDS under the same permutation (two 8-byte reads).
+// and the transposed A operand is read from the SAME row-major LDS tile under that permutation with two
+// ds_read_b64_tr_b16 (atb_tr_frag) — Q^T, K^T, dO^T never exist in memory.
 // Per step and wave: 32 MFMAs (dK/dV), 24 + 8 (dQ + its log-sum-exp pass), 16 KB of LDS reads.
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef WIW_DKV_OCC   // waves per SIMD the register allocator is held to (A/B knob of the build: -DWIW_DKV_OCC= to lift)
-#define WIW_DKV_OCC
+// Waves per SIMD the register allocator is held to (A/B knobs of the build: -DWIW_DKV_OCC= / -DWIW_DQ_OCC= lift them).  Both
+// kernels are bound by VALU issue beside their MFMAs (exp2, the dS products, packing), so a third / fourth resident wave
+// per SIMD is what fills the matrix pipe: dK/dV 164 VGPRs, dQ 124, no spills (profiles/r04b_attn_bwd_ab.txt).
+#ifndef WIW_DKV_OCC
+#define WIW_DKV_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 #ifndef WIW_DQ_OCC
 #define WIW_DQ_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 constexpr int ATB_ROW = 72;    // elements per LDS row of a [32 rows][64 d] tile (144 B: 16-byte reads of 16 rows spread over the banks)
-constexpr int ATB_TROW = 40;   // elements per LDS row of a [64 d][32 rows] transposed tile (80 B)
 
-__device__ __forceinline__ bf16x8 atb_tr_frag(const uint16_t* base) {     // rows 4 fq .. +3 and 16 + 4 fq .. +3 of one d
-    const uint2 lo = *(const uint2*)base, hi = *(const uint2*)(base + 16);
-    union { uint32_t u[4]; bf16x8 v; } x;
-    x.u[0] = lo.x; x.u[1] = lo.y; x.u[2] = hi.x; x.u[3] = hi.y;
+// Transposed MFMA operand straight from a ROW-MAJOR [32 rows][64 d] LDS tile with ds_read_b64_tr_b16: every lane hands in
+// the address of 4 contiguous elements, the 16 lanes of a group together one [4 rows][16 d] block (lane i: row i / 4,
+// columns 4 (i % 4) ..), and lane i gets column i of the block (tools/ubench/tr_read.hip).  Two reads: rows 4 fq .. + 3
+// and 16 + 4 fq .. + 3 of column d = 16 db + fr — the k permutation of the packed score operand.  No transposed copies
+// of Q, K, dO in global memory, no second set of tiles.
+typedef short atb_short4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 atb_tr_frag(const uint16_t* tile, int db, int fr, int fq) {
+    const uint16_t* p = tile + (4 * fq + (fr >> 2)) * ATB_ROW + db * 16 + (fr & 3) * 4;
+    union { atb_short4 h[2]; bf16x8 v; } x;
+    x.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) atb_short4*)p);
+    x.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) atb_short4*)(p + 16 * ATB_ROW));
     return x.v;
 }
 
 template <int D>
 __global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
-                                                                  const uint16_t* __restrict__ Qt, const uint16_t* __restrict__ dOt,
-                                                                  int64_t ldt, const uint16_t* __restrict__ dO, int ldo,
+                                                                  const uint16_t* __restrict__ dO, int ldo,
                                                                   uint16_t* __restrict__ dQKV, int ldd, const float* __restrict__ LSE,
                                                                   const float* __restrict__ Dsum, int S, int heads, int k_blocks,
                                                                   float scale, float scale_log2e) {
     static_assert(D == 64, "head_dim 64");
     __shared__ __attribute__((aligned(16))) uint16_t Qs[32 * ATB_ROW];
     __shared__ __attribute__((aligned(16))) uint16_t dOs[32 * ATB_ROW];
-    __shared__ __attribute__((aligned(16))) uint16_t Qts[64 * ATB_TROW];
-    __shared__ __attribute__((aligned(16))) uint16_t dOts[64 * ATB_TROW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -763,12 +770,9 @@ __global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(con
         for (int db = 0; db < 4; ++db) { dk[kt][db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][db] = dk[kt][db]; }
     }
     const int lr = tid >> 3, lc = (tid & 7) * 8;       // loader: [32][64] tiles, 16 bytes per thread
-    const int tr = tid >> 2, tc = (tid & 3) * 8;       //         [64][32] transposed tiles
     const uint16_t* gq = QKV + (row0 + lr) * ld + h * D + lc;
     const uint16_t* gdo = dO + (row0 + lr) * ldo + h * D + lc;
-    const uint16_t* gqt = Qt + (int64_t)(h * D + tr) * ldt + row0 + tc;
-    const uint16_t* gdot = dOt + (int64_t)(h * D + tr) * ldt + row0 + tc;
-    uint4 r0 = *(const uint4*)gq, r1 = *(const uint4*)gdo, r2 = *(const uint4*)gqt, r3 = *(const uint4*)gdot;
+    uint4 r0 = *(const uint4*)gq, r1 = *(const uint4*)gdo;
     const float* lse_p = LSE + (seq * heads + h) * S;
     const float* dsum_p = Dsum + (seq * heads + h) * S;
     const int nq = S / 32;
@@ -776,14 +780,10 @@ __global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(con
         __syncthreads();                               // every wave is done with the previous tile
         *(uint4*)(Qs + lr * ATB_ROW + lc) = r0;
         *(uint4*)(dOs + lr * ATB_ROW + lc) = r1;
-        *(uint4*)(Qts + tr * ATB_TROW + tc) = r2;
-        *(uint4*)(dOts + tr * ATB_TROW + tc) = r3;
         __syncthreads();
         if (qt + 1 < nq) {                             // next tile: in flight behind this tile's MFMAs
             r0 = *(const uint4*)(gq + (int64_t)(qt + 1) * 32 * ld);
             r1 = *(const uint4*)(gdo + (int64_t)(qt + 1) * 32 * ldo);
-            r2 = *(const uint4*)(gqt + (qt + 1) * 32);
-            r3 = *(const uint4*)(gdot + (qt + 1) * 32);
         }
         if (!active) continue;
         union { uint32_t u[4]; bf16x8 v; } po[2], dso[2];
@@ -818,8 +818,8 @@ __global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(con
         }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            const bf16x8 x1 = atb_tr_frag(dOts + (db * 16 + fr) * ATB_TROW + fq * 4);
-            const bf16x8 x2 = atb_tr_frag(Qts + (db * 16 + fr) * ATB_TROW + fq * 4);
+            const bf16x8 x1 = atb_tr_frag(dOs, db, fr, fq);      // dO^T[d = 16 db + fr][queries 4 fq .., 16 + 4 fq ..]
+            const bf16x8 x2 = atb_tr_frag(Qs, db, fr, fq);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 dv[kt][db] = WIW_MFMA(x1, po[kt].v, dv[kt][db]);     // dV^T[d][key] += dO^T[d][q] P[q][key], 32 queries deep
@@ -845,7 +845,6 @@ __global__ __launch_bounds__(256) WIW_DKV_OCC void attn_bwd_dkv_tiled_kernel(con
 
 template <int D>
 __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const uint16_t* __restrict__ QKV, int ld, int k_off, int v_off,
-                                                                 const uint16_t* __restrict__ Kt, int64_t ldt,
                                                                  const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, int ldo,
                                                                  uint16_t* __restrict__ dQKV, int ldd, float* __restrict__ LSE,
                                                                  float* __restrict__ Dsum, int S, int heads, int q_blocks, float scale,
@@ -853,7 +852,6 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
     static_assert(D == 64, "head_dim 64");
     __shared__ __attribute__((aligned(16))) uint16_t Ks[32 * ATB_ROW];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[32 * ATB_ROW];
-    __shared__ __attribute__((aligned(16))) uint16_t Kts[64 * ATB_TROW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -885,14 +883,12 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
         dsum[qt] = xor32_sum(xor16_sum(acc));          // D of query fr of tile qt (same summation order as the simple form)
     }
     const int lr = tid >> 3, lc = (tid & 7) * 8;
-    const int tr = tid >> 2, tc = (tid & 3) * 8;
     const uint16_t* gk = QKV + (row0 + lr) * ld + k_off + h * D + lc;
     const uint16_t* gv = QKV + (row0 + lr) * ld + v_off + h * D + lc;
-    const uint16_t* gkt = Kt + (int64_t)(h * D + tr) * ldt + row0 + tc;
     const int nk = S / 32;
     // ---- pass 1: row log-sum-exp (log2 domain) over all keys
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    uint4 r0 = *(const uint4*)gk, r1, r2;
+    uint4 r0 = *(const uint4*)gk, r1;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
         *(uint4*)(Ks + lr * ATB_ROW + lc) = r0;
@@ -946,17 +942,15 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int db = 0; db < 4; ++db) dq[qt][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    r0 = *(const uint4*)gk; r1 = *(const uint4*)gv; r2 = *(const uint4*)gkt;
+    r0 = *(const uint4*)gk; r1 = *(const uint4*)gv;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
         *(uint4*)(Ks + lr * ATB_ROW + lc) = r0;
         *(uint4*)(Vs + lr * ATB_ROW + lc) = r1;
-        *(uint4*)(Kts + tr * ATB_TROW + tc) = r2;
         __syncthreads();
         if (kt + 1 < nk) {
             r0 = *(const uint4*)(gk + (int64_t)(kt + 1) * 32 * ld);
             r1 = *(const uint4*)(gv + (int64_t)(kt + 1) * 32 * ld);
-            r2 = *(const uint4*)(gkt + (kt + 1) * 32);
         }
         if (!active) continue;
         union { uint32_t u[4]; bf16x8 v; } dso[2];
@@ -985,7 +979,7 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
         }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            const bf16x8 x = atb_tr_frag(Kts + (db * 16 + fr) * ATB_TROW + fq * 4);
+            const bf16x8 x = atb_tr_frag(Ks, db, fr, fq);        // K^T[d = 16 db + fr][keys 4 fq .., 16 + 4 fq ..]
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) dq[qt][db] = WIW_MFMA(x, dso[qt].v, dq[qt][db]);   // lane: query fr, d = 16 db + 4 fq + r
         }
@@ -1148,26 +1142,26 @@ namespace {
 extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
                                  const void* dOt, int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd,
                                  float* lse, float* dsum, int seqs, int S, int Sp, int heads, int head_dim, float scale) {
-    WIW_REQUIRE(QKV && Qt && Kt && dOt && O && dO && dQKV && lse && dsum, "attn_bwd: null pointer");
+    const bool tiled = S == Sp && S % 32 == 0 && S >= 128;   // the LDS-tiled kernels read Q, K, dO row-major only
+    WIW_REQUIRE(QKV && O && dO && dQKV && lse && dsum && (tiled || (Qt && Kt && dOt)), "attn_bwd: null pointer");
     WIW_REQUIRE(seqs > 0 && S > 0 && heads > 0 && Sp >= S && Sp % 16 == 0, "attn_bwd: bad sizes (Sp % 16 == 0)");
     WIW_REQUIRE(head_dim == 64, "attn_bwd: head_dim 64 only");
-    WIW_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldt % 4 == 0 && ldo % 8 == 0 && ldd % 4 == 0,
+    WIW_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && (tiled || ldt % 4 == 0) && ldo % 8 == 0 && ldd % 4 == 0,
                 "attn_bwd: misaligned strides");
     const int tiles = Sp / 16;
     const int64_t total = (int64_t)seqs * heads * tiles;
     WIW_REQUIRE(total < (1ll << 32), "attn_bwd: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const float LOG2E_ = 1.4426950408889634f;
-    if (S == Sp && S % 32 == 0 && S >= 128) {          // long (spatial) sequences: the LDS-tiled kernels, 128 rows per workgroup
+    if (tiled) {                                       // long (spatial) sequences: the LDS-tiled kernels, 128 rows per workgroup
         const int blocks128 = (S + 127) / 128;
         const int64_t grid = (int64_t)seqs * heads * blocks128;
-        WIW_REQUIRE(ld % 8 == 0 && ldt % 8 == 0 && ldd % 4 == 0, "attn_bwd: misaligned strides (tiled form)");
         hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
-                           v_off, (const uint16_t*)Kt, ldt, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
-                           dsum, S, heads, blocks128, scale, scale * LOG2E_);
+                           v_off, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum, S, heads, blocks128,
+                           scale, scale * LOG2E_);
         hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
-                           v_off, (const uint16_t*)Qt, (const uint16_t*)dOt, ldt, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
-                           dsum, S, heads, blocks128, scale, scale * LOG2E_);
+                           v_off, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum, S, heads, blocks128, scale,
+                           scale * LOG2E_);
         return wiw_check_launch("wiw_attn_bwd_bf16");
     }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,

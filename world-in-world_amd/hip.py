@@ -454,10 +454,12 @@ class Hip:
         Cn, M = heads * 64, seqs * Sp
         assert Sp % 16 == 0 and qkv.shape == (M, 3 * Cn) and O.shape == (M, Cn) and dO.shape == (M, Cn)
         dt, dev = self.dtype, self.device
-        Qt, Kt, dOt = (torch.empty(Cn, M, dtype=dt, device=dev) for _ in range(3))
-        self.transpose(qkv, 3 * Cn, 0, M, Cn, Qt, M)
-        self.transpose(qkv, 3 * Cn, Cn, M, Cn, Kt, M)
-        self.transpose(dO, Cn, 0, M, Cn, dOt, M)
+        Qt = Kt = dOt = None
+        if not (Sp == S and S % 32 == 0 and S >= 128):      # the one-wave-per-tile form reads transposed copies; the LDS-tiled
+            Qt, Kt, dOt = (torch.empty(Cn, M, dtype=dt, device=dev) for _ in range(3))   # kernels transpose in their LDS reads
+            self.transpose(qkv, 3 * Cn, 0, M, Cn, Qt, M)
+            self.transpose(qkv, 3 * Cn, Cn, M, Cn, Kt, M)
+            self.transpose(dO, Cn, 0, M, Cn, dOt, M)
         dqkv = torch.empty(M, 3 * Cn, dtype=dt, device=dev)
         lse = torch.empty(seqs * heads * Sp, dtype=torch.float32, device=dev)
         dsum = torch.empty_like(lse)
