@@ -353,6 +353,13 @@ int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_of
  *                       conv as a stride-1 conv), 2 sum-pool 2x2 (gradient of the upsample), 3 (b,t,s) -> (b,s,t padded to Tp)
  *                       and 4 back (temporal attention as per-site sequences). */
 int wiw_gather_taps_bf16(void* stream, const void* X, int64_t M, int C, int H, int Wd, int T, int temporal, int stride, void* Xcol);
+/*   wiw_wgrad_tn_bf16   weight gradient from ROW-MAJOR operands: slabs[s][n][k] = sum over the rows of split s of dY[m][n] X[m][k]
+ *                       (fp32 [splits][N][K]; rows split in whole 32-row steps, ceil(M / splits) rounded up to 32; the caller
+ *                       sums the slabs in order, e.g. wiw_colsum(slabs, is_f32, rows = splits, C = N*K, parts = 1)).  Both
+ *                       MFMA operands are read transposed from LDS (ds_read_b64_tr_b16): no dY^T / X^T copies.  N, K, ldy,
+ *                       ldx % 8 == 0; rows >= M and columns >= N / K contribute zeros. */
+int wiw_wgrad_tn_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K, int splits,
+                      float* slabs);
 /*   wiw_gather_taps_t_bf16  the same im2col rows written TRANSPOSED, XcolT [taps*C][Mp] (zero columns for M <= m < Mp, Mp % 8
  *                       == 0): directly the K-contiguous operand of the weight-gradient GEMM, without the [M][taps*C]
  *                       intermediate and its transpose. */

@@ -543,10 +543,40 @@ def test_full_width_training_step_runs(golden):
 
 
 @pytest.mark.gpu
-def test_weight_gradient_gemm_plans_model_and_measured():
-    """dW = dy^T x through `train.wgrad_gemm`: the schedule model's plan and the MEASURED plan (every orientation / split-K
-    candidate timed once, the fastest kept) both equal the fp32 product of the same 16-bit operands; a measured plan is
-    cached per shape and survives `wgrad_plans` / `load_wgrad_plans` (what `Trainer.save` / `load` carry)."""
+@pytest.mark.parametrize("M,N,K,splits,pad", [(4032, 320, 640, 4, 0), (2016, 64, 2880, 7, 0), (14, 1280, 320, 1, 48), (8064, 1280, 1280, 3, 0),
+                                              (1000, 72, 136, 5, 24), (64, 256, 192, 2, 0)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_weight_gradient_from_row_major_operands(M, N, K, splits, pad, dtype):
+    """wiw_wgrad_tn_bf16: dW = dY^T X with both operands ROW-MAJOR (transposed LDS reads, no dY^T / X^T copies) against the
+    fp32 product of the same 16-bit operands: ragged tiles (N = 72, 320 = 256 + 64; K = 136, 640 = 5 x 128), row counts that
+    are not multiples of 32 (14, 1000, 2016 = 63 x 32), padded leading dimensions, extra rows beyond M that must NOT be
+    read into the sum, 1-7 row splits; transpose-detecting (N != K); bit-identical run to run."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.hip import Hip
+
+    hip = Hip(torch.device(DEV), dtype)
+    dy_full = _rnd(M + 3, N + pad, seed=M + N).to(dtype).to(DEV)      # 3 poison rows beyond M, `pad` poison columns
+    x_full = _rnd(M + 3, K + pad, seed=M + K + 1).to(dtype).to(DEV)
+    dy_full[M:] = 1e4
+    x_full[M:] = 1e4
+    dy, x = dy_full[:, :N], x_full[:, :K]
+    ref = dy[:M].float().t() @ x[:M].float()
+    got = hip.wgrad_tn(dy, x, M, N, K, splits)
+    assert tuple(got.shape) == (N, K)
+    mx = float((got - ref).abs().max() / ref.abs().max())
+    assert mx <= 2e-5, mx
+    assert torch.equal(got, hip.wgrad_tn(dy, x, M, N, K, splits))
+
+
+@pytest.mark.gpu
+def test_weight_gradient_plans_default_and_measured():
+    """dW = dy^T x through `train.wgrad`: the default plan and the MEASURED plan (every candidate — the row-major kernel over
+    its row splits, `wiw_gemm_bf16` on transposed operands over orientation and split-K — timed once end to end, the fastest
+    kept) both equal the fp32 product of the same 16-bit operands, for a linear layer and for a convolution's im2col
+    operand; a measured plan is cached per shape and survives `wgrad_plans` / `load_wgrad_plans` (what `Trainer.save` /
+    `load` carry)."""
+    import torch.nn.functional as F
+
     import wiw_amd  # noqa: F401
     from wiw_amd import train as T
     from wiw_amd.hip import Hip
@@ -554,28 +584,42 @@ def test_weight_gradient_gemm_plans_model_and_measured():
     hip = Hip(torch.device(DEV))
     T.clear_wgrad_plans()
     try:
-        for n_out, k_in, rows in ((320, 640, 4032), (64, 2880, 2304), (1280, 320, 8064)):
-            dyT = _rnd(n_out, rows, seed=n_out).to(torch.bfloat16)
-            xT = _rnd(k_in, rows, seed=k_in + 1).to(torch.bfloat16)
-            ref = dyT.float() @ xT.float().t()
+        for n_out, k_in, rows, conv in ((320, 640, 4032, None), (64, 9 * 64, 2 * 24 * 32, (64, 24, 32, 1, False, 1)), (1280, 320, 8064, None)):
+            dy = _rnd(rows, n_out, seed=n_out).to(torch.bfloat16)
+            if conv is None:
+                x = _rnd(rows, k_in, seed=k_in + 1).to(torch.bfloat16)
+                ref = dy.float().t() @ x.float()
+            else:                                      # 3x3 pad 1 im2col of a (2, 64, 24, 32) activation, [tap][cin] columns
+                cin, h, w = conv[0], conv[1], conv[2]
+                x = _rnd(rows, cin, seed=5).to(torch.bfloat16)
+                img = x.float().reshape(2, h, w, cin).permute(0, 3, 1, 2)
+                cols = F.unfold(img, 3, padding=1).reshape(2, cin, 9, h * w).permute(0, 3, 2, 1).reshape(rows, 9 * cin)
+                ref = dy.float().t() @ cols
+            key = f"{n_out},{k_in},{rows}" + (",c" if conv else "")
             T.set_wgrad_tuning(False)
-            got = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            got = T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv)
             assert tuple(got.shape) == (n_out, k_in) and _rel(got, ref)[0] <= 2e-5
-            assert T.wgrad_plans()[f"{n_out},{k_in},{rows}"] == T.wgrad_plan(n_out, k_in, rows)
+            assert T.wgrad_plans()[key] == T.wgrad_default_plan(n_out, k_in, rows, conv is not None)
             T.clear_wgrad_plans()
             T.set_wgrad_tuning(True)
-            got = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            got = T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv)
             assert _rel(got, ref)[0] <= 2e-5
-            plan = T.wgrad_plans()[f"{n_out},{k_in},{rows}"]
-            again = T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows)
+            plan = T.wgrad_plans()[key]
+            again = T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv)
             assert torch.equal(got, again)                                # the plan is fixed once chosen: same summation order
             saved = {k: list(v) for k, v in T.wgrad_plans().items()}
             T.clear_wgrad_plans(); T.set_wgrad_tuning(False)
             T.load_wgrad_plans(saved)
-            assert T.wgrad_plans()[f"{n_out},{k_in},{rows}"] == plan
-            assert torch.equal(got, T.wgrad_gemm(hip, dyT.to(DEV), xT.to(DEV), n_out, k_in, rows))
-            print(f"[f2] wgrad {n_out}x{k_in} over {rows} rows: model plan {T.wgrad_plan(n_out, k_in, rows)}, measured {plan}")
+            assert T.wgrad_plans()[key] == plan
+            assert torch.equal(got, T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv))
+            print(f"[f2] wgrad {n_out}x{k_in} over {rows} rows{' (conv)' if conv else ''}: default plan "
+                  f"{T.wgrad_default_plan(n_out, k_in, rows, conv is not None)}, measured {plan}")
             T.clear_wgrad_plans()
+            # every mode gives the same gradient up to fp32 summation order
+            for forced in ((0, 1), (1, 3), (2, 1), (2, 5)):
+                T.load_wgrad_plans({key: forced})
+                assert _rel(T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv), ref)[0] <= 2e-5, forced
+                T.clear_wgrad_plans()
     finally:
         T.set_wgrad_tuning(False)
         T.clear_wgrad_plans()

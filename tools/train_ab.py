@@ -34,6 +34,6 @@ for rnd in range(2):
         if tune and rnd == 1:
             flips = sum(1 for v in T.wgrad_plans().values() if v[0])
             print(f"{len(T.wgrad_plans())} shapes, {flips} flipped")
-            model = {k: T.wgrad_plan(*map(int, k.replace(',v', '').split(','))) for k in T.wgrad_plans()}
-            for k, v in sorted(T.wgrad_plans().items(), key=lambda kv: tuple(map(int, kv[0].replace(',v', '').split(',')))):
+            model = {k: T.wgrad_default_plan(*map(int, k.replace(',v', '').replace(',c', '').split(',')), ',c' in k) for k in T.wgrad_plans()}
+            for k, v in sorted(T.wgrad_plans().items(), key=lambda kv: tuple(map(int, kv[0].replace(',v', '').replace(',c', '').split(',')))):
                 print(f"  {k:22s} measured {tuple(v)} model {model[k]}")

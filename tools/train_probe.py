@@ -133,6 +133,23 @@ def wgrad_sweep():
                 except Exception as e:  # noqa: BLE001
                     res.append((1e9, flip, s))
         res.sort()
+        # the row-major ("TN") kernel: no transposes; the NT numbers above exclude the two transposes it saves
+        dy = dyT.t().contiguous(); x = xT.t().contiguous()
+        ref = (dyT.float() @ xT.float().t())
+        tn = []
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384):
+            if M // sp < 128:
+                break
+            t = timeit(lambda: hip.wgrad_tn(dy, x, M, N, K, sp), 3)
+            tn.append((t, sp))
+        tn.sort()
+        err = float((hip.wgrad_tn(dy, x, M, N, K, tn[0][1]) - ref).abs().max() / ref.abs().max())
+        def tr2():
+            a_ = torch.empty(N, M, dtype=dy.dtype, device=dev); hip.transpose(dy, N, 0, M, N, a_, M)
+            b_ = torch.empty(K, M, dtype=dy.dtype, device=dev); hip.transpose(x, K, 0, M, K, b_, M)
+        t_tr = timeit(tr2, 3)
+        print(f"      TN best: " + ", ".join(f"s={sp} {t:.3f}" for t, sp in tn[:3]) + f"   (max err vs fp32 {err:.1e}); the two transposes NT needs: {t_tr:.3f} ms")
+        del dy, x, ref
         tf = 2.0 * N * K * M / 1e9
         print(f"  {name:14s} N={N:5d} K={K:5d} M={M:6d}: plan {'T' if f0 else 'N'}/s={s0:3d} {base:7.3f} ms ({tf/base:6.0f} TF/s) | best "
               + ", ".join(f"{'T' if f else 'N'}/s={s} {t:.3f}" for t, f, s in res[:4]))

@@ -999,6 +999,93 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient straight from ROW-MAJOR operands ("TN" GEMM):  dW[n][k] = sum_m dY[m][n] X[m][k]  (fp32), the contraction
+// over the M rows of the layer.  wiw_gemm_bf16 wants both operands K-contiguous, i.e. dY^T and X^T made by two transposes
+// per layer; here a workgroup stages [32 rows][256 n] of dY and [32 rows][128 k] of X row-major in LDS (64-column panels
+// at the attention kernels' 144-byte row stride) and BOTH MFMA operands are read transposed with ds_read_b64_tr_b16
+// (atb_tr_frag; the two reads per operand select rows 4 fq .. + 3 and 16 + 4 fq .. + 3 — the same permutation of the 32
+// contracted rows on both sides, so the product is unchanged).  4 waves, wave w owns n = 64 w .. + 63 and all 128 k:
+// 32 accumulator fragments, 24 transposed reads per 32 MFMAs; the next 32 rows' global loads are in flight behind them.
+// The M rows are split over gridDim.y; split s writes its raw sums to slab s of `out` ([splits][N][K] fp32), summed in a
+// fixed order by the caller (wiw_colsum over the slabs).  Rows >= M, columns >= N / K read as zeros.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WTN_BN = 256, WTN_BK = 128, WTN_PANEL = 32 * ATB_ROW;
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const uint16_t* __restrict__ dY, int64_t ldy, const uint16_t* __restrict__ X,
+                                                        int64_t ldx, int64_t M, int N, int K, int64_t rows_per_split,
+                                                        float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[4 * WTN_PANEL];      // dY tile: 4 panels of [32 rows][64 n]
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2 * WTN_PANEL];      // X tile:  2 panels of [32 rows][64 k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kt_n = (K + WTN_BK - 1) / WTN_BK;
+    const int n0 = (int)(blockIdx.x / kt_n) * WTN_BN, k0 = (int)(blockIdx.x % kt_n) * WTN_BK;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = m_begin + rows_per_split < M ? m_begin + rows_per_split : M;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // loader: A 32 rows x 32 chunks of 16 B (4 per thread), B 32 x 16 (2 per thread)
+    const int a_row = tid >> 5, a_ch = tid & 31;          // rows a_row + 8 j
+    const int b_row = tid >> 4, b_ch = tid & 15;          // rows b_row + 16 j
+    const bool a_ok = n0 + a_ch * 8 < N, b_ok = k0 + b_ch * 8 < K;
+    const uint16_t* ga = dY + n0 + a_ch * 8;
+    const uint16_t* gb = X + k0 + b_ch * 8;
+    uint16_t* sa = As + (a_ch >> 3) * WTN_PANEL + a_row * ATB_ROW + (a_ch & 7) * 8;
+    uint16_t* sb = Bs + (b_ch >> 3) * WTN_PANEL + b_row * ATB_ROW + (b_ch & 7) * 8;
+    uint4 ra[4], rb[2];
+    auto fetch = [&](int64_t m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = m + a_row + 8 * j;
+            ra[j] = (a_ok && r < m_end) ? *(const uint4*)(ga + r * ldy) : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t r = m + b_row + 16 * j;
+            rb[j] = (b_ok && r < m_end) ? *(const uint4*)(gb + r * ldx) : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    fetch(m_begin);
+    const uint16_t* a_panel = As + wave * WTN_PANEL;
+    for (int64_t m = m_begin; m < m_end; m += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(uint4*)(sa + 8 * j * ATB_ROW) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *(uint4*)(sb + 16 * j * ATB_ROW) = rb[j];
+        __syncthreads();
+        if (m + 32 < m_end) fetch(m + 32);
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = atb_tr_frag(a_panel, i, fr, fq);          // dY^T[n = 64 wave + 16 i + fr][32 rows]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16x8 bfr = atb_tr_frag(Bs + (j >> 2) * WTN_PANEL, j & 3, fr, fq);   // X[32 rows][k = 16 j + fr]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = WIW_MFMA(af[i], bfr, acc[i][j]);
+        }
+    }
+    // lane: n = n0 + 64 wave + 16 i + 4 fq + r, k = k0 + 16 j + fr
+    float* slab = out + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wave * 64 + i * 16 + fq * 4 + r;
+            if (n < N) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + j * 16 + fr;
+                    if (k < K) slab[(int64_t)n * K + k] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Small glue kernels of the training graph (HBM-bound, 16 bytes per thread)
 // ---------------------------------------------------------------------------------------------------------------------
 // out = a x + b y (y may be NULL)
@@ -1223,6 +1310,21 @@ extern "C" int wiw_groupnorm_bwd(void* stream, const void* X, const void* dY, co
     hipLaunchKernelGGL(gnb_apply_kernel, dim3(splits, units), dim3(256), 0, s, (const uint16_t*)X, (const uint16_t*)dY, stats,
                        AB, gamma, beta, C, rows_per_unit, rows_per_block, eps, silu, (uint16_t*)dX);
     return wiw_check_launch("wiw_groupnorm_bwd");
+}
+
+extern "C" int wiw_wgrad_tn_bf16(void* stream, const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K,
+                                 int splits, float* slabs) {
+    WIW_REQUIRE(dY && X && slabs && M > 0 && N > 0 && K > 0 && splits > 0 && splits <= 65535, "wgrad_tn: bad arguments");
+    WIW_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K, "wgrad_tn: N, K, ldy, ldx % 8");
+    WIW_REQUIRE(((((uintptr_t)dY) | ((uintptr_t)X)) & 15) == 0, "wgrad_tn: operands must be 16-byte aligned");
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;                                  // whole 32-row steps per split
+    WIW_REQUIRE((int64_t)(splits - 1) * rps < M, "wgrad_tn: more splits than 32-row steps");
+    const int64_t tiles = (int64_t)((N + WTN_BN - 1) / WTN_BN) * ((K + WTN_BK - 1) / WTN_BK);
+    WIW_REQUIRE(tiles < (1ll << 31), "wgrad_tn: grid too large");
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dY,
+                       ldy, (const uint16_t*)X, ldx, M, N, K, rps, slabs);
+    return wiw_check_launch("wiw_wgrad_tn_bf16");
 }
 
 extern "C" int wiw_colsum(void* stream, const void* X, int is_f32, int64_t rows, int C, int parts, float* out) {

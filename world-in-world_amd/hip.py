@@ -121,6 +121,8 @@ EXPORTS = {
                                     C.c_void_p, C.c_int]),
     "wiw_gather_taps_t_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p]),
+    "wiw_wgrad_tn_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p]),
     "wiw_colsum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "wiw_layernorm_bwd_partials": (C.c_int64, [C.c_int64]),
     "wiw_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p,
@@ -475,6 +477,21 @@ class Hip:
         self._ck(self.lib.wiw_gather_taps_bf16(self._stream(), _p(X), M, Cn, H, Wd, T, int(temporal), stride, _p(out)),
                  "wiw_gather_taps_bf16")
         return out
+
+    def wgrad_tn(self, dY, X, M, N, K, splits):
+        """fp32 dW [N, K] = dY[:M]^T . X[:M] from ROW-MAJOR 16-bit operands (dY [>= M, N], X [>= M, K]); the M rows are split
+        into `splits` ranges whose slabs are summed in order."""
+        splits = max(1, min(int(splits), -(-M // 32)))
+        while splits > 1 and (splits - 1) * (-(-(-(-M // splits)) // 32) * 32) >= M:   # every split owns at least one 32-row step
+            splits -= 1
+        slabs = torch.empty(splits, N * K, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_wgrad_tn_bf16(self._stream(), _p(dY), dY.stride(0), _p(X), X.stride(0), M, N, K, splits, _p(slabs)),
+                 "wiw_wgrad_tn_bf16")
+        if splits == 1:
+            return slabs.reshape(N, K)
+        out = torch.empty(1, N * K, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.wiw_colsum(self._stream(), _p(slabs), 1, splits, N * K, 1, _p(out)), "wiw_colsum")
+        return out.reshape(N, K)
 
     def gather_taps_t(self, X, M, Cn, H, Wd, T=1, temporal=False, stride=1):
         """The im2col rows of `gather_taps`, TRANSPOSED: [taps*Cn, Mp] with Mp = M rounded up to 64 (zero columns) — the

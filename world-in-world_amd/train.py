@@ -123,7 +123,8 @@ def wgrad_plan(n_out: int, k_in: int, k_rows: int, n_cu: int = 256):
     return best[1], best[2]
 
 
-# Measured plans (key "n_out,k_in,k_rows" -> [flip, splitk]).  The weight-gradient GEMMs stream BOTH operands over a K loop of
+# Measured plans (key "n_out,k_in,rows[,c][,v]" -> [mode, splits]; mode 0 / 1 = `wiw_gemm_bf16` on transposed operands, dW /
+# dW^T; mode 2 = `wiw_wgrad_tn_bf16` on the row-major operands).  The weight-gradient GEMMs stream BOTH operands over a K loop of
 # up to 129 024 rows, so their speed is decided by how the concurrently running items share operand panels in the per-XCD L2s
 # — which the schedule model of `wgrad_plan` does not see (it is 1.0-1.7x off on the convolutions).  With tuning on
 # (`set_wgrad_tuning(True)`, `Trainer(autotune=True)`, `bench.py --train`), the first call of a shape times every candidate
@@ -164,42 +165,106 @@ def _wgrad_run(hip: Hip, dyT, xT, n_out, k_in, k_rows, flip, sk, view_ok=False):
     return out
 
 
-def _wgrad_tune(hip: Hip, dyT, xT, n_out, k_in, k_rows, view_ok):
-    nk = k_rows // 64
-    cands = [(f, sk) for f in (0, 1) for sk in range(1, 129)
-             if nk % sk == 0 and (sk == 1 or nk // sk >= 8) and sk * n_out * k_in * 4 <= (1 << 30)]
-    model = wgrad_plan(n_out, k_in, k_rows)
-    best = None
-    for f, sk in cands:
-        _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk, view_ok)         # warm (workspace allocation, code load)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(2):
-            _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, f, sk, view_ok)
-        b.record()
-        b.synchronize()
-        t = a.elapsed_time(b)
-        if best is None or t < best[0] * (0.97 if (f, sk) != model else 1.0):  # ties go to the model's deterministic choice
-            best = (t, f, sk)
-    return best[1], best[2]
+def wgrad_tn_splits(n_out: int, k_in: int, rows: int, n_cu: int = 256) -> int:
+    """Row splits of the row-major weight-gradient kernel (`wiw_wgrad_tn_bf16`, 256 x 128 output tiles, two workgroups
+    resident per CU): about 480 (tile, split) items — one full set of resident workgroups — with at least 128 rows per split
+    (sweep of the served shapes, profiles/r04d_wgrad_tn_sweep.txt)."""
+    tiles = -(-n_out // 256) * -(-k_in // 128)
+    return int(max(1, min(round(1.875 * n_cu / tiles), rows // 128, 512)))
+
+
+def wgrad_default_plan(n_out: int, k_in: int, rows: int, conv: bool):
+    """(mode, splits) without measuring.  mode 2 = `wiw_wgrad_tn_bf16` on the row-major operands (no transposes): ahead on
+    every linear layer of the served architecture once the two transposes the other modes need are counted; mode 0 / 1 =
+    `wiw_gemm_bf16` on transposed operands (dW / dW^T, `wgrad_plan`): still ahead on the long-K convolutions, whose
+    operand arrives transposed from `wiw_gather_taps_t_bf16` anyway."""
+    if not conv:
+        return 2, wgrad_tn_splits(n_out, k_in, rows)
+    return wgrad_plan(n_out, k_in, -(-rows // 64) * 64)
+
+
+def _wgrad_operands_nt(hip: Hip, dy, x, M, N, K, conv):
+    """K-contiguous operands of the `wiw_gemm_bf16` modes: dy^T and x^T (or the transposed im2col rows), rows zero-padded to 64."""
+    Mp = -(-M // 64) * 64
+    alloc = torch.empty if Mp == M else torch.zeros
+    dyT = alloc(N, Mp, dtype=hip.dtype, device=hip.device)
+    hip.transpose(dy, dy.stride(0), 0, M, N, dyT, Mp)
+    if conv is None:
+        xT = alloc(K, Mp, dtype=hip.dtype, device=hip.device)
+        hip.transpose(x, x.stride(0), 0, M, K, xT, Mp)
+    else:
+        xT = hip.gather_taps_t(x, M, *conv)                          # [taps * Cin, Mp], one pass over x
+    return dyT, xT, Mp
+
+
+def _wgrad_exec(hip: Hip, plan, dy, x, M, N, K, conv, view_ok):
+    if plan[0] == 2:
+        xr = x if conv is None else hip.gather_taps(x, M, *conv)      # row-major im2col rows [M, taps * Cin]
+        return hip.wgrad_tn(dy, xr, M, N, K, plan[1])
+    dyT, xT, Mp = _wgrad_operands_nt(hip, dy, x, M, N, K, conv)
+    return _wgrad_run(hip, dyT, xT, N, K, Mp, plan[0], plan[1], view_ok)
+
+
+def _time(fn, reps=2):
+    fn()                                                              # warm (workspace allocation, code load)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def _wgrad_tune(hip: Hip, dy, x, M, N, K, conv, view_ok):
+    """Every candidate once, end to end: the row-major kernel over its row splits; the `wiw_gemm_bf16` modes over orientation
+    and split-K with the time of making their transposed operands added.  Ties go to the default plan."""
+    default = wgrad_default_plan(N, K, M, conv is not None)
+    cands = []
+    xr = x if conv is None else hip.gather_taps(x, M, *conv)
+    t_gather = 0.0 if conv is None else _time(lambda: hip.gather_taps(x, M, *conv))
+    s0 = wgrad_tn_splits(N, K, M)
+    for sp in sorted({1, max(1, s0 // 4), max(1, s0 // 2), max(1, (3 * s0) // 4), s0, (3 * s0) // 2, 2 * s0, 3 * s0}):
+        if sp >= 1 and M // sp >= 64 and sp * N * K * 4 <= (1 << 30):
+            cands.append((_time(lambda: hip.wgrad_tn(dy, xr, M, N, K, sp)) + t_gather, (2, sp)))
+    del xr
+    dyT, xT, Mp = _wgrad_operands_nt(hip, dy, x, M, N, K, conv)
+    t_prep = _time(lambda: _wgrad_operands_nt(hip, dy, x, M, N, K, conv))
+    nk = Mp // 64
+    for f in (0, 1):
+        for sk in range(1, 129):
+            if nk % sk == 0 and (sk == 1 or nk // sk >= 8) and sk * N * K * 4 <= (1 << 30):
+                cands.append((_time(lambda: _wgrad_run(hip, dyT, xT, N, K, Mp, f, sk, view_ok)) + t_prep, (f, sk)))
+    best = min(cands, key=lambda c: c[0] * (1.0 if c[1] == default else 1.03))
+    return best[1]
+
+
+def wgrad(hip: Hip, dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, view_ok: bool = False, conv=None) -> torch.Tensor:
+    """fp32 dW [N, K] = dy[:M]^T . X[:M] with the plan of the shape.  dy [>= M rows, N] row-major; X = x [>= M rows, K], or,
+    conv = (Cin, H, W, T, temporal, stride), the im2col rows of the activation x (K = taps * Cin), built in whichever layout
+    the plan's kernel reads.  view_ok: a flipped `wiw_gemm_bf16` plan may return the transposed view (the caller re-lays
+    the gradient out anyway)."""
+    key = f"{N},{K},{M}" + (",c" if conv is not None else "") + (",v" if view_ok else "")
+    plan = _WGRAD_PLANS.get(key)
+    if plan is None:
+        plan = _wgrad_tune(hip, dy, x, M, N, K, conv, view_ok) if _WGRAD_TUNE else wgrad_default_plan(N, K, M, conv is not None)
+        _WGRAD_PLANS[key] = plan
+    return _wgrad_exec(hip, plan, dy, x, M, N, K, conv, view_ok)
 
 
 def wgrad_gemm(hip: Hip, dyT: torch.Tensor, xT: torch.Tensor, n_out: int, k_in: int, k_rows: int, view_ok: bool = False) -> torch.Tensor:
-    """fp32 dW [n_out, k_in] = dyT [n_out, k_rows] . xT [k_in, k_rows]^T in the orientation / split of the shape's plan
-    (contiguous — a flipped plan pays for the copy back — unless view_ok: then a flipped plan returns the transposed view)."""
-    key = f"{n_out},{k_in},{k_rows}" + (",v" if view_ok else "")
-    plan = _WGRAD_PLANS.get(key)
-    if plan is None:
-        plan = _wgrad_tune(hip, dyT, xT, n_out, k_in, k_rows, view_ok) if _WGRAD_TUNE else wgrad_plan(n_out, k_in, k_rows)
-        _WGRAD_PLANS[key] = plan
-    return _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, plan[0], plan[1], view_ok)
+    """The `wiw_gemm_bf16` form alone, on operands that are ALREADY K-contiguous (dyT [n_out, k_rows], xT [k_in, k_rows]):
+    orientation / split-K from the schedule model."""
+    flip, sk = wgrad_plan(n_out, k_in, k_rows)
+    return _wgrad_run(hip, dyT, xT, n_out, k_in, k_rows, flip, sk, view_ok)
 
 
 def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, need_db: bool = True,
                     need_dw: bool = True):
     """Backward of y = x . W^T (+ b) with x [M, K], W [N, K], dy [M, N] in the Hip's 16-bit type (M, N, K % 64 == 0):
          dx [M, K] (16-bit)  = dy . W              -> wiw_gemm_bf16(A = dy, W = W^T)
-         dW [N, K] (fp32)    = dy^T . x            -> wiw_gemm_bf16(A = dy^T, W = x^T, fp32 output): K loop over the M rows
+         dW [N, K] (fp32)    = dy^T . x            -> `wgrad`: wiw_wgrad_tn_bf16 on the row-major operands (or wiw_gemm_bf16 on
+                                                      transposed ones), contraction over the M rows
          db [N]   (fp32)     = column sums of dy   -> wiw_colsum
        (`nn.Linear` backward, attention_processor.py:2358-2391 / attention.py:1185-1243 call sites).  The transposes are
        wiw_transpose_bf16 passes; fp32 accumulation over all M rows inside the MFMA K loop."""
@@ -209,7 +274,6 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
     N = W.shape[0]
     assert W.shape == (N, K) and dy.shape == (M, N) and M % 8 == 0 and N % 64 == 0 and K % 64 == 0
     dev, dt = hip.device, hip.dtype
-    Mp = -(-M // 64) * 64              # the weight-gradient GEMM contracts over the rows: zero columns pad M to its K tile
     dx = None
     if need_dx:
         Wt = torch.empty(K, N, dtype=dt, device=dev)
@@ -217,13 +281,8 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
         dx = torch.empty(M, K, dtype=dt, device=dev)
         hip.gemm(dy, Wt, dx, M=M, N=K, K=N, C1=N)
     dW = None
-    if need_dw:                        # frozen weights (`--train_param_type new`): no transposes, no weight-gradient GEMM
-        alloc = torch.empty if Mp == M else torch.zeros
-        dyT = alloc(N, Mp, dtype=dt, device=dev)
-        hip.transpose(dy, N, 0, M, N, dyT, Mp)
-        xT = alloc(K, Mp, dtype=dt, device=dev)
-        hip.transpose(x, K, 0, M, K, xT, Mp)
-        dW = wgrad_gemm(hip, dyT, xT, N, K, Mp)
+    if need_dw:                        # frozen weights (`--train_param_type new`): no weight-gradient GEMM
+        dW = wgrad(hip, dy, x, M, N, K)
     db = hip.colsum(dy, M, N) if need_db else None
     return dx, dW, db
 
@@ -234,7 +293,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     or, temporal=True, (3,1,1) pad 1 over T (TemporalResnetBlock, resnet.py:570-592).  x [M, Cin] token-major, Wk [Cout, taps*Cin]
     in the kernel's layout ([Cout][ky][kx][Cin] / [Cout][kt][Cin]), dy [M, Cout]; Cin, Cout, M % 64 == 0.
         dx  = the SAME convolution of dy with the taps mirrored and the channel roles swapped (W2[ci][tap'][co] = W[co][tap][ci])
-        dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: wiw_gather_taps_t_bf16 = transposed im2col rows in one pass, dy^T, one GEMM over the M rows)
+        dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: `wgrad` with the im2col operand built in the layout its plan reads)
         db  = column sums of dy
     (the stride-2 / upsampling variants are not covered yet)."""
     from .hip import A_CONV3X3, A_CONV_T3, EPI_OUT_F32
@@ -244,8 +303,6 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
     taps = 3 if temporal else 9
     assert Wk.shape == (Cout, taps * Cin) and dy.shape == (M, Cout) and M % 8 == 0 and Cin % 64 == 0 and Cout % 64 == 0
     dev, dt = hip.device, hip.dtype
-    Mp = -(-M // 64) * 64
-    alloc = torch.empty if Mp == M else torch.zeros
     dx = None
     if need_dx:
         W2 = Wk.reshape(Cout, taps, Cin).flip(1).permute(2, 1, 0).reshape(Cin, taps * Cout).contiguous()   # host re-layout
@@ -253,10 +310,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
         hip.gemm(dy, W2, dx, M=M, N=Cin, K=taps * Cout, C1=Cout, mode=A_CONV_T3 if temporal else A_CONV3X3, H=H, Wd=Wd, T=T)
     if not need_dw:
         return dx, None, None
-    xcolT = hip.gather_taps_t(x, M, Cin, H, Wd, T, temporal)              # [taps * Cin, Mp], one pass over x
-    dyT = alloc(Cout, Mp, dtype=dt, device=dev)
-    hip.transpose(dy, Cout, 0, M, Cout, dyT, Mp)
-    dW = wgrad_gemm(hip, dyT, xcolT, Cout, taps * Cin, Mp, view_ok=True)   # [Cout, taps * Cin], possibly a transposed view
+    dW = wgrad(hip, dy, x, M, Cout, taps * Cin, view_ok=True, conv=(Cin, H, Wd, T, temporal, 1))   # possibly a transposed view
     return dx, dW, hip.colsum(dy, M, Cout)
 
 

@@ -193,13 +193,8 @@ class UNetTrain:
                 dx = torch.empty(4 * M_out, Cin, dtype=self.dt, device=self.device)
                 hip.gemm(dil, W2, dx, M=4 * M_out, N=Cin, K=9 * Wp.shape[0], C1=Wp.shape[0], mode=A_CONV3X3, H=2 * H, Wd=2 * W)
                 if need_dw:
-                    Mp = -(-M_out // 64) * 64
-                    alloc = torch.empty if Mp == M_out else torch.zeros
-                    xcolT = hip.gather_taps_t(x, M_out, Cin, H, W, stride=2)
-                    dyT = alloc(dyp.shape[1], Mp, dtype=self.dt, device=self.device)
-                    hip.transpose(dyp, dyp.shape[1], 0, M_out, dyp.shape[1], dyT, Mp)
-                    from .train import wgrad_gemm
-                    dW = wgrad_gemm(hip, dyT, xcolT, dyp.shape[1], 9 * Cin, Mp, view_ok=True)
+                    from .train import wgrad
+                    dW = wgrad(hip, dyp, x, M_out, dyp.shape[1], 9 * Cin, view_ok=True, conv=(Cin, H, W, 1, False, 2))
                     db = hip.colsum(dy, M_out, Cout)
             else:
                 dx, dW, db = conv_backward(hip, x, Wp, dyp, H, W, T=T, temporal=(mode == A_CONV_T3), need_dw=need_dw)
