@@ -92,17 +92,29 @@ class UNetTrain:
     # ------------------------------------------------------------------------------------------
     # 16-bit operand copies in the kernels' layouts (re-made after every optimiser step)
     # ------------------------------------------------------------------------------------------
-    def refresh(self) -> None:
+    def refresh(self, names=None) -> None:
+        """(Re)build the 16-bit GEMM operands from the fp32 masters.  names = None: all of them (construction, checkpoint load,
+        the sharded optimiser's all-gather); otherwise only the given parameter names.  `self._direct[name]` is the operand
+        (or the slice of a fused operand) that is a plain cast of master[name]: `wiw_adamw_step` writes those itself (`p16`),
+        so the single-process step only comes here for the re-laid-out ones (convolutions, padded inputs)."""
         m, dt = self.master, self.dt
-        self.W: Dict[str, torch.Tensor] = {}
+        full = names is None
+        if full:
+            self.W: Dict[str, torch.Tensor] = {}
+            self._direct: Dict[str, torch.Tensor] = {}
         for k, v in m.items():
-            if not k.endswith(".weight") or v.dim() < 2:
+            if not k.endswith(".weight") or v.dim() < 2 or (not full and k not in names):
+                continue
+            if not full and k in self._direct:                            # a plain cast, possibly into a fused operand's slice
+                self._direct[k].copy_(v)
                 continue
             if v.dim() == 2:
                 w = v
                 if w.shape[1] % 64:                                       # add_action_proj.proj: K = 168 -> 192
                     w = torch.cat([w, w.new_zeros(w.shape[0], -w.shape[1] % 64)], dim=1)
                 self.W[k] = w.to(dt).contiguous()
+                if full and v.shape[1] % 64 == 0:
+                    self._direct[k] = self.W[k]
             elif v.dim() == 4:                                            # (O, I, 3, 3) | (O, I, 1, 1) -> [O][ky][kx][I]
                 w = v
                 if w.shape[1] % 64:                                       # conv_in: 8 -> 64 input channels
@@ -110,11 +122,17 @@ class UNetTrain:
                 self.W[k] = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
             else:                                                         # (O, I, 3, 1, 1) -> [O][kt][I]
                 self.W[k] = v[:, :, :, 0, 0].permute(0, 2, 1).reshape(v.shape[0], -1).to(dt).contiguous()
-        # fused q | k | v projections of the self-attentions
+        if not full:
+            return
+        # fused q | k | v projections of the self-attentions: ONE [3C, C] operand, the three reference tensors are its row slices
         for k in list(m):
             if k.endswith(".attn1.to_q.weight"):
                 p = k[: -len("to_q.weight")]
-                self.W[p + "to_qkv.weight"] = torch.cat([m[p + "to_q.weight"], m[p + "to_k.weight"], m[p + "to_v.weight"]]).to(dt).contiguous()
+                fused = torch.cat([m[p + "to_q.weight"], m[p + "to_k.weight"], m[p + "to_v.weight"]]).to(dt).contiguous()
+                self.W[p + "to_qkv.weight"] = fused
+                C = m[k].shape[0]
+                for i, nm in enumerate(("to_q.weight", "to_k.weight", "to_v.weight")):
+                    self.W[p + nm] = self._direct[p + nm] = fused[i * C:(i + 1) * C]
 
     # ------------------------------------------------------------------------------------------
     # operators (forward + tape entry)
@@ -677,12 +695,17 @@ class Trainer:
         self._acc = {}
         self.steps += 1
         if self.opt is None:
+            stale = set()
             for name, g in grads.items():                                  # parameters without a gradient (the dead ones) stay
                 if not self.trainable(name):
                     continue
-                p = net.master[name]
+                p, p16 = net.master[name], net._direct.get(name)            # plain-cast operands are refreshed by the kernel itself
                 hip.adamw_step(p.view(-1), g.reshape(-1).contiguous(), self.m[name].view(-1), self.v[name].view(-1), self.steps,
-                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
+                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd, p16=None if p16 is None else p16.view(-1))
+                if p16 is None:
+                    stale.add(name)
+            net.refresh(stale)                                             # the re-laid-out operands (convolutions, padded inputs)
+            return float(loss)
         else:
             if not overlapped:                                           # first step, or fp16 (un-scaled after the backward)
                 for name, g in grads.items():
