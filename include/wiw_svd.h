@@ -31,11 +31,13 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 6   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 7   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
-                             6: WiwGemmArgs gained lnfold / ln_eps (WIW_EPI_LNFOLD) */
+                             6: WiwGemmArgs gained lnfold / ln_eps (WIW_EPI_LNFOLD);
+                             7: the training entry points settled: wiw_colsum sums CONTIGUOUS row ranges, wiw_attn_bwd_bf16
+                                takes NULL transposes on its LDS-tiled path, wiw_gather_taps_t_bf16, wiw_wgrad_tn_bf16 */
 
 int wiw_abi_version(void);
 
