@@ -616,7 +616,7 @@ def test_weight_gradient_plans_default_and_measured():
                   f"{T.wgrad_default_plan(n_out, k_in, rows, conv is not None)}, measured {plan}")
             T.clear_wgrad_plans()
             # every mode gives the same gradient up to fp32 summation order
-            for forced in ((0, 1), (1, 3), (2, 1), (2, 5)):
+            for forced in ((0, 1), (1, 3), (2, 1), (2, 5), (3, 2)):
                 T.load_wgrad_plans({key: forced})
                 assert _rel(T.wgrad(hip, dy.to(DEV), x.to(DEV), rows, n_out, k_in, conv=conv), ref)[0] <= 2e-5, forced
                 T.clear_wgrad_plans()

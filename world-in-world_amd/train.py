@@ -124,7 +124,7 @@ def wgrad_plan(n_out: int, k_in: int, k_rows: int, n_cu: int = 256):
 
 
 # Measured plans (key "n_out,k_in,rows[,c][,v]" -> [mode, splits]; mode 0 / 1 = `wiw_gemm_bf16` on transposed operands, dW /
-# dW^T; mode 2 = `wiw_wgrad_tn_bf16` on the row-major operands).  The weight-gradient GEMMs stream BOTH operands over a K loop of
+# dW^T; mode 2 = `wiw_wgrad_tn_bf16` on the row-major operands, mode 3 = the same with the operands swapped, dW^T).  The weight-gradient GEMMs stream BOTH operands over a K loop of
 # up to 129 024 rows, so their speed is decided by how the concurrently running items share operand panels in the per-XCD L2s
 # — which the schedule model of `wgrad_plan` does not see (it is 1.0-1.7x off on the convolutions).  With tuning on
 # (`set_wgrad_tuning(True)`, `Trainer(autotune=True)`, `bench.py --train`), the first call of a shape times every candidate
@@ -174,11 +174,16 @@ def wgrad_tn_splits(n_out: int, k_in: int, rows: int, n_cu: int = 256) -> int:
 
 
 def wgrad_default_plan(n_out: int, k_in: int, rows: int, conv: bool):
-    """(mode, splits) without measuring.  mode 2 = `wiw_wgrad_tn_bf16` on the row-major operands (no transposes): ahead on
+    """(mode, splits) without measuring.  mode 2 / 3 = `wiw_wgrad_tn_bf16` on the row-major operands (no transposes): ahead on
     every linear layer of the served architecture once the two transposes the other modes need are counted; mode 0 / 1 =
     `wiw_gemm_bf16` on transposed operands (dW / dW^T, `wgrad_plan`): still ahead on the long-K convolutions, whose
     operand arrives transposed from `wiw_gather_taps_t_bf16` anyway."""
     if not conv:
+        # the kernel's tile is 256 (first operand's columns) x 128: the orientation with the smaller padded output (mode 3
+        # computes dW^T with the operands swapped: a 320-wide dy fills 3 x 128 better than 2 x 256)
+        pad = lambda a, b: -(-a // 256) * 256 * (-(-b // 128) * 128)  # noqa: E731
+        if 1.25 * pad(k_in, n_out) < pad(n_out, k_in):                # (the copy back has to be paid for: measured plans agree)
+            return 3, wgrad_tn_splits(k_in, n_out, rows)
         return 2, wgrad_tn_splits(n_out, k_in, rows)
     return wgrad_plan(n_out, k_in, -(-rows // 64) * 64)
 
@@ -198,9 +203,12 @@ def _wgrad_operands_nt(hip: Hip, dy, x, M, N, K, conv):
 
 
 def _wgrad_exec(hip: Hip, plan, dy, x, M, N, K, conv, view_ok):
-    if plan[0] == 2:
+    if plan[0] >= 2:
         xr = x if conv is None else hip.gather_taps(x, M, *conv)      # row-major im2col rows [M, taps * Cin]
-        return hip.wgrad_tn(dy, xr, M, N, K, plan[1])
+        if plan[0] == 2:
+            return hip.wgrad_tn(dy, xr, M, N, K, plan[1])
+        out = hip.wgrad_tn(xr, dy, M, K, N, plan[1]).t()               # mode 3: dW^T = X^T dY, operands swapped
+        return out if view_ok else out.contiguous()
     dyT, xT, Mp = _wgrad_operands_nt(hip, dy, x, M, N, K, conv)
     return _wgrad_run(hip, dyT, xT, N, K, Mp, plan[0], plan[1], view_ok)
 
@@ -223,10 +231,11 @@ def _wgrad_tune(hip: Hip, dy, x, M, N, K, conv, view_ok):
     cands = []
     xr = x if conv is None else hip.gather_taps(x, M, *conv)
     t_gather = 0.0 if conv is None else _time(lambda: hip.gather_taps(x, M, *conv))
-    s0 = wgrad_tn_splits(N, K, M)
-    for sp in sorted({1, max(1, s0 // 4), max(1, s0 // 2), max(1, (3 * s0) // 4), s0, (3 * s0) // 2, 2 * s0, 3 * s0}):
-        if sp >= 1 and M // sp >= 64 and sp * N * K * 4 <= (1 << 30):
-            cands.append((_time(lambda: hip.wgrad_tn(dy, xr, M, N, K, sp)) + t_gather, (2, sp)))
+    for mode in (2, 3):
+        s0 = wgrad_tn_splits(N, K, M) if mode == 2 else wgrad_tn_splits(K, N, M)
+        for sp in sorted({1, max(1, s0 // 4), max(1, s0 // 2), max(1, (3 * s0) // 4), s0, (3 * s0) // 2, 2 * s0, 3 * s0}):
+            if sp >= 1 and M // sp >= 64 and sp * N * K * 4 <= (1 << 30):
+                cands.append((_time(lambda: _wgrad_exec(hip, (mode, sp), dy, xr, M, N, K, None, view_ok)) + t_gather, (mode, sp)))
     del xr
     dyT, xT, Mp = _wgrad_operands_nt(hip, dy, x, M, N, K, conv)
     t_prep = _time(lambda: _wgrad_operands_nt(hip, dy, x, M, N, K, conv))
