@@ -165,3 +165,31 @@ def test_training_step_other_noise_levels_and_dropout_branches(golden, which):
             name = key[len(f"{which}__grad__"):].replace("__", ".")
             r = torch.from_numpy(e[key])
             assert float((grads[name] - r).abs().max()) <= 2e-4 * float(r.abs().max()) + 1e-12, name
+
+
+def test_weight_gradient_plan_functions_return_launchable_plans():
+    """`train.wgrad_plan` / `wgrad_tn_splits` / `wgrad_default_plan` (pure host logic) over the served shapes and odd ones: a
+    split-K factor always divides the K-tile count and leaves >= 8 tiles per range (what wiw_gemm_bf16 requires), a row split
+    keeps >= 128 rows (or is 1), linear layers default to the row-major kernel, convolutions to the transposed-operand GEMM."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import wiw_amd  # noqa: F401
+    from wiw_amd.train import wgrad_default_plan, wgrad_plan, wgrad_tn_splits
+
+    M0 = 14 * 72 * 128
+    for n_out in (64, 320, 640, 960, 1280, 1920, 2560, 5120, 10240):
+        for k_in in (192, 320, 576, 640, 1280, 2880, 5760, 11520, 23040):
+            for rows in (64, 2048, M0 >> 4, M0 >> 2, M0):
+                flip, sk = wgrad_plan(n_out, k_in, rows)
+                nk = rows // 64
+                assert flip in (0, 1) and sk >= 1 and nk % sk == 0 and (sk == 1 or nk // sk >= 8), (n_out, k_in, rows, flip, sk)
+                sp = wgrad_tn_splits(n_out, k_in, rows)
+                assert sp == 1 or rows // sp >= 128, (n_out, k_in, rows, sp)
+                mode, s = wgrad_default_plan(n_out, k_in, rows, conv=False)
+                assert mode in (2, 3) and s >= 1
+                assert wgrad_default_plan(n_out, k_in, rows, conv=True) == wgrad_plan(n_out, k_in, rows)
+    # a 320-wide dy against a wide x: operands swapped (3 x 128 columns instead of 2 x 256 rows); square / tall: not
+    assert wgrad_default_plan(320, 1280, M0, False)[0] == 3 and wgrad_default_plan(320, 320, M0, False)[0] == 2
+    assert wgrad_default_plan(2560, 320, M0, False)[0] == 2
