@@ -620,7 +620,15 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     // (measured: K = 320 GEGLU -6 %, plain +-2 %; K >= 640 +4...+28 %)
     if (a.K < 640 && !getenv("WIW_GEMM_HUGE_ANYK")) return false;
     const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
-    return tiles >= 200;
+    if (tiles < 200) return false;
+    // persistent grid of one block per CU: a tile count just above a multiple of the CU count leaves the last round mostly
+    // idle (M = 8064, N = 3840: 384 tiles = 1.5 rounds of 256) while the 256 x 160 tile's count fills its rounds (768 = 3.0):
+    // 128 us against 107 us (tools/gemm_probe.py, profiles/r04l_tile_probe.txt).  gfx950: 256 CUs.
+    const int64_t cus = 256, tiles_b = (int64_t)((a.M + HM - 1) / HM) * ((a.N + 159) / 160);
+    const double fill_h = (double)tiles / (double)(((tiles + cus - 1) / cus) * cus);
+    const double fill_b = (double)tiles_b / (double)(((tiles_b + cus - 1) / cus) * cus);
+    if (!ge && fill_h < 0.8 && fill_b > fill_h + 0.15) return false;
+    return true;
 }
 
 int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
