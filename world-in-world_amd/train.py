@@ -277,8 +277,6 @@ def linear_backward(hip: Hip, x: torch.Tensor, W: torch.Tensor, dy: torch.Tensor
          db [N]   (fp32)     = column sums of dy   -> wiw_colsum
        (`nn.Linear` backward, attention_processor.py:2358-2391 / attention.py:1185-1243 call sites).  The transposes are
        wiw_transpose_bf16 passes; fp32 accumulation over all M rows inside the MFMA K loop."""
-    from .hip import EPI_OUT_F32
-
     M, K = x.shape
     N = W.shape[0]
     assert W.shape == (N, K) and dy.shape == (M, N) and M % 8 == 0 and N % 64 == 0 and K % 64 == 0
@@ -305,7 +303,7 @@ def conv_backward(hip: Hip, x: torch.Tensor, Wk: torch.Tensor, dy: torch.Tensor,
         dW  = dy^T . im2col(x)   (fp32 [Cout, taps*Cin]: `wgrad` with the im2col operand built in the layout its plan reads)
         db  = column sums of dy
     (the stride-2 / upsampling variants are not covered yet)."""
-    from .hip import A_CONV3X3, A_CONV_T3, EPI_OUT_F32
+    from .hip import A_CONV3X3, A_CONV_T3
 
     M, Cin = x.shape
     Cout = Wk.shape[0]

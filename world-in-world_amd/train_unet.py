@@ -468,7 +468,6 @@ class UNetTrain:
     def _add_rowvec(self, x, vec, rows_per_vec):
         """x + vec[row // rows_per_vec] (vec fp32 [units, C]): a 1x... broadcast add through the GEMM-free path."""
         hip, tape = self.hip, self.tape
-        M, C = x.shape
         rep = vec.to(self.dt).repeat_interleave(rows_per_vec, dim=0).contiguous()      # plumbing: broadcast copy
         y = hip.axpby(x, 1.0, rep, 1.0)
 
