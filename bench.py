@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="BASELINE config 4 instead of the inference loop: one fine-tuning step per 'step' (un-fused training "
                          "forward, EDM loss, backward through every operator, AdamW), one sample per GPU, data parallel over "
-                         "the ranks (ShardedAdamW: gradient reduce-scatter + parameter all-gather).  Functional, untuned.")
+                         "the ranks (ShardedAdamW: gradient reduce-scatter overlapped with the backward + parameter all-gather).")
     ap.add_argument("--no-autotune", action="store_true", help="--train: the schedule model's weight-gradient GEMM plans instead "
                     "of the ones measured during warm-up")
     ap.add_argument("--train-height", type=int, default=576, help="train_svd.sh:22-23 trains at 576x1024 (the dataset comments "

@@ -6,8 +6,8 @@ reverse with the backward building blocks of `train.py` / `csrc/train.hip` and r
 the reference's state-dict layout.  The exactly dead parameters of the inference path (single-key cross-attention `norm2`,
 `attn2.to_q/to_k`; `add_embedding`) are dead here too and get no gradient — as in the reference's autograd.
 
-FIRST, correctness-first form: activations are 16-bit (as the forward kernels produce them), parameter gradients fp32; no
-operator fusion, explicit concat / residual tensors, untuned backward kernels (`csrc/train.hip`).  Tiny host-side pieces
+Activations are 16-bit (as the forward kernels produce them), parameter gradients fp32; no operator fusion, explicit concat /
+residual tensors; the backward kernels (`csrc/train.hip`) are described and measured in DESIGN.md 3.6 / 8.  Tiny host-side pieces
 (sinusoidal features, sums of three [T, E] embedding rows, gradient accumulation of sub-64 k-element tensors, weight
 re-layouts) are PyTorch plumbing.  Pinned by `tests/golden/train_step_tiny*.npz` (the reference's own `loss.backward()`).
 """
