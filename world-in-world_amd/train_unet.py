@@ -676,10 +676,18 @@ class Trainer:
         grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
         net.tape.after_op = None
         self._seen = {n for n in grads if self.trainable(n)}
-        if self.loss_scale != 1.0 and not bool(torch.stack([torch.isfinite(g).all() for g in grads.values()]).all()):   # one host sync
-            self.loss_scale *= 0.5                                         # overflow: skip the update, as a GradScaler does
-            self._micro, self._acc = 0, {}
-            return float(loss)
+        if self.loss_scale != 1.0:
+            bad = ~torch.stack([torch.isfinite(g).all() for g in grads.values()]).all()
+            if self.opt is not None and self.opt.world > 1:                # EVERY rank skips, or none: the collectives of
+                import torch.distributed as dist                           # `opt.step()` must be entered by all of them
+
+                flag = bad.to(torch.float32).reshape(1)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                bad = flag[0] > 0
+            if bool(bad):                                                  # (one host sync)
+                self.loss_scale *= 0.5                                     # overflow: skip the update, as a GradScaler does
+                self._micro, self._acc = 0, {}
+                return float(loss)
         self._micro += 1
         if self._micro % self.grad_accum != 0:                             # not the last micro-batch: accumulate, no update
             inv = 1.0 / self.grad_accum
