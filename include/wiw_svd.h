@@ -31,13 +31,14 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 7   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 8   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
                              6: WiwGemmArgs gained lnfold / ln_eps (WIW_EPI_LNFOLD);
                              7: the training entry points settled: wiw_colsum sums CONTIGUOUS row ranges, wiw_attn_bwd_bf16
-                                takes NULL transposes on its LDS-tiled path, wiw_gather_taps_t_bf16, wiw_wgrad_tn_bf16 */
+                                takes NULL transposes on its LDS-tiled path, wiw_gather_taps_t_bf16, wiw_wgrad_tn_bf16;
+                             8: wiw_ffn_geglu_bf16 (fused LayerNorm + GEGLU FeedForward of the C = 320 level) */
 
 int wiw_abi_version(void);
 
@@ -171,6 +172,30 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  * ---------------------------------------------------------------------------------------------- */
 int wiw_temporal_attn_block_bf16(void* stream, const void* X, const void* Wqkv, const float* fold, void* O, int ldo,
                                  int batch, int T, int S, int heads, float eps, float scale, const void* zeros);
+
+/* ------------------------------------------------------------------------------------------------
+ * FUSED FeedForward (GEGLU) of the 320-channel level, optionally with the LayerNorm in front of it, ONE kernel:
+ *
+ *   h   = GEGLU( LN?(X) . W1^T + b1 )            [M][1280], never written to memory
+ *   out = alpha * ( h . W2^T + b2 + rowvec[m / rows_per_vec] ) + beta1 * res1 + beta2 * res2
+ *
+ * Replaces FeedForward.forward (dp/models/attention.py:1185-1243: net.0 = GEGLU proj, activations.py:93-123, exact-erf
+ * GELU; net.2 = Linear) together with the residual add / AlphaBlender that follows it
+ * (attention.py:565-582, 756-762; transformer_temporal.py:364-372), and with ln != 0 also norm3 / norm_in
+ * (nn.LayerNorm, attention.py:540-567, 745-756).  Per 128-row tile the hidden activation lives in LDS / registers only.
+ *   X    : bf16 [M][ldx]; ln == 0: the LayerNorm OUTPUT; ln != 0: the RAW LayerNorm input (statistics over the 320 columns,
+ *          two-pass in registers, eps = ln_eps) — then W1 must hold W1 * gamma and b1 must hold W1 . beta + b1
+ *   W1   : bf16 [2560][320], rows packed in chunks of 128 = [64 value rows | 64 gate rows] of hidden units 64c .. 64c+63
+ *          (value rows = first half of net.0.proj.weight, gate rows = second half), TILED (WIW_W_TILED layout, above)
+ *   b1   : fp32 [2560] packed the same way;   W2: bf16 [320][1280] TILED;   b2: fp32 [320] or NULL
+ *   rowvec / rows_per_vec / res1 / res2 / alpha / beta1 / beta2 : as for wiw_gemm_bf16 (fp32 vector rows; bf16 residuals)
+ *   C_in, hidden : must be 320, 1280 (anything else returns WIW_EINVAL: the wider levels run on wiw_gemm_bf16)
+ * All pointers 16-byte aligned; ldx, ldo, ldr1, ldr2 multiples of 8; rowvec_ld a multiple of 4.
+ * ---------------------------------------------------------------------------------------------- */
+int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                       const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
+                       float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
+                       int C_in, int hidden, int ln, float ln_eps);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) in NHWC, split into statistics + fused normalise/affine/SiLU.

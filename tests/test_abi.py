@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path, variant, code):
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported by {os.path.basename(path)}"
     lib.wiw_abi_version.restype = ctypes.c_int
     lib.wiw_dtype.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 7 and lib.wiw_dtype() == code
+    assert lib.wiw_abi_version() == 8 and lib.wiw_dtype() == code
 
 
 def test_gemm_args_struct_layout():
@@ -73,3 +73,10 @@ def test_argument_validation_without_gpu(lib_path):
     assert b"T <= 16" in lib.wiw_last_error()
     assert lib.wiw_attn_spatial_bf16(None, 1, 128, 64, 1, 8, 1, 64, 1, 4, 1, 0.125, 1) == -1
     assert b"multiple of 8" in lib.wiw_last_error()
+    # fused FeedForward: built for the 320 / 1280 level only; misaligned pointers are refused
+    assert lib.wiw_ffn_geglu_bf16(None, 16, 640, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 640, 128,
+                                  640, 2560, 0, 1e-5) == -1
+    assert b"C = 320" in lib.wiw_last_error()
+    assert lib.wiw_ffn_geglu_bf16(None, 8, 320, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 320, 128,
+                                  320, 1280, 0, 1e-5) == -1
+    assert b"16-byte aligned" in lib.wiw_last_error()

@@ -1,0 +1,459 @@
+// Fused FeedForward for the C = 320 level of the UNet on gfx950 (MI355X):
+//
+//   out = alpha * ( GEGLU( LN?(X) . W1^T + b1 ) . W2^T + b2 + rowvec[m / rows_per_vec] ) + beta1 * res1 + beta2 * res2
+//
+// (FeedForward with GEGLU: dp/models/attention.py:1185-1243, activations.py:93-123; optionally the LayerNorm in front of
+// it, attention.py:540-567 / 745-756.)  The [M][1280] hidden tensor — 660 MB written and read back per layer at
+// M = 258 048 — never exists, and the K = 320 up-projection, whose 5-K-tile output tiles spent a third of their time in
+// an epilogue with the matrix pipe idle, becomes part of ONE long MFMA stream per 128-row tile.
+//
+// Work item = 128 rows of X.  The hidden dimension is walked in 20 chunks of 64 units; a chunk is
+//   phase 1:  Hc[128][64 v | 64 g] = X[128][320] . W1c[128][320]^T          (K = 320: 5 K tiles of 64)
+//   GEGLU  :  H[128][64] = (v + b_v) * gelu_erf(g + b_g)  -> 16-bit, to LDS
+//   phase 2:  Y[128][320] += H[128][64] . W2c[320][64]^T                      (K = 64)
+// 8 waves, TWO ROLES (one wave of each role per SIMD: waves w and w + 4 share a SIMD):
+//   * H-waves 0..3: rows 32w..32w+31.  X fragments live in REGISTERS for the whole tile (80 VGPRs), so phase 1 reads only
+//     W1 fragments from LDS (8 ds_read_b128 per 16 MFMAs); accumulators 32 rows x 128 columns (64 VGPRs); then the GEGLU
+//     on the VALU and 8-byte LDS writes of H;
+//   * Y-waves 4..7: own Y[32 rows][320] (160 accumulator VGPRs) for the whole tile, issue EVERY LDS-DMA instruction of the
+//     block (W1 K tiles, W2 chunk, bias chunk) while the H-wave of their SIMD streams MFMAs, and run phase 2 of chunk c-1
+//     (80 MFMAs) exactly while that H-wave evaluates the GEGLU of chunk c on the VALU — matrix pipe and VALU of a SIMD
+//     are busy with different waves instead of taking turns inside one.
+// The roles are one chunk apart (H_c goes through a double-buffered LDS tile), H-waves run ahead across tile boundaries
+// (next tile's X loads are issued under the last GEGLU), the Y-waves' epilogue (bias, per-frame vector, residuals,
+// 16-byte streaming stores through a per-wave LDS transpose) happens once per 629 MFLOP instead of once per 26.
+// One block barrier per slot; 6 slots per chunk: 5 K tiles + the GEGLU / phase-2 slot.
+//
+// Weights: W1 packed [2560][320] in chunks of 128 rows = [64 value | 64 gate] and W2 [320][1280], both in the tiled
+// layout of wiw_gemm_bf16 (1-KiB blocks, chunks pre-swizzled): one DMA instruction copies one contiguous KiB and the LDS
+// image is the XOR-swizzled row-major tile the fragment reads expect.
+#include <stdlib.h>
+
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr int C = 320, HID = 1280, HC = 64, NCH = HID / HC;      // 20 hidden chunks
+constexpr int BM = 128, BK = 64, NKT = C / BK;                   // 5 K tiles per chunk
+constexpr int KS = C / 32;                                       // 10 k-steps of 32 over X's K
+constexpr int RING_STAGES = 3, RING_STAGE_BYTES = 2 * HC * BK * 2;   // W1 K tile: 128 rows x 64 k = 16 KiB
+constexpr int W2_OFF = RING_STAGES * RING_STAGE_BYTES;           // 49152
+constexpr int W2_BYTES = C * HC * 2;                             // 320 rows x 64 k = 40 KiB
+constexpr int H_OFF = W2_OFF + W2_BYTES;                         // 90112
+constexpr int H_BYTES = BM * HC * 2;                             // 16 KiB per parity
+constexpr int BIAS_OFF = H_OFF + 2 * H_BYTES;                    // 122880
+constexpr int BIAS_BYTES = 2 * HC * 4;                           // 512 B per parity
+constexpr int SMEM = BIAS_OFF + 2 * BIAS_BYTES;                  // 123904
+constexpr int STG_ROWB = 336;                                    // epilogue staging: 160 columns + 16 B skew
+constexpr int STG_WAVE = 16 * STG_ROWB;                          // 5376 B per Y-wave, inside the W2 buffer
+static_assert(4 * STG_WAVE <= W2_BYTES, "epilogue staging must fit in the W2 buffer");
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// LDS-DMA (16 bytes per lane, LDS destination = wave-uniform base + 16 * lane) as INLINE ASM: hipcc models the builtin as a
+// FLAT access that may touch LDS, and while one is pending every compiler-inserted wait for a ds_read is lgkmcnt(0) — the
+// Y-waves' software-pipelined fragment reads of phase 2 (8 in flight) would drain at every use.  The asm form is invisible to
+// that bookkeeping: its completion is counted by hand (wait_vmcnt below), exactly as for the builtin.  M0 carries the LDS
+// address and is saved / restored inside the statement (the compiler does not preserve it around asm).
+WIW_DEV void glds16(const char* g, char* l) {
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)l);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+template <int N>
+WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+WIW_DEV void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+WIW_DEV void slot_barrier() {   // this wave's LDS accesses are retired, then rendezvous of all 8 waves
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct FfnArgs {
+    const uint16_t* X;      // [M][ldx]   LayerNorm output, or its raw input when ln != 0
+    const uint16_t* W1;     // packed + tiled [2560][320]
+    const float* b1;        // packed [2560]
+    const uint16_t* W2;     // tiled [320][1280]
+    const float* b2;        // [320] or null
+    const float* rowvec;    // [M / rows_per_vec][rowvec_ld] or null
+    const uint16_t* res1;   // [M][ldr1] or null
+    const uint16_t* res2;   // [M][ldr2] or null
+    uint16_t* out;          // [M][ldo]
+    int M, ldx, ldo, ldr1, ldr2, rowvec_ld, rows_per_vec, ln;
+    float alpha, beta1, beta2, ln_eps;
+};
+
+__global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int wq = wave & 3;                            // row quarter of the tile served by this wave (both roles)
+    const int ntiles = (p.M + BM - 1) / BM;
+    const int nb = gridDim.x;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int ntl = (ntiles - (int)blockIdx.x + nb - 1) / nb;   // tiles of this block: blockIdx.x + i * nb
+    const int NC = ntl * NCH;                                   // chunks of this block; H-waves at chunk cc, Y-waves at cc - 1
+
+    if (wave < 4) {
+        // =====================================================================================================
+        // H-waves: phase 1 + GEGLU
+        // =====================================================================================================
+        bf16x8 xa[2][KS];      // X fragments of the tile: rows 16*mi + frow, k = 32*ks + 8*fq .. +7
+        f32x4 acc[2][8];       // lane: row 16*mi + frow, chunk columns 16*ni + 4*fq + r  (ni 0..3 value, 4..7 gate)
+        bf16x8 fbA[8], fbB[8]; // W1 fragments of k-step 0 / 1 of the K tile in flight
+        auto load_x = [&](int tile) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                int m = tile * BM + wq * 32 + mi * 16 + frow;
+                m = m < p.M ? m : p.M - 1;   // rows past M are computed on a copy of the last row and never stored
+                const uint16_t* src = p.X + (int64_t)m * p.ldx + fq * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xa[mi][ks] = *(const bf16x8*)(src + ks * 32);
+            }
+        };
+        // LayerNorm without its affine (gamma is folded into W1, beta into b1): two passes over the 320 values of a row,
+        // which sit in the 4 lanes (fq) of the row x 10 fragments x 8 values; result rounded to the 16-bit operand type
+        auto normalize_x = [&]() {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float s = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    union { bf16x8 v; uint32_t u[4]; } x;
+                    x.v = xa[mi][ks];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const wiw_f32x2 lh = unpack2(x.u[j]); s += lh.x + lh.y; }
+                }
+                const float mean = xor32_sum(xor16_sum(s)) * (1.0f / (float)C);
+                float q = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    union { bf16x8 v; uint32_t u[4]; } x;
+                    x.v = xa[mi][ks];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const wiw_f32x2 lh = unpack2(x.u[j]);
+                        const float a = lh.x - mean, b = lh.y - mean;
+                        q = __builtin_fmaf(a, a, __builtin_fmaf(b, b, q));
+                    }
+                }
+                const float rstd = rsqrtf(xor32_sum(xor16_sum(q)) * (1.0f / (float)C) + p.ln_eps);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    union { bf16x8 v; uint32_t u[4]; } x;
+                    x.v = xa[mi][ks];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const wiw_f32x2 lh = unpack2(x.u[j]);
+                        x.u[j] = pack2bf((lh.x - mean) * rstd, (lh.y - mean) * rstd);
+                    }
+                    xa[mi][ks] = x.v;
+                }
+            }
+        };
+        const int sw0 = (fq ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;   // swizzled chunk of k-step 0 / 1
+        auto read_w1 = [&](bf16x8* fb, int stage, int sw) {
+            const char* s = smem + stage * RING_STAGE_BYTES + frow * 128 + sw;
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) fb[ni] = *(const bf16x8*)(s + ni * 2048);
+        };
+        auto mma = [&](const bf16x8* fb, const bf16x8& x0, const bf16x8& x1) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                acc[0][ni] = WIW_MFMA(fb[ni], x0, acc[0][ni]);
+                acc[1][ni] = WIW_MFMA(fb[ni], x1, acc[1][ni]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        load_x(blockIdx.x);
+        int st = 0;          // ring stage of the next K tile
+        int c = 0, ti = 0;   // chunk inside the tile, tile counter of this block
+        for (int cc = 0; cc <= NC; ++cc) {
+            if (cc == NC) {   // drain iteration: the Y-waves finish the last chunk (+ the tile-end barrier, see below)
+#pragma unroll
+                for (int i = 0; i < NKT + 2; ++i) slot_barrier();
+                break;
+            }
+            if (c == 0 && p.ln) normalize_x();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // ---- slots 0..4: K tile kt.  The MFMAs of a K tile's second k-step run in the NEXT slot, under that slot's
+            // first fragment reads, so the matrix pipe is not idle while a slot's first reads are in flight.
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                slot_barrier();
+                read_w1(fbA, st, sw0);
+                if (kt > 0) mma(fbB, xa[0][2 * kt - 1], xa[1][2 * kt - 1]);
+                read_w1(fbB, st, sw1);
+                mma(fbA, xa[0][2 * kt], xa[1][2 * kt]);
+                st = st + 1 == RING_STAGES ? 0 : st + 1;
+            }
+            // ---- slot 5: last k-step, then the GEGLU on the VALU while the Y-wave of this SIMD runs phase 2 of chunk cc - 1
+            slot_barrier();
+            mma(fbB, xa[0][KS - 1], xa[1][KS - 1]);
+            if (c == NCH - 1 && ti + 1 < ntl) load_x(blockIdx.x + (ti + 1) * nb);   // X of the next tile: latency under the GEGLU
+            {
+                const char* bs = smem + BIAS_OFF + (cc & 1) * BIAS_BYTES;
+                char* hb = smem + H_OFF + (cc & 1) * H_BYTES;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float4 bv = *(const float4*)(bs + (ni * 16 + fq * 4) * 4);
+                    const float4 bg = *(const float4*)(bs + (HC + ni * 16 + fq * 4) * 4);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const f32x4 v = acc[mi][ni], g = acc[mi][ni + 4];
+                        uint2 pk;
+                        pk.x = pack2bf((v[0] + bv.x) * gelu_erf_f(g[0] + bg.x), (v[1] + bv.y) * gelu_erf_f(g[1] + bg.y));
+                        pk.y = pack2bf((v[2] + bv.z) * gelu_erf_f(g[2] + bg.z), (v[3] + bv.w) * gelu_erf_f(g[3] + bg.w));
+                        // H[row][16*ni + 4*fq .. +3]: 16-byte chunk 2*ni + (fq >> 1) of the row, swizzled like every K tile
+                        const int row = wq * 32 + mi * 16 + frow;
+                        *(uint2*)(hb + row * 128 + (((2 * ni + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+                    }
+                }
+            }
+            // tile-end barrier: in this iteration the Y-waves finished a tile (its last chunk is cc - 1) and stage its
+            // epilogue in the W2 buffer, which every Y-wave must have stopped reading first
+            if (c == 0 && cc >= 1) slot_barrier();
+            if (++c == NCH) { c = 0; ++ti; }
+        }
+    } else {
+        // =====================================================================================================
+        // Y-waves: all LDS-DMA of the block, phase 2, tile epilogue
+        // =====================================================================================================
+        f32x4 accY[2][20];     // lane: row 16*mi + frow, output columns 16*nj + 4*fq + r
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 20; ++nj) accY[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* const W1b = (const char*)p.W1;
+        const char* const W2b = (const char*)p.W2;
+        // loader state: next W1 K tile to issue = K tile ld_kt of chunk ld_c (of any tile: the weights repeat), stage ld_st
+        int ld_c = 0, ld_kt = 0, ld_st = 0;
+        int ld_left = NC * NKT;                        // W1 K tiles still to be issued
+        auto issue_w1 = [&]() {   // this wave's quarter (4 x 1 KiB = rows 32*wq .. +31 of the chunk) of one W1 K tile
+            const char* src = W1b + ((int64_t)((ld_c * 16 + wq * 4) * NKT + ld_kt)) * 1024 + lane * 16;
+            char* dst = smem + ld_st * RING_STAGE_BYTES + wq * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(src + (int64_t)i * NKT * 1024, dst + i * 1024);
+            if (++ld_kt == NKT) { ld_kt = 0; ld_c = ld_c + 1 == NCH ? 0 : ld_c + 1; }
+            ld_st = ld_st + 1 == RING_STAGES ? 0 : ld_st + 1;
+            --ld_left;
+        };
+        // prologue: K tiles 0 and 1
+        issue_w1();
+        issue_w1();
+        wait_vmcnt<4>();
+
+        const int sw0 = (fq ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;
+        int c = 0;   // chunk (inside its tile) the H-waves work on in this iteration; this wave works on chunk c - 1
+        int ti = 0;  // tile counter of the chunk THIS wave works on
+        for (int cc = 0; cc <= NC; ++cc) {
+            const int c2 = c == 0 ? NCH - 1 : c - 1;   // chunk of phase 2 in this iteration (valid for cc >= 1)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                slot_barrier();
+                // bias chunk of the H-waves' current chunk (512 B; read by them in slot 5 of this iteration)
+                if (kt == 0 && cc < NC && wq == 0) {
+                    if (lane < 32) glds16((const char*)p.b1 + c * (2 * HC * 4) + lane * 16, smem + BIAS_OFF + (cc & 1) * BIAS_BYTES);
+                }
+                // W2 chunk c2, rows 64*kt .. +63 (8 blocks of 1 KiB, 2 per Y-wave): consumed in slot 5 of this iteration
+                if (cc >= 1) {
+                    const int rb = kt * 8 + wq * 2;
+                    const char* src = W2b + ((int64_t)rb * NCH + c2) * 1024 + lane * 16;
+                    char* dst = smem + W2_OFF + rb * 1024;
+                    glds16(src, dst);
+                    glds16(src + (int64_t)NCH * 1024, dst + 1024);
+                }
+                // W1 K tile two slots ahead of the one the H-waves read now; everything issued before it must have landed
+                // at the end of this slot (the K tile of the NEXT slot, this slot's W2 part, the bias chunk)
+                if (ld_left > 0) {
+                    issue_w1();
+                    wait_vmcnt<4>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+            }
+            slot_barrier();
+            if (cc >= 1) {
+                // ---- phase 2 of chunk c2: Y += H . W2c^T  (H of the previous iteration, parity (cc - 1) & 1)
+                const char* hb = smem + H_OFF + ((cc - 1) & 1) * H_BYTES + (wq * 32 + frow) * 128;
+                bf16x8 hf[2][2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    hf[mi][0] = *(const bf16x8*)(hb + mi * 2048 + sw0);
+                    hf[mi][1] = *(const bf16x8*)(hb + mi * 2048 + sw1);
+                }
+                const char* wb = smem + W2_OFF + frow * 128;
+                // 40 W2 fragments (k-step ks = j / 20, column block nj = j % 20), each feeding 2 MFMAs, through a ring of 8
+                // registers: the order [2 MFMAs | 1 ds_read] is pinned so that 8 reads stay in flight behind the matrix pipe
+                // (left alone the compiler issues 2 reads and waits for both before every 4 MFMAs)
+                auto wread = [&](int j) { return *(const bf16x8*)(wb + (j % 20) * 2048 + (j >= 20 ? sw1 : sw0)); };
+                bf16x8 wf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf[j] = wread(j);
+                __builtin_amdgcn_s_setprio(1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 40; ++j) {
+                    accY[0][j % 20] = WIW_MFMA(wf[j & 7], hf[0][j / 20], accY[0][j % 20]);
+                    accY[1][j % 20] = WIW_MFMA(wf[j & 7], hf[1][j / 20], accY[1][j % 20]);
+                    if (j + 8 < 40) wf[j & 7] = wread(j + 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (c2 == NCH - 1) {
+                    // ---- tile epilogue: 4 passes of 16 rows x 160 columns through a per-wave LDS transpose staged in the
+                    // W2 buffer (free once EVERY Y-wave is through phase 2 — the tile-end barrier — until the next slot's
+                    // DMA); row-major phase: lane = (row lrow + 3k, 16-byte column chunk lch)
+                    slot_barrier();
+                    const int tile = blockIdx.x + ti * nb;
+                    const int mw0 = tile * BM + wq * 32;
+                    char* stg = smem + W2_OFF + wq * STG_WAVE;
+                    const int lrow = lane / 20 < 3 ? lane / 20 : 2;   // 60 lanes = 3 rows x 20 chunks; lanes 60..63 repeat row 2
+                    const int lch = lane - (lane / 20) * 20;
+                    const float al = p.alpha;
+                    const bool rv_fast = p.rowvec != nullptr && (p.rows_per_vec % 16) == 0;   // one vector row per 16-row pass
+                    auto pass = [&](auto mi_tag, auto half_tag) {
+                        constexpr int mi = decltype(mi_tag)::value, half = decltype(half_tag)::value;
+                        const int ncol = half * 160 + lch * 8;
+                        const int mp0 = mw0 + mi * 16;
+                        // every global load of the pass is issued up front (rows past M re-read the last row)
+                        float4 b0 = float4{0.f, 0.f, 0.f, 0.f}, b1v = b0, r0 = b0, r1v = b0;
+                        uint4 q1[6], q2[6];
+                        if (p.b2) { b0 = *(const float4*)(p.b2 + ncol); b1v = *(const float4*)(p.b2 + ncol + 4); }
+                        if (rv_fast) {
+                            const float* rv = p.rowvec + (int64_t)((mp0 < p.M ? mp0 : p.M - 1) / p.rows_per_vec) * p.rowvec_ld + ncol;
+                            r0 = *(const float4*)rv; r1v = *(const float4*)(rv + 4);
+                        }
+                        if (p.res1) {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) {
+                                int m = mp0 + (lrow + k * 3 < 16 ? lrow + k * 3 : 15);
+                                m = m < p.M ? m : p.M - 1;
+                                q1[k] = *(const uint4*)(p.res1 + (int64_t)m * p.ldr1 + ncol);
+                            }
+                        }
+                        char* wrow = stg + frow * STG_ROWB + fq * 8;
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            const f32x4 v = accY[mi][half * 10 + j];
+                            uint2 pk;
+                            pk.x = pack2bf(v[0] * al, v[1] * al);
+                            pk.y = pack2bf(v[2] * al, v[3] * al);
+                            *(uint2*)(wrow + j * 32) = pk;
+                        }
+                        if (p.res2) {   // (after the staging writes: those accumulator registers are free now)
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) {
+                                int m = mp0 + (lrow + k * 3 < 16 ? lrow + k * 3 : 15);
+                                m = m < p.M ? m : p.M - 1;
+                                q2[k] = *(const uint4*)(p.res2 + (int64_t)m * p.ldr2 + ncol);
+                            }
+                        }
+                        wave_lds_sync();
+                        const float cb[8] = {al * (b0.x + r0.x), al * (b0.y + r0.y), al * (b0.z + r0.z), al * (b0.w + r0.w),
+                                             al * (b1v.x + r1v.x), al * (b1v.y + r1v.y), al * (b1v.z + r1v.z), al * (b1v.w + r1v.w)};
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int rr = lrow + k * 3 < 16 ? lrow + k * 3 : 15;
+                            const int m = mp0 + rr;
+                            const bool ok = m < p.M;
+                            float v[8], f[8];
+                            unpack8(*(const uint4*)(stg + rr * STG_ROWB + lch * 16), v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += cb[e];
+                            if (p.rowvec && !rv_fast) {   // odd rows_per_vec (small test shapes): the vector row of every item
+                                const float* rv = p.rowvec + (int64_t)((ok ? m : p.M - 1) / p.rows_per_vec) * p.rowvec_ld + ncol;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += al * rv[e];
+                            }
+                            if (p.res1) {
+                                unpack8(q1[k], f);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += p.beta1 * f[e];
+                            }
+                            if (p.res2) {
+                                unpack8(q2[k], f);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += p.beta2 * f[e];
+                            }
+                            if (ok) {
+                                const uint4 ov = pack8(v);
+                                uint4* dst = (uint4*)(p.out + (int64_t)m * p.ldo + ncol);
+                                __builtin_nontemporal_store(ov.x, &dst->x); __builtin_nontemporal_store(ov.y, &dst->y);
+                                __builtin_nontemporal_store(ov.z, &dst->z); __builtin_nontemporal_store(ov.w, &dst->w);
+                            }
+                        }
+                        wave_lds_sync();
+                    };
+                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+                    pass(I0{}, I0{}); pass(I0{}, I1{}); pass(I1{}, I0{}); pass(I1{}, I1{});
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < 20; ++nj) accY[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ++ti;
+                }
+            }
+            c = c + 1 == NCH ? 0 : c + 1;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                                  const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
+                                  int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
+                                  int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps) {
+    WIW_REQUIRE(X && W1 && b1 && W2 && out, "ffn_geglu: null X / W1 / b1 / W2 / out pointer");
+    WIW_REQUIRE(C_in == C && hidden == HID, "ffn_geglu: built for C = 320, hidden = 1280 (the UNet's first level); use wiw_gemm_bf16 elsewhere");
+    WIW_REQUIRE(M > 0 && M < (1ll << 31) - BM, "ffn_geglu: bad M");
+    WIW_REQUIRE(ldx % 8 == 0 && ldx >= C && ldo % 8 == 0 && ldo >= C, "ffn_geglu: ldx / ldo must be multiples of 8 and >= 320");
+    WIW_REQUIRE(res1 == nullptr || (ldr1 % 8 == 0 && ldr1 >= C), "ffn_geglu: ldr1 must be a multiple of 8 and >= 320");
+    WIW_REQUIRE(res2 == nullptr || (ldr2 % 8 == 0 && ldr2 >= C), "ffn_geglu: ldr2 must be a multiple of 8 and >= 320");
+    WIW_REQUIRE(rowvec == nullptr || (rows_per_vec > 0 && rowvec_ld % 4 == 0 && rowvec_ld >= C), "ffn_geglu: bad rowvec_ld / rows_per_vec");
+    WIW_REQUIRE((((uintptr_t)X | (uintptr_t)W1 | (uintptr_t)b1 | (uintptr_t)W2 | (uintptr_t)b2 | (uintptr_t)rowvec | (uintptr_t)res1 |
+                  (uintptr_t)res2 | (uintptr_t)out) & 15) == 0, "ffn_geglu: pointers must be 16-byte aligned");
+    WIW_REQUIRE(!ln || ln_eps > 0.0f, "ffn_geglu: the fused LayerNorm needs ln_eps > 0");
+    static std::once_flag once;
+    static bool attr_ok = false;
+    static int num_cu = 256;
+    std::call_once(once, [] {
+        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cu = prop.multiProcessorCount;
+    });
+    if (!attr_ok) {
+        wiw_set_error("hipFuncSetAttribute(ffn) failed");
+        return WIW_ELAUNCH;
+    }
+    FfnArgs a;
+    a.X = (const uint16_t*)X; a.W1 = (const uint16_t*)W1; a.b1 = b1; a.W2 = (const uint16_t*)W2; a.b2 = b2;
+    a.rowvec = rowvec; a.res1 = (const uint16_t*)res1; a.res2 = (const uint16_t*)res2; a.out = (uint16_t*)out;
+    a.M = (int)M; a.ldx = ldx; a.ldo = ldo; a.ldr1 = ldr1; a.ldr2 = ldr2; a.rowvec_ld = rowvec_ld;
+    a.rows_per_vec = rows_per_vec > 0 ? rows_per_vec : 1; a.ln = ln;
+    a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2; a.ln_eps = ln_eps;
+    const int tiles = (int)((M + BM - 1) / BM);
+    const int grid = tiles < num_cu ? tiles : num_cu;
+    hipLaunchKernelGGL(ffn_kernel, dim3((unsigned)grid), dim3(512), SMEM, (hipStream_t)stream, a);
+    return wiw_check_launch("wiw_ffn_geglu_bf16");
+}

@@ -21,6 +21,8 @@ EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
 EPI_LNFOLD = 64  # epilogue bit: A is the raw LayerNorm input, W = W * gamma, lnfold = [s | t] (include/wiw_svd.h)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
+FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
+FFN_C, FFN_HIDDEN = 320, 1280   # the one shape wiw_ffn_geglu_bf16 is built for
 
 
 class TiledW:
@@ -92,6 +94,9 @@ EXPORTS = {
                                          C.c_int, C.c_int, C.c_float]),
     "wiw_temporal_attn_block_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "wiw_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                     C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
     "wiw_clip_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -179,7 +184,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 7:
+        if self.lib.wiw_abi_version() != 8:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -286,6 +291,21 @@ class Hip:
                                                   heads, eps, scale, self.zeros.data_ptr()),
             "wiw_temporal_attn_block_bf16"))
         return O
+
+    def ffn_geglu(self, X, W1, b1, W2, b2, out, M, *, ldx=FFN_C, rowvec=None, rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0,
+                  beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0, ldo=FFN_C, ln=False, ln_eps=1e-5):
+        """Fused (LayerNorm +) GEGLU FeedForward of the 320-channel level (ffn.hip): the [M, 1280] hidden tensor never
+        exists.  W1 / b1 packed by `unet.pack_geglu(..., tile=FFN_CHUNK)` (+ TiledW), W2 a TiledW of [320, 1280]."""
+        flops = 2.0 * M * (2 * FFN_HIDDEN * FFN_C + FFN_C * FFN_HIDDEN)
+        nbytes = 2.0 * M * FFN_C * (2 + (res1 is not None) + (res2 is not None)) + 2.0 * 3 * FFN_HIDDEN * FFN_C
+
+        def launch():
+            self._ck(self.lib.wiw_ffn_geglu_bf16(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec),
+                                                 rowvec_ld, rows_per_vec, _p(res1), ldr1, beta1, _p(res2), ldr2, beta2, alpha,
+                                                 _p(out), ldo, M, FFN_C, FFN_HIDDEN, 1 if ln else 0, ln_eps),
+                     "wiw_ffn_geglu_bf16")
+        self._timed("ffn_fused", flops, nbytes, launch)
+        return out
 
     def attn_small(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, seqs, S, Sp, heads, head_dim, scale):
         self._timed("attn_small", 4.0 * seqs * heads * S * S * head_dim, 8.0 * seqs * S * heads * head_dim, lambda: self._ck(

@@ -28,7 +28,7 @@ import torch
 
 from .config import UNetConfig
 from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI_GEGLU, EPI_OUT_F32, EPI_SILU,
-                  GEGLU_TILE, Hip, TiledW, tile_weight)
+                  FFN_C, FFN_CHUNK, FFN_HIDDEN, GEGLU_TILE, Hip, TiledW, tile_weight)
 from .weights import validate_state_dict
 
 CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
@@ -52,9 +52,11 @@ def action_features(action_ids: np.ndarray) -> np.ndarray:
     return f.reshape(x.shape[0] * x.shape[1], x.shape[2] * 12)
 
 
-def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+def pack_geglu(w: torch.Tensor, b: torch.Tensor, tile: int = GEGLU_TILE):
     """Re-order the GEGLU projection [8C, K] (value rows then gate rows, activations.py:122) into tiles of
-    160 rows = [80 value | 80 gate] so the GEMM epilogue finds both halves in one block tile."""
+    2 * tile rows = [tile value | tile gate] so the GEMM epilogue finds both halves in one block tile (tile = 80:
+    gemm.hip's 160-column tile; tile = 64: the hidden chunks of the fused FeedForward kernel, ffn.hip)."""
+    GEGLU_TILE = tile  # noqa: N806  (shadows the module constant for the body below)
     n_half = w.shape[0] // 2
     pad = (-n_half) % GEGLU_TILE
     wv, wg = w[:n_half], w[n_half:]
@@ -131,6 +133,10 @@ class UNetHIP:
         self.ln_fold = bool(os.environ.get("WIW_LN_FOLD")) if fold_layernorm is None else bool(fold_layernorm)
         self.swapped_vt = bool(os.environ.get("WIW_SWAPPED_VT"))   # A/B knob: V^T by a swapped-operand GEMM (round 1)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
+        # fused FeedForward kernel of the 320-channel level (ffn.hip); A/B knobs: WIW_FF_UNFUSED=1 -> two GEMMs again,
+        # WIW_FFN_NO_LN=1 -> fused FeedForward behind a separate LayerNorm pass
+        self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED")
+        self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
         self._prepare(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -210,6 +216,15 @@ class UNetHIP:
                 w[p + ".net.0.proj.lnfold.weight"] = wgp
                 w[p + ".net.0.proj.lnfold.st"] = torch.stack([wgp.float().sum(dim=1), tp.float()]).contiguous()
             lin(p + ".net.2")
+            if self.ffn_fused and w0.shape == (2 * FFN_HIDDEN, FFN_C):
+                # operands of wiw_ffn_geglu_bf16: W1 in chunks of [64 value | 64 gate] rows; with the LayerNorm fused, gamma
+                # goes into W1 and beta into b1 (the kernel normalises the raw rows in registers)
+                w1, b1, _ = pack_geglu(w0, b0, FFN_CHUNK)
+                w[p + ".ffn.w1"], w[p + ".ffn.b1"] = TiledW(w1.to(bf).contiguous()), b1.contiguous()
+                if ln is not None and self.ffn_ln:
+                    gamma, beta = self._t(sd, ln + ".weight"), self._t(sd, ln + ".bias")
+                    w1, b1, _ = pack_geglu(w0 * gamma[None, :], w0 @ beta + b0, FFN_CHUNK)
+                    w[p + ".ffn.w1ln"], w[p + ".ffn.b1ln"] = TiledW(w1.to(bf).contiguous()), b1.contiguous()
 
         def transformer(p):
             norm(p + ".norm"); lin(p + ".proj_in"); lin(p + ".proj_out")
@@ -283,6 +298,9 @@ class UNetHIP:
                 if (k.endswith(".weight") and torch.is_tensor(t_) and t_.dim() == 2 and t_.dtype == bf
                         and t_.shape[1] % 64 == 0 and not k.endswith(".attn1.to_v.weight") and ".fused." not in k):
                     w[k] = TiledW(t_)
+        for k in list(w):   # the fused FeedForward kernel streams W2 tiled whatever the A/B knob above says
+            if k.endswith(".ffn.w1") and torch.is_tensor(w[k[:-len("ffn.w1")] + "net.2.weight"]):
+                w[k[:-len("ffn.w1")] + "net.2.weight"] = TiledW(w[k[:-len("ffn.w1")] + "net.2.weight"])
         # frame-position embeddings depend only on the frame index -> computed once (transformer_temporal.py:329-339)
         T = cfg.num_frames
         self.pos_emb_T: Dict[str, torch.Tensor] = {}
@@ -341,6 +359,16 @@ class UNetHIP:
         """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue.
         ln_input: the RAW input of the LayerNorm in front of this FeedForward — given instead of `a` (= None) where the
         norm is folded into the projection (`_fold_ln`)."""
+        if (p + ".ffn.w1") in self.w:     # C = 320: ONE kernel, the [M, 4C] hidden tensor never exists (ffn.hip)
+            ln = ln_input is not None
+            assert not ln or (p + ".ffn.w1ln") in self.w
+            out = self._empty(M, Cn)
+            kw = {k: v for k, v in epi_kw.items() if k in ("rowvec", "rowvec_ld", "rows_per_vec", "res1", "ldr1", "beta1",
+                                                           "res2", "ldr2", "beta2", "alpha")}
+            assert len(kw) == len(epi_kw), f"unsupported FeedForward epilogue arguments: {set(epi_kw) - set(kw)}"
+            return self.hip.ffn_geglu(ln_input if ln else a, self.w[p + (".ffn.w1ln" if ln else ".ffn.w1")],
+                                      self.w[p + (".ffn.b1ln" if ln else ".ffn.b1")], self.w[p + ".net.2.weight"],
+                                      self.w[p + ".net.2.bias"], out, M, ln=ln, ln_eps=1e-5, **kw)
         g = self._empty(M, 4 * Cn)
         if ln_input is not None:
             W1 = self.w[p + ".net.0.proj.lnfold.weight"]
@@ -447,7 +475,7 @@ class UNetHIP:
         # LayerNorm folded into its consumer GEMM where that GEMM runs on the 256x160 tile (`_fold_ln`): the projection
         # reads the RAW residual stream, the kernel derives mean / rstd of its rows from the operand fragments
         fold_qkv = (b + ".attn1.to_qkv.lnfold.weight") in w and not self.swapped_vt
-        fold_ff = (b + ".ff.net.0.proj.lnfold.weight") in w and not legacy
+        fold_ff = ((b + ".ff.net.0.proj.lnfold.weight") in w or (b + ".ff.ffn.w1ln") in w) and not legacy
         a = xn
         if not fold_qkv:
             a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
