@@ -34,19 +34,38 @@
 
 #include "common.h"
 
+#ifndef FFN_P2_PRIO
+#define FFN_P2_PRIO 0   // s_setprio of the Y-waves' phase-2 MFMA stream (A/B knob)
+#endif
+#ifndef FFN_GE_PRIO
+#define FFN_GE_PRIO 0   // s_setprio of the H-waves' GEGLU segment (A/B knob)
+#endif
+#ifndef FFN_ABLATE
+#define FFN_ABLATE 0   // timing-only builds (tools/build_variant.py): 1 no GELU math, 2 no phase-2 MFMAs, 3 no LDS-DMA, 4 no phase-1 MFMAs
+#endif
+
 namespace {
 
 constexpr int C = 320, HID = 1280, HC = 64, NCH = HID / HC;      // 20 hidden chunks
 constexpr int BM = 128, BK = 64, NKT = C / BK;                   // 5 K tiles per chunk
 constexpr int KS = C / 32;                                       // 10 k-steps of 32 over X's K
-constexpr int RING_STAGES = 3, RING_STAGE_BYTES = 2 * HC * BK * 2;   // W1 K tile: 128 rows x 64 k = 16 KiB
-constexpr int W2_OFF = RING_STAGES * RING_STAGE_BYTES;           // 49152
+#ifndef FFN_RING
+#define FFN_RING 5
+#endif
+constexpr int RING_STAGES = FFN_RING, LEAD = RING_STAGES - 1;     // W1 K tiles: issued LEAD slots before they are read
+constexpr int RING_STAGE_BYTES = 2 * HC * BK * 2;                 // one W1 K tile: 128 rows x 64 k = 16 KiB
+constexpr int W2_OFF = RING_STAGES * RING_STAGE_BYTES;           // 81920
 constexpr int W2_BYTES = C * HC * 2;                             // 320 rows x 64 k = 40 KiB
-constexpr int H_OFF = W2_OFF + W2_BYTES;                         // 90112
+constexpr int H_OFF = W2_OFF + W2_BYTES;                         // 122880
 constexpr int H_BYTES = BM * HC * 2;                             // 16 KiB per parity
-constexpr int BIAS_OFF = H_OFF + 2 * H_BYTES;                    // 122880
+constexpr int BIAS_OFF = H_OFF + 2 * H_BYTES;                    // 155648
 constexpr int BIAS_BYTES = 2 * HC * 4;                           // 512 B per parity
-constexpr int SMEM = BIAS_OFF + 2 * BIAS_BYTES;                  // 123904
+constexpr int SMEM = BIAS_OFF + 2 * BIAS_BYTES;                  // 156672 of the 163840 bytes of a CU
+#ifdef WIW_FFN_TRACE
+constexpr int SMEM_LAUNCH = SMEM + 1024;                         // + the trace stamps
+#else
+constexpr int SMEM_LAUNCH = SMEM;
+#endif
 constexpr int STG_ROWB = 336;                                    // epilogue staging: 160 columns + 16 B skew
 constexpr int STG_WAVE = 16 * STG_ROWB;                          // 5376 B per Y-wave, inside the W2 buffer
 static_assert(4 * STG_WAVE <= W2_BYTES, "epilogue staging must fit in the W2 buffer");
@@ -59,6 +78,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // that bookkeeping: its completion is counted by hand (wait_vmcnt below), exactly as for the builtin.  M0 carries the LDS
 // address and is saved / restored inside the statement (the compiler does not preserve it around asm).
 WIW_DEV void glds16(const char* g, char* l) {
+#if FFN_ABLATE == 3
+    asm volatile("" ::"v"(g), "s"(l));
+    return;
+#endif
     const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)l);
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -66,6 +89,42 @@ WIW_DEV void glds16(const char* g, char* l) {
 }
 template <int N>
 WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+WIW_DEV void wait_vmcnt_rt(int n) {   // wave-uniform n (s_waitcnt takes an immediate)
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        case 17: wait_vmcnt<17>(); break;
+        case 18: wait_vmcnt<18>(); break;
+        case 19: wait_vmcnt<19>(); break;
+        case 20: wait_vmcnt<20>(); break;
+        case 21: wait_vmcnt<21>(); break;
+        case 22: wait_vmcnt<22>(); break;
+        case 23: wait_vmcnt<23>(); break;
+        case 24: wait_vmcnt<24>(); break;
+        case 25: wait_vmcnt<25>(); break;
+        case 26: wait_vmcnt<26>(); break;
+        case 27: wait_vmcnt<27>(); break;
+        case 28: wait_vmcnt<28>(); break;
+        case 29: wait_vmcnt<29>(); break;
+        case 30: wait_vmcnt<30>(); break;
+        default: wait_vmcnt<31>(); break;
+    }
+}
 WIW_DEV void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -77,6 +136,76 @@ WIW_DEV void slot_barrier() {   // this wave's LDS accesses are retired, then re
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifdef WIW_FFN_TRACE   // debug build: block 0 stamps s_memtime at the slot boundaries of two steady-state chunks (waves 0 and 4)
+__device__ long long g_ftrace[2][64];
+__device__ unsigned g_fhwid[8];
+constexpr int TR_CC0 = 23, TR_NCC = 2;   // chunks 3 and 4 of the block's second tile
+// (stamps go to LDS and are copied out at the end: a global store per stamp sits in the vmcnt queue the Y-waves' counted
+// waits watch, and made every slot look ~500 cycles longer)
+#define FTP(role, idx)                                                                                           \
+    do {                                                                                                         \
+        if (trace_blk && cc >= TR_CC0 && cc < TR_CC0 + TR_NCC)                                                   \
+            *(volatile long long*)(smem + SMEM + ((role) * 64 + (cc - TR_CC0) * 32 + (idx)) * 8) = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define FTP(role, idx) do { } while (0)
+#endif
+
+// gelu_erf_f of common.h (exact-erf GELU, Abramowitz-Stegun 7.1.26, same arithmetic bit for bit) on EIGHT values as four
+// PACKED pairs, breadth first.  Why (tools/ubench/valu_rate.hip, tools/ffn_trace.py): one wave issues at most one VALU
+// instruction per ~5.4 cycles (8.5 when it depends on the previous one, ~9 for v_exp / v_rcp) whether it is packed or not
+// and whether or not a second wave shares the SIMD — so the cost of the GEGLU is its INSTRUCTION COUNT times 5.4 if every
+// stage has independent work, and v_pk_* halves the count.  Evaluated value by value (a loop over gelu_erf_f) the 32
+// values of a wave took 3.8 k cycles, dependent-chain-bound.
+//   REGP4: an empty asm statement that reads and writes the four pairs of a stage — every pair exists in its own registers
+//   there and nothing of the next stage can be computed before it (source order and sched_barrier do not survive
+//   instruction selection for pure arithmetic).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define REGP4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+WIW_DEV f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
+WIW_DEV void gelu_erf8(float (&x)[8]) {
+    f32x2_t xv[4], ax[4], z[4], t[4], e[4], poly[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xv[i] = f32x2_t{x[2 * i], x[2 * i + 1]};
+        ax[i] = f32x2_t{fabsf(x[2 * i]), fabsf(x[2 * i + 1])};
+        z[i] = ax[i] * 0.70710678118654752f;
+    }
+    REGP4(z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { t[i] = pk_fma(f32x2_t{0.3275911f, 0.3275911f}, z[i], f32x2_t{1.0f, 1.0f}); e[i] = (z[i] * -1.4426950408889634f) * z[i]; }
+    REGP4(t); REGP4(e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] = f32x2_t{__builtin_amdgcn_rcpf(t[i].x), __builtin_amdgcn_rcpf(t[i].y)};
+        e[i] = f32x2_t{__builtin_amdgcn_exp2f(e[i].x), __builtin_amdgcn_exp2f(e[i].y)};
+    }
+    REGP4(t); REGP4(e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(f32x2_t{1.061405429f, 1.061405429f}, t[i], f32x2_t{-1.453152027f, -1.453152027f});
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{1.421413741f, 1.421413741f});
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{-0.284496736f, -0.284496736f});
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{0.254829592f, 0.254829592f});
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = -poly[i] * t[i];
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], e[i], f32x2_t{1.0f, 1.0f});     // erf|x|
+    REGP4(poly);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = pk_fma(ax[i], poly[i], xv[i]) * 0.5f;
+    REGP4(xv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = xv[i].x; x[2 * i + 1] = xv[i].y; }
 }
 
 struct FfnArgs {
@@ -105,6 +234,10 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
     if ((int)blockIdx.x >= ntiles) return;
     const int ntl = (ntiles - (int)blockIdx.x + nb - 1) / nb;   // tiles of this block: blockIdx.x + i * nb
     const int NC = ntl * NCH;                                   // chunks of this block; H-waves at chunk cc, Y-waves at cc - 1
+#ifdef WIW_FFN_TRACE
+    const bool trace_blk = blockIdx.x == 0 && lane == 0 && (wave & 3) == 0;
+    if (blockIdx.x == 0 && lane == 0) g_fhwid[wave] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[15:0]
+#endif
 
     if (wave < 4) {
         // =====================================================================================================
@@ -169,7 +302,19 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) fb[ni] = *(const bf16x8*)(s + ni * 2048);
         };
+        auto mma1 = [&](const bf16x8& f, const bf16x8& x0, const bf16x8& x1, int ni) {   // one W1 fragment x both row blocks
+#if FFN_ABLATE == 4
+            asm volatile("" ::"v"(f), "v"(x0), "v"(x1));
+            return;
+#endif
+            acc[0][ni] = WIW_MFMA(f, x0, acc[0][ni]);
+            acc[1][ni] = WIW_MFMA(f, x1, acc[1][ni]);
+        };
         auto mma = [&](const bf16x8* fb, const bf16x8& x0, const bf16x8& x1) {
+#if FFN_ABLATE == 4
+            asm volatile("" ::"v"(fb[0]), "v"(fb[7]), "v"(x0), "v"(x1));
+            return;
+#endif
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni) {
@@ -197,17 +342,45 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             // first fragment reads, so the matrix pipe is not idle while a slot's first reads are in flight.
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+                FTP(0, 2 * kt);          // end of the previous slot's work
                 slot_barrier();
-                read_w1(fbA, st, sw0);
-                if (kt > 0) mma(fbB, xa[0][2 * kt - 1], xa[1][2 * kt - 1]);
-                read_w1(fbB, st, sw1);
-                mma(fbA, xa[0][2 * kt], xa[1][2 * kt]);
+                FTP(0, 2 * kt + 1);      // barrier passed
+                // two halves of [2 MFMAs | 1 ds_read_b128] x 8, order pinned: the first half runs the PENDING k-step (fragments
+                // fbB of the previous slot) while this K tile's k-step-0 fragments arrive, the second half runs k-step 0 while
+                // the k-step-1 fragments arrive — the reads' issue slots sit inside the MFMAs' pipe time (left alone the
+                // compiler issues 8 reads, then 16 MFMAs: 64 issue cycles per half with the matrix pipe draining)
+                {
+                    const char* sp = smem + st * RING_STAGE_BYTES + frow * 128;
+                    if (kt > 0) {
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int ni = 0; ni < 8; ++ni) {
+                            mma1(fbB[ni], xa[0][2 * kt - 1], xa[1][2 * kt - 1], ni);
+                            fbA[ni] = *(const bf16x8*)(sp + sw0 + ni * 2048);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+                        read_w1(fbA, st, sw0);
+                        __builtin_amdgcn_s_setprio(1);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni) {
+                        mma1(fbA[ni], xa[0][2 * kt], xa[1][2 * kt], ni);
+                        fbB[ni] = *(const bf16x8*)(sp + sw1 + ni * 2048);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
                 st = st + 1 == RING_STAGES ? 0 : st + 1;
             }
             // ---- slot 5: last k-step, then the GEGLU on the VALU while the Y-wave of this SIMD runs phase 2 of chunk cc - 1
+            FTP(0, 10);
             slot_barrier();
+            FTP(0, 11);
             mma(fbB, xa[0][KS - 1], xa[1][KS - 1]);
+            FTP(0, 12);              // last k-step issued
             if (c == NCH - 1 && ti + 1 < ntl) load_x(blockIdx.x + (ti + 1) * nb);   // X of the next tile: latency under the GEGLU
+            if (FFN_GE_PRIO) __builtin_amdgcn_s_setprio(FFN_GE_PRIO);
             {
                 const char* bs = smem + BIAS_OFF + (cc & 1) * BIAS_BYTES;
                 char* hb = smem + H_OFF + (cc & 1) * H_BYTES;
@@ -215,23 +388,35 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 for (int ni = 0; ni < 4; ++ni) {
                     const float4 bv = *(const float4*)(bs + (ni * 16 + fq * 4) * 4);
                     const float4 bg = *(const float4*)(bs + (HC + ni * 16 + fq * 4) * 4);
+                    // the 8 gate values of (ni; mi = 0, 1) go through the GELU together, stage by stage (gelu_erf8)
+                    float g8[8] = {acc[0][ni + 4][0] + bg.x, acc[0][ni + 4][1] + bg.y, acc[0][ni + 4][2] + bg.z, acc[0][ni + 4][3] + bg.w,
+                                   acc[1][ni + 4][0] + bg.x, acc[1][ni + 4][1] + bg.y, acc[1][ni + 4][2] + bg.z, acc[1][ni + 4][3] + bg.w};
+#if FFN_ABLATE != 1
+                    gelu_erf8(g8);
+#endif
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) {
-                        const f32x4 v = acc[mi][ni], g = acc[mi][ni + 4];
+                        const f32x4 v = acc[mi][ni];
                         uint2 pk;
-                        pk.x = pack2bf((v[0] + bv.x) * gelu_erf_f(g[0] + bg.x), (v[1] + bv.y) * gelu_erf_f(g[1] + bg.y));
-                        pk.y = pack2bf((v[2] + bv.z) * gelu_erf_f(g[2] + bg.z), (v[3] + bv.w) * gelu_erf_f(g[3] + bg.w));
+                        pk.x = pack2bf((v[0] + bv.x) * g8[4 * mi], (v[1] + bv.y) * g8[4 * mi + 1]);
+                        pk.y = pack2bf((v[2] + bv.z) * g8[4 * mi + 2], (v[3] + bv.w) * g8[4 * mi + 3]);
                         // H[row][16*ni + 4*fq .. +3]: 16-byte chunk 2*ni + (fq >> 1) of the row, swizzled like every K tile
                         const int row = wq * 32 + mi * 16 + frow;
                         *(uint2*)(hb + row * 128 + (((2 * ni + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
                     }
+                    FTP(0, 20 + ni);
                 }
             }
+            if (FFN_GE_PRIO) __builtin_amdgcn_s_setprio(0);
+            FTP(0, 13);              // GEGLU done, H written
             // tile-end barrier: in this iteration the Y-waves finished a tile (its last chunk is cc - 1) and stage its
             // epilogue in the W2 buffer, which every Y-wave must have stopped reading first
             if (c == 0 && cc >= 1) slot_barrier();
             if (++c == NCH) { c = 0; ++ti; }
         }
+#ifdef WIW_FFN_TRACE
+        if (trace_blk) for (int i = 0; i < 64; ++i) g_ftrace[0][i] = *(volatile long long*)(smem + SMEM + i * 8);
+#endif
     } else {
         // =====================================================================================================
         // Y-waves: all LDS-DMA of the block, phase 2, tile epilogue
@@ -255,10 +440,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             ld_st = ld_st + 1 == RING_STAGES ? 0 : ld_st + 1;
             --ld_left;
         };
-        // prologue: K tiles 0 and 1
-        issue_w1();
-        issue_w1();
-        wait_vmcnt<4>();
+        // prologue: K tiles 0 .. LEAD-1 (NC >= 20 chunks: they exist); tile 0 has landed when <= 4 * (LEAD - 1) are outstanding
+#pragma unroll
+        for (int i = 0; i < LEAD; ++i) issue_w1();
+        wait_vmcnt<4 * (LEAD - 1)>();
+        int h1 = LEAD >= 3 ? 4 : 0, h2 = LEAD >= 4 ? 4 : 0;   // DMA instructions issued in the previous two DMA slots (prologue tiles)
 
         const int sw0 = (fq ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;
         int c = 0;   // chunk (inside its tile) the H-waves work on in this iteration; this wave works on chunk c - 1
@@ -267,29 +453,43 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             const int c2 = c == 0 ? NCH - 1 : c - 1;   // chunk of phase 2 in this iteration (valid for cc >= 1)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+                FTP(1, 3 * kt);          // end of the previous slot's work
                 slot_barrier();
-                // bias chunk of the H-waves' current chunk (512 B; read by them in slot 5 of this iteration)
-                if (kt == 0 && cc < NC && wq == 0) {
-                    if (lane < 32) glds16((const char*)p.b1 + c * (2 * HC * 4) + lane * 16, smem + BIAS_OFF + (cc & 1) * BIAS_BYTES);
+                FTP(1, 3 * kt + 1);      // barrier passed
+                // The W1 K tile the H-waves read in slot d + 1 was issued LEAD - 1 = 3 DMA slots before slot d: at the end of a
+                // slot only what was issued more than two slots ago has to have landed (an LDS-DMA takes ~1.5 k cycles from
+                // issue to landed under this kernel's load: with a two-slot lead every slot ended in a 200-350 cycle vmcnt
+                // wait, tools/ffn_trace.py).  W2 chunk c2 (40 blocks of 1 KiB, consumed in slot 5) goes out in slots 0..2 as
+                // 4 | 3 | 3 blocks per wave (slot 4 therefore waits for everything older than ONE slot), the bias chunk of the
+                // H-waves' current chunk (512 B, read by them in slot 5) as 128 B per wave in slot 0.
+                int h0 = 0;
+                if (kt == 0 && cc < NC) {
+                    if (lane < 8) glds16((const char*)p.b1 + c * (2 * HC * 4) + wq * 128 + lane * 16,
+                                         smem + BIAS_OFF + (cc & 1) * BIAS_BYTES + wq * 128);
+                    h0 += 1;
                 }
-                // W2 chunk c2, rows 64*kt .. +63 (8 blocks of 1 KiB, 2 per Y-wave): consumed in slot 5 of this iteration
-                if (cc >= 1) {
-                    const int rb = kt * 8 + wq * 2;
+                if (cc >= 1 && kt < 3) {
+                    const int NB2 = kt == 0 ? 4 : 3;              // blocks per wave in this slot (kt is unrolled)
+                    const int RB0 = kt == 0 ? 0 : 16 + (kt - 1) * 12;   // first block of this slot: 0 | 16 | 28
+                    const int rb = RB0 + wq * NB2;
                     const char* src = W2b + ((int64_t)rb * NCH + c2) * 1024 + lane * 16;
                     char* dst = smem + W2_OFF + rb * 1024;
-                    glds16(src, dst);
-                    glds16(src + (int64_t)NCH * 1024, dst + 1024);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < NB2) glds16(src + (int64_t)i * NCH * 1024, dst + i * 1024);
+                    h0 += NB2;
                 }
-                // W1 K tile two slots ahead of the one the H-waves read now; everything issued before it must have landed
-                // at the end of this slot (the K tile of the NEXT slot, this slot's W2 part, the bias chunk)
-                if (ld_left > 0) {
+                if (ld_left > 0) {   // W1 K tile LEAD slots ahead of the one the H-waves read now
                     issue_w1();
-                    wait_vmcnt<4>();
-                } else {
-                    wait_vmcnt<0>();
+                    h0 += 4;
                 }
+                FTP(1, 3 * kt + 2);  // DMA issued
+                wait_vmcnt_rt(h0 + (LEAD >= 3 ? h1 : 0) + (LEAD >= 4 && kt != 4 ? h2 : 0));
+                h2 = h1; h1 = h0;
             }
+            FTP(1, 15);
             slot_barrier();
+            FTP(1, 16);
             if (cc >= 1) {
                 // ---- phase 2 of chunk c2: Y += H . W2c^T  (H of the previous iteration, parity (cc - 1) & 1)
                 const char* hb = smem + H_OFF + ((cc - 1) & 1) * H_BYTES + (wq * 32 + frow) * 128;
@@ -307,16 +507,25 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 bf16x8 wf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) wf[j] = wread(j);
-                __builtin_amdgcn_s_setprio(1);
+                // NO s_setprio here: with this wave at priority 1 the H-wave of the SIMD — evaluating the GEGLU on the VALU at
+                // the same time — is starved (its 1.6 k cycles of VALU work ran only AFTER these 80 MFMAs: 4.3 k cycles for the
+                // slot, tools/ffn_trace.py); at equal priority the older H-wave keeps its issue slots and the MFMAs, one issue
+                // per 16 cycles, take the rest
+                __builtin_amdgcn_s_setprio(FFN_P2_PRIO);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 40; ++j) {
+#if FFN_ABLATE == 2
+                    asm volatile("" ::"v"(wf[j & 7]), "v"(hf[0][j / 20]), "v"(hf[1][j / 20]));
+#else
                     accY[0][j % 20] = WIW_MFMA(wf[j & 7], hf[0][j / 20], accY[0][j % 20]);
                     accY[1][j % 20] = WIW_MFMA(wf[j & 7], hf[1][j / 20], accY[1][j % 20]);
+#endif
                     if (j + 8 < 40) wf[j & 7] = wread(j + 8);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
+                FTP(1, 17);          // phase 2 issued
                 if (c2 == NCH - 1) {
                     // ---- tile epilogue: 4 passes of 16 rows x 160 columns through a per-wave LDS transpose staged in the
                     // W2 buffer (free once EVERY Y-wave is through phase 2 — the tile-end barrier — until the next slot's
@@ -413,10 +622,22 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             }
             c = c + 1 == NCH ? 0 : c + 1;
         }
+#ifdef WIW_FFN_TRACE
+        if (trace_blk) for (int i = 0; i < 64; ++i) g_ftrace[1][i] = *(volatile long long*)(smem + SMEM + (64 + i) * 8);
+#endif
     }
 }
 
 }  // namespace
+
+#ifdef WIW_FFN_TRACE
+extern "C" int wiw_ffn_trace_read(long long* out) {   // debug builds only: copy the slot-boundary timestamps to the host
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ftrace), sizeof(long long) * 2 * 64) == hipSuccess ? 0 : -1;
+}
+extern "C" int wiw_ffn_hwid_read(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fhwid), sizeof(unsigned) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
                                   const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
@@ -436,7 +657,7 @@ extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const vo
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_LAUNCH) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -454,6 +675,6 @@ extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const vo
     a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2; a.ln_eps = ln_eps;
     const int tiles = (int)((M + BM - 1) / BM);
     const int grid = tiles < num_cu ? tiles : num_cu;
-    hipLaunchKernelGGL(ffn_kernel, dim3((unsigned)grid), dim3(512), SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ffn_kernel, dim3((unsigned)grid), dim3(512), SMEM_LAUNCH, (hipStream_t)stream, a);
     return wiw_check_launch("wiw_ffn_geglu_bf16");
 }
