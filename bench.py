@@ -46,6 +46,20 @@ def synth_actions(B, T):
     return np.tile(np.array(base, dtype=np.int64), (B, 1))
 
 
+def _cpu_model() -> str:
+    """Host CPU model string (SURVEY 8d asks for it next to the core count)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(sd_cpu, cfg, threads, device=None, dtype=None):
     """Oracle ("port") on the host cores: ONE fp32 UNet forward of BASELINE config 0 (256x256x8, CFG on)
     = 1/10 of its 10-step rollout; frames/s extrapolated as 8 / (10 * t_forward).  With `device` given the HIP path
@@ -69,7 +83,7 @@ def cpu_baseline(sd_cpu, cfg, threads, device=None, dtype=None):
         ref = O.unet_forward(sd_cpu, ocfg, sample, torch.tensor(1.0), ehs, tids, aid)
     dt = time.time() - t0
     res = {"value": round(8.0 / (10.0 * dt), 5), "unit": "frames/s", "cores": threads, "kind": "port",
-           "seconds_per_forward": round(dt, 3),
+           "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "seconds_per_forward": round(dt, 3),
            "sample": "1 of the 10 UNet forwards (CFG batch 2, fp32, full-size weights) of BASELINE config 0 "
                      "(256x256x8, 10 steps); frames/s = 8 / (10 * t_forward)"}
     if device is not None:
@@ -350,7 +364,7 @@ def train_bench(args, rank, world, device):
     net = UNetTrain(cfg, random_state_dict_torch(cfg, 0, device, torch.float32), device, dtype=dtype)
     opt = None
     if world > 1:
-        opt = ShardedAdamW({k: tuple(v.shape) for k, v in net.master.items()}, device,
+        opt = ShardedAdamW(Trainer.optimizer_shapes(net), device,   # trainable AND live parameters only
                            lambda p, g, m, v, step, lr, b1, b2, eps, wd: net.hip.adamw_step(p, g, m, v, step, lr, b1, b2, eps, wd),
                            lr=1e-5)
     tr = Trainer(net, lr=1e-5, optimizer=opt, autotune=not args.no_autotune)

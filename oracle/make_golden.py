@@ -236,6 +236,26 @@ def gen_schema(ns):
         json.dump({"n_tensors": len(schema), "n_params": int(sum(int(np.prod(v)) for v in schema.values())),
                    "tensors": schema}, f, separators=(",", ":"))
     print(f"wrote {path}: {len(schema)} tensors")
+    # ... and the `unet/config.json` the reference's `save_pretrained` writes next to the weights (what its own
+    # `from_pretrained(<dir>, subfolder="unet")` needs, train_svd.py:586-600, eval_inference.py:115-131): served width + the
+    # tiny width of the fixtures.  `save_config` only: no weights are materialised.
+    import tempfile
+
+    cfgs = {"unet_config.json": (m, cfg)}
+    tcfg = UNetConfig.tiny(4)
+    with torch.device("meta"):
+        cfgs["unet_config_tiny.json"] = (ns.UNet(block_out_channels=tcfg.block_out_channels,
+                                                 num_attention_heads=tcfg.num_attention_heads, num_frames=tcfg.num_frames,
+                                                 action_strategy="micro_cond", task_type="navigation",
+                                                 action_input_channel=tcfg.action_input_channel), tcfg)
+    for name, (model, _) in cfgs.items():
+        with tempfile.TemporaryDirectory() as d:
+            model.save_config(d)
+            with open(os.path.join(d, "config.json")) as f:
+                txt = f.read()
+        with open(os.path.join(OUT, name), "w") as f:
+            f.write(txt)
+        print(f"wrote {os.path.join(OUT, name)}")
 
 
 def gen_pipeline(ns):

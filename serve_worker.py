@@ -8,8 +8,9 @@ or a standalone TCP server with --port (client protocol of downstream/solver_bas
     python serve_worker.py --random_weights --port 7000          # no checkpoints: random-init weights (bring-up)
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 serve_worker.py --port 7000 ...   # one request over 8 GPUs
 
-The denoising loop and the VAE encode / decode run on the hand-written HIP path (libwiwsvd.so; no fallback);
-the CLIP image encoder is the third-party `transformers` module the reference uses, on PyTorch-ROCm.
+Everything between request ingest and the uint8 frames runs on the hand-written HIP path (libwiwsvd.so; no fallback): the
+CLIP ViT-H/14 image encoder (`clip.CLIPVisionHIP` — the `transformers` module is only the container its weights are read
+from), the VAE encoder, the denoising loop and the temporal VAE decoder.
 """
 from __future__ import annotations
 
@@ -99,8 +100,9 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
     unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype)
     den = SVDDenoiser(unet)
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)
-    # VAE on the HIP kernels (vae.py); CLIP is the reference's third-party module.  There is no PyTorch / MIOpen VAE
-    # route in the product (it needed > 6 minutes per decode on a fresh box); the fp32 PyTorch chain lives in oracle/.
+    # VAE and CLIP on the HIP kernels (vae.py, clip.py: HIPFrontend builds `CLIPVisionHIP` from the `transformers` module's
+    # weights).  There is no PyTorch / MIOpen route in the product (the VAE alone needed > 6 minutes per decode on a fresh
+    # box); the fp32 PyTorch chain lives in oracle/.
     fe = HIPFrontend(VAEHIP(vae_sd, args.device, hip=unet.hip, **vae_cfg), clip, dtype=dtype, device_io=True)
 
     def denoise(image_latents, image_embeddings, noise, actions, **kw):

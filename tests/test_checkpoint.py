@@ -55,3 +55,19 @@ def test_sharded_optimizer_files_are_per_rank(tmp_path):
     for rank in (0, 1):
         _, o, meta = C.load_checkpoint(os.path.join(out, "checkpoint-10"), rank=rank, sharded=True)
         assert meta["world"] == 2 and float(o["master"][0]) == float(rank)
+
+
+def test_unet_config_json_is_the_file_the_reference_writes(tmp_path):
+    """`unet/config.json` next to the weights, byte for byte what the reference's own `save_pretrained` / `save_config` writes
+    (tests/golden/unet_config*.json: produced by running the reference class, oracle/make_golden.py `schema`), so its
+    `from_pretrained(<dir>, subfolder="unet", ...)` (train_svd.py load hook, eval_inference.py:115-131) finds both files."""
+    from wiw_amd.config import UNetConfig
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for fname, cfg in (("unet_config.json", UNetConfig()), ("unet_config_tiny.json", UNetConfig.tiny(4))):
+        master, optim = _state(5)
+        path = C.save_checkpoint(str(tmp_path / fname), 7, master, optim, {"micro": 0, "loss_scale": 1.0, "world": 1},
+                                 unet_config=C.unet_config_dict(cfg))
+        assert sorted(os.listdir(os.path.join(path, "unet"))) == ["config.json", "diffusion_pytorch_model.safetensors"]
+        with open(os.path.join(path, C.UNET_CONFIG_FILE)) as f, open(os.path.join(golden, fname)) as g:
+            assert f.read() == g.read()

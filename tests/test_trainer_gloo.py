@@ -204,3 +204,102 @@ def test_sharded_adamw_bucket_layout_properties():
         run()
     finally:
         dist.destroy_process_group()
+
+
+def test_dead_parameter_rule_matches_the_reference_autograd():
+    """`Trainer.is_dead` (which parameters an optimiser must NOT hold: torch.optim.AdamW never touches a parameter without a
+    gradient, a flat optimiser over everything would weight-decay it) against the gradient norms of the reference's own
+    `loss.backward()` (tests/golden/train_step_tiny.npz): dead <=> the reference gradient is (round-off) zero."""
+    import numpy as np
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.train_unet import Trainer
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train_step_tiny.npz"), allow_pickle=True)
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    med = float(np.median(norms[norms > 0]))
+    dead = [n for n in names if Trainer.is_dead(n)]
+    assert len(dead) == 132
+    for n, nr in zip(names, norms):      # dead: autograd round-off only (<= 1e-9); live: a gradient (a scalar mix_factor may be 1e-8)
+        assert (nr <= 5e-9) if Trainer.is_dead(n) else (nr >= 1e-8), (n, nr, med)      # (median live norm: 5.7e-4)
+
+    class _Net:
+        master = {n: torch.zeros(1) for n in names}
+    full = Trainer.optimizer_shapes(_Net, "full")
+    assert set(full) == set(names) - set(dead) and list(full) == [n for n in names if n in full]      # model order kept
+    new = Trainer.optimizer_shapes(_Net, "new")
+    assert new and all(("action" in n) or ("noise" in n) for n in new)
+
+
+def _subset_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import conftest  # noqa: F401  (registers the package alias)
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.parallel import ShardedAdamW
+    from wiw_amd.train_unet import Trainer
+
+    class _TrainStep:                      # the EDM loss kernel is not part of this test
+        def __init__(self, hip):
+            pass
+
+        def loss_and_grad(self, pred, st):
+            return torch.tensor(1.0), torch.zeros(1)
+    T.TrainStep = _TrainStep
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = _StubNet()
+        shapes = {k: tuple(v.shape) for k, v in net.master.items() if k != "frozen.weight"}     # the optimiser holds a SUBSET
+        opt = ShardedAdamW(shapes, torch.device("cpu"), _adamw_torch, bucket_elems=256, lr=1e-2, weight_decay=0.5)
+        tr = Trainer(net, lr=1e-2, weight_decay=0.5, optimizer=opt, loss_scale=4.0, scale_growth_interval=2)
+        frozen0 = net.master["frozen.weight"].clone()
+        assert "frozen.weight" not in opt.offsets and not tr.trainable("frozen.weight") and tr.trainable("a.weight")
+        scales = []
+        for i in range(5):
+            tr.step(_St(0.1 * (i + rank)))
+            scales.append(tr.loss_scale)
+        ok = torch.equal(net.master["frozen.weight"], frozen0) and scales == [4.0, 8.0, 8.0, 16.0, 16.0]    # x2 every 2 good steps
+        # layout fingerprint: same construction -> same hash; another bucket size -> another hash (resume would refuse it)
+        same = ShardedAdamW(shapes, torch.device("cpu"), _adamw_torch, bucket_elems=256).layout_fingerprint() == opt.layout_fingerprint()
+        other = ShardedAdamW(shapes, torch.device("cpu"), _adamw_torch, bucket_elems=512).layout_fingerprint() != opt.layout_fingerprint()
+        import tempfile
+
+        d = tempfile.mkdtemp(prefix=f"ck{rank}_") if rank else None
+        box = [d]
+        dist.broadcast_object_list(box, src=1 if world > 1 else 0)
+        out = box[0] or tempfile.mkdtemp()
+        path = tr.save(out)
+        dist.barrier()
+        tr.load(path)                                                   # same layout: accepted
+        net3 = _StubNet()
+        tr3 = Trainer(net3, lr=1e-2, optimizer=ShardedAdamW(shapes, torch.device("cpu"), _adamw_torch, bucket_elems=512), loss_scale=4.0)
+        refused = False
+        try:
+            tr3.load(path)
+        except AssertionError as e:
+            refused = "flat layout" in str(e)
+        q.put((rank, ok, same, other, refused, tr.loss_scale))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_optimizer_subset_loss_scale_growth_and_layout_fingerprint():
+    """(i) a sharded optimiser built from the trainable / live shapes only — the frozen parameter is neither
+    decayed nor read back; (ii) GradScaler-style growth of the fp16 loss scale (x2 after N good steps in a row); (iii) a
+    resume under another flat layout is refused instead of silently permuting optimiser slices."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subset_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, same, other, refused, scale in res:
+        assert ok and same and other and refused and scale == 16.0, (rank, ok, same, other, refused, scale)

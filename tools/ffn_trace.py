@@ -47,8 +47,8 @@ def main():
             nxt = h[2 * kt + 2]
             print(f"   slot {kt}: barrier wait {h[2 * kt + 1] - h[2 * kt]:6d} | work (8 rd, 16 mfma, 8 rd, 16 mfma) {nxt - h[2 * kt + 1]:6d}")
         print(f"   slot 5: barrier wait {h[11] - h[10]:6d} | last 16 mfma {h[12] - h[11]:6d} | GEGLU + H write {h[13] - h[12]:6d}")
-        g = t[0][ch * 32 + 20: ch * 32 + 24]
-        print(f"   GEGLU by ni group (from 'last k-step issued'): {g[0] - h[12]:6d} {g[1] - g[0]:6d} {g[2] - g[1]:6d} {g[3] - g[2]:6d}")
+        g = t[0][ch * 32 + 20: ch * 32 + 22]
+        print(f"   GEGLU by pass of 16 gate values (from 'last k-step issued'): {g[0] - h[12]:6d} {g[1] - g[0]:6d}")
         print(f"   chunk total (slot-0 stamp to GEGLU done): {h[13] - h[0]:6d} cycles")
         print(f"--- chunk {ch}: Y-wave (wave 4)")
         for kt in range(5):

@@ -3,10 +3,13 @@
 Layout (train_svd.py:586-626, 1032-1062 — `accelerator.save_state` with the save hook writing `unet/`):
 
     <output_dir>/checkpoint-<global_step>/
-        unet/diffusion_pytorch_model.safetensors   fp32 master parameters under the reference's parameter names: the file
-                                                   `UNetSpatioTemporalConditionModel.from_pretrained(<dir>/unet)` and this
-                                                   package's serving loader (`weights.load_safetensors`, `serve_worker.py
-                                                   --unet_path`) read
+        unet/config.json                           the config `save_pretrained` writes (train_svd.py:586-600 save hook): with the
+                                                   weights file below, what the reference's own loaders need —
+                                                   `UNetSpatioTemporalConditionModel.from_pretrained(<dir>, subfolder="unet", ...)`
+                                                   (train_svd.py load hook, eval_inference.py:115-131)
+        unet/diffusion_pytorch_model.safetensors   fp32 master parameters under the reference's parameter names; also read by
+                                                   this package's serving loader (`weights.load_safetensors`, `serve_worker.py
+                                                   --unet_path`)
         optimizer.safetensors                      AdamW moments `exp_avg.<name>` / `exp_avg_sq.<name>` (single process), or
         optimizer_rank<r>.safetensors              this rank's ZeRO-1 slices of the flat buffers (`parallel.ShardedAdamW`)
         trainer_state.json                         global_step, micro-batch counter, loss scale, world size
@@ -25,6 +28,33 @@ from typing import Dict, Optional, Tuple
 import torch
 
 UNET_FILE = os.path.join("unet", "diffusion_pytorch_model.safetensors")
+UNET_CONFIG_FILE = os.path.join("unet", "config.json")
+DIFFUSERS_VERSION = "0.31.0"      # the vendored fork's version string (FTsvd/diffusers-private), as it writes it
+
+
+def unet_config_dict(cfg) -> dict:
+    """The `unet/config.json` of `UNetSpatioTemporalConditionModel.save_pretrained` for a `config.UNetConfig`: the
+    registered __init__ arguments (unet_spatio_temporal_condition.py:72-97).  The fork's runtime kwargs (action_strategy,
+    task_type, action_input_channel) are NOT stored there — the reference passes them at load time
+    (eval_inference.py:116-125).  Pinned to files the reference itself wrote: tests/golden/unet_config*.json."""
+    n = len(cfg.block_out_channels)
+    return {
+        "_class_name": "UNetSpatioTemporalConditionModel",
+        "_diffusers_version": DIFFUSERS_VERSION,
+        "addition_time_embed_dim": cfg.addition_time_embed_dim,
+        "block_out_channels": list(cfg.block_out_channels),
+        "cross_attention_dim": cfg.cross_attention_dim,
+        "down_block_types": ["CrossAttnDownBlockSpatioTemporal"] * (n - 1) + ["DownBlockSpatioTemporal"],
+        "in_channels": cfg.in_channels,
+        "layers_per_block": cfg.layers_per_block,
+        "num_attention_heads": list(cfg.num_attention_heads),
+        "num_frames": cfg.num_frames,
+        "out_channels": cfg.out_channels,
+        "projection_class_embeddings_input_dim": cfg.projection_class_embeddings_input_dim,
+        "sample_size": None,
+        "transformer_layers_per_block": 1,
+        "up_block_types": ["UpBlockSpatioTemporal"] + ["CrossAttnUpBlockSpatioTemporal"] * (n - 1),
+    }
 
 
 def _step_of(name: str) -> int:
@@ -64,15 +94,19 @@ def prune(output_dir: str, total_limit: Optional[int]):
 
 def save_checkpoint(output_dir: str, global_step: int, master: Optional[Dict[str, torch.Tensor]],
                     optimizer: Dict[str, torch.Tensor], meta: dict, rank: int = 0, sharded: bool = False,
-                    total_limit: Optional[int] = None) -> str:
+                    total_limit: Optional[int] = None, unet_config: Optional[dict] = None) -> str:
     """Write checkpoint-<global_step>.  master: the fp32 parameters (rank 0 writes them; pass None on other ranks);
-    optimizer: flat name -> tensor dict (this rank's part when sharded).  Returns the directory."""
+    optimizer: flat name -> tensor dict (this rank's part when sharded); unet_config: `unet_config_dict(cfg)`, written as
+    unet/config.json next to the weights (the file set of `save_pretrained`).  Returns the directory."""
     from safetensors.torch import save_file
 
     path = os.path.join(output_dir, f"checkpoint-{global_step}")
     os.makedirs(os.path.join(path, "unet"), exist_ok=True)
     if rank == 0 and master is not None:
         save_file({k: v.detach().to("cpu", torch.float32).contiguous() for k, v in master.items()}, os.path.join(path, UNET_FILE))
+        if unet_config is not None:
+            with open(os.path.join(path, UNET_CONFIG_FILE), "w") as f:       # same formatting as diffusers' to_json_string
+                f.write(json.dumps(unet_config, indent=2, sort_keys=True) + "\n")
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump(dict(meta, global_step=int(global_step)), f, indent=1, sort_keys=True)
     name = f"optimizer_rank{rank}.safetensors" if sharded else "optimizer.safetensors"

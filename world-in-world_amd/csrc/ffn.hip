@@ -87,6 +87,18 @@ WIW_DEV void glds16(const char* g, char* l) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
+// X rows and residual rows are read exactly once by the whole launch: streaming (nt) loads, so that they do not evict the
+// 2.4 MB of weights every CU of the XCD re-reads from its L2 for every tile (A/B knob FFN_PLAIN_LOADS)
+template <typename T>
+WIW_DEV T ld_stream(const T* p) {
+#ifdef FFN_PLAIN_LOADS
+    return *p;
+#else
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(T) == 16, "16-byte loads");
+    return __builtin_bit_cast(T, __builtin_nontemporal_load((const i32x4_t*)p));
+#endif
+}
 template <int N>
 WIW_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 WIW_DEV void wait_vmcnt_rt(int n) {   // wave-uniform n (s_waitcnt takes an immediate)
@@ -159,53 +171,53 @@ constexpr int TR_CC0 = 23, TR_NCC = 2;   // chunks 3 and 4 of the block's second
 // and whether or not a second wave shares the SIMD — so the cost of the GEGLU is its INSTRUCTION COUNT times 5.4 if every
 // stage has independent work, and v_pk_* halves the count.  Evaluated value by value (a loop over gelu_erf_f) the 32
 // values of a wave took 3.8 k cycles, dependent-chain-bound.
-//   REGP4: an empty asm statement that reads and writes the four pairs of a stage — every pair exists in its own registers
+//   REGP8: an empty asm statement that reads and writes the eight pairs of a stage — every pair exists in its own registers
 //   there and nothing of the next stage can be computed before it (source order and sched_barrier do not survive
 //   instruction selection for pure arithmetic).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#define REGP4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define REGP8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 WIW_DEV f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
-WIW_DEV void gelu_erf8(float (&x)[8]) {
-    f32x2_t xv[4], ax[4], z[4], t[4], e[4], poly[4];
+WIW_DEV void gelu_erf16(float (&x)[16]) {   // 8 packed pairs per stage: a stage's issue time (~45 cycles) covers a packed result's latency
+    f32x2_t xv[8], ax[8], z[8], t[8], e[8], poly[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         xv[i] = f32x2_t{x[2 * i], x[2 * i + 1]};
         ax[i] = f32x2_t{fabsf(x[2 * i]), fabsf(x[2 * i + 1])};
         z[i] = ax[i] * 0.70710678118654752f;
     }
-    REGP4(z);
+    REGP8(z);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { t[i] = pk_fma(f32x2_t{0.3275911f, 0.3275911f}, z[i], f32x2_t{1.0f, 1.0f}); e[i] = (z[i] * -1.4426950408889634f) * z[i]; }
-    REGP4(t); REGP4(e);
+    for (int i = 0; i < 8; ++i) { t[i] = pk_fma(f32x2_t{0.3275911f, 0.3275911f}, z[i], f32x2_t{1.0f, 1.0f}); e[i] = (z[i] * -1.4426950408889634f) * z[i]; }
+    REGP8(t); REGP8(e);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
         t[i] = f32x2_t{__builtin_amdgcn_rcpf(t[i].x), __builtin_amdgcn_rcpf(t[i].y)};
         e[i] = f32x2_t{__builtin_amdgcn_exp2f(e[i].x), __builtin_amdgcn_exp2f(e[i].y)};
     }
-    REGP4(t); REGP4(e);
+    REGP8(t); REGP8(e);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(f32x2_t{1.061405429f, 1.061405429f}, t[i], f32x2_t{-1.453152027f, -1.453152027f});
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = pk_fma(f32x2_t{1.061405429f, 1.061405429f}, t[i], f32x2_t{-1.453152027f, -1.453152027f});
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{1.421413741f, 1.421413741f});
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{1.421413741f, 1.421413741f});
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{-0.284496736f, -0.284496736f});
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{-0.284496736f, -0.284496736f});
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{0.254829592f, 0.254829592f});
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = pk_fma(poly[i], t[i], f32x2_t{0.254829592f, 0.254829592f});
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = -poly[i] * t[i];
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = -poly[i] * t[i];
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) poly[i] = pk_fma(poly[i], e[i], f32x2_t{1.0f, 1.0f});     // erf|x|
-    REGP4(poly);
+    for (int i = 0; i < 8; ++i) poly[i] = pk_fma(poly[i], e[i], f32x2_t{1.0f, 1.0f});     // erf|x|
+    REGP8(poly);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xv[i] = pk_fma(ax[i], poly[i], xv[i]) * 0.5f;
-    REGP4(xv);
+    for (int i = 0; i < 8; ++i) xv[i] = pk_fma(ax[i], poly[i], xv[i]) * 0.5f;
+    REGP8(xv);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { x[2 * i] = xv[i].x; x[2 * i + 1] = xv[i].y; }
+    for (int i = 0; i < 8; ++i) { x[2 * i] = xv[i].x; x[2 * i + 1] = xv[i].y; }
 }
 
 struct FfnArgs {
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 m = m < p.M ? m : p.M - 1;   // rows past M are computed on a copy of the last row and never stored
                 const uint16_t* src = p.X + (int64_t)m * p.ldx + fq * 8;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xa[mi][ks] = *(const bf16x8*)(src + ks * 32);
+                for (int ks = 0; ks < KS; ++ks) xa[mi][ks] = ld_stream((const bf16x8*)(src + ks * 32));
             }
         };
         // LayerNorm without its affine (gamma is folded into W1, beta into b1): two passes over the 320 values of a row,
@@ -385,26 +397,39 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 const char* bs = smem + BIAS_OFF + (cc & 1) * BIAS_BYTES;
                 char* hb = smem + H_OFF + (cc & 1) * H_BYTES;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const float4 bv = *(const float4*)(bs + (ni * 16 + fq * 4) * 4);
-                    const float4 bg = *(const float4*)(bs + (HC + ni * 16 + fq * 4) * 4);
-                    // the 8 gate values of (ni; mi = 0, 1) go through the GELU together, stage by stage (gelu_erf8)
-                    float g8[8] = {acc[0][ni + 4][0] + bg.x, acc[0][ni + 4][1] + bg.y, acc[0][ni + 4][2] + bg.z, acc[0][ni + 4][3] + bg.w,
-                                   acc[1][ni + 4][0] + bg.x, acc[1][ni + 4][1] + bg.y, acc[1][ni + 4][2] + bg.z, acc[1][ni + 4][3] + bg.w};
+                for (int np = 0; np < 2; ++np) {      // two 16-column fragments (ni = 2*np, 2*np + 1) per pass: 16 gate values
+                    float4 bv[2], bg[2];
+                    float g16[16];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ni = 2 * np + h;
+                        bv[h] = *(const float4*)(bs + (ni * 16 + fq * 4) * 4);
+                        bg[h] = *(const float4*)(bs + (HC + ni * 16 + fq * 4) * 4);
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            g16[h * 8 + mi * 4 + 0] = acc[mi][ni + 4][0] + bg[h].x; g16[h * 8 + mi * 4 + 1] = acc[mi][ni + 4][1] + bg[h].y;
+                            g16[h * 8 + mi * 4 + 2] = acc[mi][ni + 4][2] + bg[h].z; g16[h * 8 + mi * 4 + 3] = acc[mi][ni + 4][3] + bg[h].w;
+                        }
+                    }
 #if FFN_ABLATE != 1
-                    gelu_erf8(g8);
+                    gelu_erf16(g16);
 #endif
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        const f32x4 v = acc[mi][ni];
-                        uint2 pk;
-                        pk.x = pack2bf((v[0] + bv.x) * g8[4 * mi], (v[1] + bv.y) * g8[4 * mi + 1]);
-                        pk.y = pack2bf((v[2] + bv.z) * g8[4 * mi + 2], (v[3] + bv.w) * g8[4 * mi + 3]);
-                        // H[row][16*ni + 4*fq .. +3]: 16-byte chunk 2*ni + (fq >> 1) of the row, swizzled like every K tile
-                        const int row = wq * 32 + mi * 16 + frow;
-                        *(uint2*)(hb + row * 128 + (((2 * ni + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+                    for (int h = 0; h < 2; ++h) {
+                        const int ni = 2 * np + h;
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            const f32x4 v = acc[mi][ni];
+                            const float* g = g16 + h * 8 + mi * 4;
+                            uint2 pk;
+                            pk.x = pack2bf((v[0] + bv[h].x) * g[0], (v[1] + bv[h].y) * g[1]);
+                            pk.y = pack2bf((v[2] + bv[h].z) * g[2], (v[3] + bv[h].w) * g[3]);
+                            // H[row][16*ni + 4*fq .. +3]: 16-byte chunk 2*ni + (fq >> 1) of the row, swizzled like every K tile
+                            const int row = wq * 32 + mi * 16 + frow;
+                            *(uint2*)(hb + row * 128 + (((2 * ni + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+                        }
                     }
-                    FTP(0, 20 + ni);
+                    FTP(0, 20 + np);
                 }
             }
             if (FFN_GE_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -555,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                             for (int k = 0; k < 6; ++k) {
                                 int m = mp0 + (lrow + k * 3 < 16 ? lrow + k * 3 : 15);
                                 m = m < p.M ? m : p.M - 1;
-                                q1[k] = *(const uint4*)(p.res1 + (int64_t)m * p.ldr1 + ncol);
+                                q1[k] = ld_stream((const uint4*)(p.res1 + (int64_t)m * p.ldr1 + ncol));
                             }
                         }
                         char* wrow = stg + frow * STG_ROWB + fq * 8;
@@ -572,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                             for (int k = 0; k < 6; ++k) {
                                 int m = mp0 + (lrow + k * 3 < 16 ? lrow + k * 3 : 15);
                                 m = m < p.M ? m : p.M - 1;
-                                q2[k] = *(const uint4*)(p.res2 + (int64_t)m * p.ldr2 + ncol);
+                                q2[k] = ld_stream((const uint4*)(p.res2 + (int64_t)m * p.ldr2 + ncol));
                             }
                         }
                         wave_lds_sync();

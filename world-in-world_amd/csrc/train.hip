@@ -1,5 +1,8 @@
-// Fine-tuning step (FTsvd/train_svd.py:844-970) — FIRST kernels of that row: the optimiser update and
-// the EDM loss with its gradient.  The backward kernels of the UNet operators are not built yet.
+// Kernels of the fine-tuning step (FTsvd/train_svd.py:844-970): the AdamW update, the
+// EDM loss with its gradient, and the backward kernels of the UNet operators that are not GEMM-shaped — attention
+// (dQ / dK / dV, LDS-tiled), GroupNorm(+SiLU), LayerNorm, GEGLU — plus the weight-gradient kernel on row-major operands
+// (wiw_wgrad_tn_bf16), column sums, the transposed im2col gather and the small element-wise helpers.  (Data gradients of the
+// linear / convolution layers are wiw_gemm_bf16 launches on re-laid-out weights.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

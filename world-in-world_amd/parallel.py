@@ -294,10 +294,22 @@ class ShardedAdamW:
         off, n, shp = self.offsets[name]
         return flat[off:off + n].view(shp)
 
+    def layout_fingerprint(self) -> str:
+        """Hash of everything the flat layout depends on — the (name, offset, size) table in order, the bucket and total
+        lengths and the world size.  Stored with a checkpoint and compared on resume: per-rank optimiser slices written
+        under another bucket size or parameter order would otherwise be copied into permuted slots without any error."""
+        import hashlib
+        import json
+
+        table = [[name, int(o), int(n)] for name, (o, n, _) in self.offsets.items()]
+        blob = json.dumps({"table": table, "bucket": int(self.bucket), "total": int(self.total), "world": int(self.world)})
+        return hashlib.sha1(blob.encode()).hexdigest()
+
     def load(self, state: dict) -> None:
-        """Initial parameters (same on every rank) -> full copy + this rank's master slices."""
-        for name, t in state.items():
-            self.view(self.params, name).copy_(torch.as_tensor(t, dtype=torch.float32))
+        """Initial parameters (same on every rank) -> full copy + this rank's master slices.  `state` may hold more names
+        than this optimiser owns (frozen / dead parameters are simply not part of it)."""
+        for name in self.offsets:
+            self.view(self.params, name).copy_(torch.as_tensor(state[name], dtype=torch.float32))
         for b in range(self.n_buckets):
             lo = b * self.bucket + self.rank * self.slice
             self.master[b * self.slice:(b + 1) * self.slice] = self.params[lo:lo + self.slice]

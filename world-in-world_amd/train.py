@@ -1,11 +1,15 @@
 """Fine-tuning step of the action-conditioned SVD UNet — SURVEY.md 8(f) row 2 (`FTsvd/train_svd.py:844-970`).
 
-STATUS: the first layer only.  What exists: the step's host-side preparation (EDM noise level draws, pre-conditioning of
-the UNet input, conditioning dropout — O(latent) elementwise work on 57 k-element tensors, PyTorch as plumbing), the EDM
-loss with its gradient and the AdamW update as HIP kernels (`csrc/train.hip`), and — under `oracle/` — the checker of the
-whole step pinned to the reference's autograd (`oracle/train_oracle.py`, `tests/golden/train_step_tiny.npz`).  What does
-NOT exist: the backward kernels of the UNet operators (dgrad / wgrad GEMM modes, GroupNorm / LayerNorm / GEGLU / attention
-backward) and the gradient reduce-scatter over xGMI; `TrainStep.backward` raises until they do.
+This module holds the pieces of the step that are not the network itself: the host-side preparation (EDM noise-level
+draws, pre-conditioning of the UNet input, conditioning dropout — O(latent) elementwise work on 57 k-element tensors,
+PyTorch as plumbing), the EDM loss with its gradient (`TrainStep.loss_and_grad`, `wiw_edm_loss_grad`), the building blocks
+of the backward pass of a linear / convolution layer (`linear_backward`, `conv_backward`: data gradients on `wiw_gemm_bf16`,
+weight gradients through the measured / modelled plans of `wgrad_gemm` — `wiw_wgrad_tn_bf16` or the GEMM on transposed
+operands), and the learning-rate schedules (`lr_at`).  The network's training forward / backward (every operator of the UNet
+on the HIP kernels of `csrc/train.hip`, gradients pinned to the reference's `loss.backward()`) is `train_unet.UNetTrain`;
+`train_unet.Trainer` is the step (forward, loss, backward, AdamW, ZeRO-1 reduction through `parallel.ShardedAdamW`,
+accumulation, loss scaling, checkpoints).  Checker of the whole step: `oracle/train_oracle.py`, pinned to the reference's
+autograd (`tests/golden/train_step_tiny*.npz`).  DESIGN.md 8.
 """
 from __future__ import annotations
 

@@ -575,9 +575,29 @@ class Trainer:
     Single process: `wiw_adamw_step` over every parameter tensor.  Data parallel: hand `optimizer=parallel.ShardedAdamW(...)`
     (gradients are copied into its flat buffer, reduced-scattered, the owned slices updated, parameters all-gathered)."""
 
+    PARAM_TYPES = {"full": lambda n: True,
+                   "new": lambda n: ("action" in n) or ("noise" in n),
+                   "new+temp_layer": lambda n: ("temporal_transformer_block" in n) or ("action" in n) or ("noise" in n)}
+
+    @staticmethod
+    def is_dead(name: str) -> bool:
+        """Parameters that never receive a gradient under `micro_cond` (in the reference's autograd too: SURVEY.md 9.3): the
+        query / key side and the LayerNorm of the single-key cross-attentions, and `add_embedding` (overwritten, unet:458-482)."""
+        return ("attn2.to_q." in name or "attn2.to_k." in name or name.startswith("add_embedding.")
+                or ("transformer_blocks." in name and ".norm2." in name))
+
+    @classmethod
+    def optimizer_shapes(cls, net: "UNetTrain", train_param_type: str = "full") -> Dict[str, tuple]:
+        """Shapes (in model order) of the parameters an optimiser has to hold: trainable under `--train_param_type` AND live.
+        Build `parallel.ShardedAdamW` from this: torch.optim.AdamW leaves parameters without a gradient untouched, a flat
+        optimiser over ALL parameters would apply its decoupled weight decay to the frozen / dead ones on every step (and
+        spend master / moment memory and collective bandwidth on 1.5 B parameters when only a few million train)."""
+        want = cls.PARAM_TYPES[train_param_type]
+        return {k: tuple(v.shape) for k, v in net.master.items() if want(k) and not cls.is_dead(k)}
+
     def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full", grad_accum: int = 1,
-                 autotune: bool = False):
+                 autotune: bool = False, scale_growth_interval: int = 2000):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
         # `--gradient_accumulation_steps` (train_svd.sh:20 runs 4; accelerate averages the micro-batch losses, train_svd.py:
         # 864, 961-969): `step` is one micro-batch, the optimiser runs on every grad_accum-th call with the mean gradient
@@ -586,13 +606,15 @@ class Trainer:
             from .train import set_wgrad_tuning
             set_wgrad_tuning(True)
         # which parameters are updated — the reference's `--train_param_type` (train_svd.py:655-663)
-        self.trainable = {"full": lambda n: True,
-                          "new": lambda n: ("action" in n) or ("noise" in n),
-                          "new+temp_layer": lambda n: ("temporal_transformer_block" in n) or ("action" in n) or ("noise" in n),
-                          }[train_param_type]
-        # static loss scale for fp16 (halved, and the step skipped, when a gradient comes back non-finite); 1 for bf16
+        base = self.PARAM_TYPES[train_param_type]
+        owned = None if optimizer is None else set(optimizer.offsets)          # a sharded optimiser may hold a subset
+        self.trainable = base if owned is None else (lambda n: base(n) and n in owned)
         net.wants = self.trainable                     # frozen weights: their weight-gradient GEMMs are not launched
+        # dynamic loss scale for fp16, as torch.cuda.amp.GradScaler (train_svd.py:960-964 through accelerate): halved — and the
+        # step skipped — when a gradient comes back non-finite, doubled after `scale_growth_interval` consecutive good
+        # optimiser steps (GradScaler's growth_interval = 2000), capped at 2^16; 1 for bf16 (no scaling)
         self.loss_scale = (2.0 ** 14 if net.dt == torch.float16 else 1.0) if loss_scale is None else loss_scale
+        self.scale_growth_interval, self._good_steps = int(scale_growth_interval), 0
         self.opt = optimizer
         self.steps = 0
         self.m = {k: torch.zeros_like(v) for k, v in net.master.items()} if optimizer is None else None
@@ -608,16 +630,19 @@ class Trainer:
 
         from .train import wgrad_plans
 
-        meta = {"micro": self._micro, "loss_scale": self.loss_scale, "grad_accum": self.grad_accum, "lr": self.lr,
-                "wgrad_plans": {k: list(v) for k, v in wgrad_plans().items()}}
+        meta = {"micro": self._micro, "loss_scale": self.loss_scale, "good_steps": self._good_steps, "grad_accum": self.grad_accum,
+                "lr": self.lr, "wgrad_plans": {k: list(v) for k, v in wgrad_plans().items()}}
+        ucfg = C.unet_config_dict(self.net.cfg) if hasattr(self.net, "cfg") else None     # unet/config.json, as save_pretrained
         if self.opt is None:
             optim = {f"exp_avg.{k}": v for k, v in self.m.items()}
             optim.update({f"exp_avg_sq.{k}": v for k, v in self.v.items()})
-            return C.save_checkpoint(output_dir, self.steps, self.net.master, optim, dict(meta, world=1), total_limit=total_limit)
+            return C.save_checkpoint(output_dir, self.steps, self.net.master, optim, dict(meta, world=1), total_limit=total_limit,
+                                     unet_config=ucfg)
         o = self.opt
         optim = {"master": o.master, "exp_avg": o.m, "exp_avg_sq": o.v}
         return C.save_checkpoint(output_dir, self.steps, self.net.master if o.rank == 0 else None, optim,
-                                 dict(meta, world=o.world), rank=o.rank, sharded=True, total_limit=total_limit)
+                                 dict(meta, world=o.world, opt_layout=o.layout_fingerprint()), rank=o.rank, sharded=True,
+                                 total_limit=total_limit, unet_config=ucfg)
 
     def load(self, path: str) -> None:
         """Resume from a directory written by `save` (`checkpoint.resolve_resume` maps "latest" to one)."""
@@ -626,6 +651,9 @@ class Trainer:
         sharded = self.opt is not None
         master, optim, meta = C.load_checkpoint(path, rank=self.opt.rank if sharded else 0, sharded=sharded)
         assert meta["world"] == (self.opt.world if sharded else 1), "the optimizer state was saved for another world size"
+        if sharded:   # the per-rank slices only mean something under the SAME flat layout (bucket size, parameter order and set)
+            assert meta.get("opt_layout") == self.opt.layout_fingerprint(), \
+                "the sharded optimizer state was saved under another flat layout (bucket size / parameter set or order)"
         assert set(master) == set(self.net.master), "checkpoint parameters do not match this architecture"
         for k, v in master.items():
             self.net.master[k].copy_(v)
@@ -640,6 +668,7 @@ class Trainer:
 
         load_wgrad_plans(meta.get("wgrad_plans", {}))          # the resumed run keeps the saved run's summation orders
         self.steps, self._micro, self.loss_scale = int(meta["global_step"]), int(meta["micro"]), float(meta["loss_scale"])
+        self._good_steps = int(meta.get("good_steps", 0))
         self._acc, self._seen = {}, None
         self.net.refresh()
 
@@ -685,7 +714,11 @@ class Trainer:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 bad = flag[0] > 0
             if bool(bad):                                                  # (one host sync)
-                self.loss_scale *= 0.5                                     # overflow: skip the update, as a GradScaler does
+                # overflow: skip the update and halve the scale, as a GradScaler does.  The micro-batches already accumulated
+                # in this window go with it: under accelerate the non-finite values are IN the accumulated .grad, the
+                # optimiser step of the window is skipped and the gradients are zeroed (train_svd.py:961-969)
+                self.loss_scale *= 0.5
+                self._good_steps = 0
                 self._micro, self._acc = 0, {}
                 return float(loss)
         self._micro += 1
@@ -701,6 +734,10 @@ class Trainer:
             grads = {name: self._mean_grad(name, g) for name, g in grads.items() if self.trainable(name)}
         self._acc = {}
         self.steps += 1
+        if self.loss_scale != 1.0:                                         # GradScaler growth: x2 after N good steps in a row
+            self._good_steps += 1
+            if self._good_steps >= self.scale_growth_interval:
+                self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 2.0 ** 16), 0
         if self.opt is None:
             stale = set()
             for name, g in grads.items():                                  # parameters without a gradient (the dead ones) stay

@@ -337,10 +337,6 @@ class UNetHIP:
             if nk % sk == 0 and tiles * sk >= 200:
                 return sk
         return 1
-        for sk in (2, 3, 4):
-            if nk % sk == 0 and tiles * sk >= 224 and nk // sk >= 16:
-                return sk
-        return 1
 
     def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, **kw):
         W = self.w[p + ".weight"]
