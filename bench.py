@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every UNet forward launch by launch (default: replay a captured hipGraph on the Euler steps "
+                         "that carry no per-launch events; same bytes)")
     ap.add_argument("--event-every", type=int, default=5,
                     help="per-launch HIP events are recorded on every n-th Euler step of the timed rollouts (every launch of "
                          "those steps); n = 1 instruments every step and costs 3.4 %% of frames/s (21 k extra events / rollout)")
@@ -150,13 +153,16 @@ def main():
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    # WIW_FORCE_DIST=1: take the multi-rank code path (env-driven RCCL process group, scatter / gather of candidate slices,
+    # ZeRO-1 optimiser) even with ONE rank — what `torchrun --nproc-per-node 1 bench.py --gpus 1` exercises on a one-GPU box
+    dist_on = world > 1 or bool(os.environ.get("WIW_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device)     # RANK / WORLD_SIZE / MASTER_* from the launcher's environment
 
     import wiw_amd  # noqa: F401
     if args.train:
-        return train_bench(args, rank, world, device)
+        return train_bench(args, rank, world, device, dist_on)
     from wiw_amd.config import UNetConfig
     from wiw_amd.parallel import sharded_denoise
     from wiw_amd.pipeline import SVDDenoiser
@@ -173,7 +179,7 @@ def main():
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
     torch.cuda.empty_cache()
-    den = SVDDenoiser(unet)
+    den = SVDDenoiser(unet, use_graph=not args.no_graph)
 
     B = args.batch
     Btot = B * world
@@ -206,7 +212,7 @@ def main():
 
     def rollout():
         arm(0)
-        if world == 1:
+        if not dist_on:
             out_ = den.denoise(req["image_latents"], req["image_embeddings"], req["noise"], req["actions"],
                                num_steps=args.num_inference_steps, callback=after_step)
         else:
@@ -217,13 +223,14 @@ def main():
         return out_
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
         rollout()
     ev["on"] = not args.no_kernel_events
+    den.host_launch = {"eager": [0.0, 0], "graph": [0.0, 0]}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -231,7 +238,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
@@ -250,8 +257,18 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
                                    f"CFG on, " + (f"{Btot} candidates in total" if strong else f"{B} candidate(s)/GPU") + ", random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
-                       "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}"},
+                       "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}",
+                       "collectives": f"rccl process group, {world} rank(s): scatter / gather of candidate slices" if dist_on else "none (single process)"},
         }
+        # host time spent enqueueing one UNet forward (~1 100 launches through ctypes, or one hipGraphLaunch): measured around the
+        # calls of the timed region, no synchronisation inside; the event-carrying steps are the eager sample
+        hl = den.host_launch
+        res["host_launch"] = {
+            "hip_graph": (not args.no_graph) and den.graph_error is None,
+            **({"graph_error": den.graph_error} if den.graph_error else {}),
+            "eager_ms_per_forward": round(1e3 * hl["eager"][0] / hl["eager"][1], 3) if hl["eager"][1] else None,
+            "graph_replay_ms_per_forward": round(1e3 * hl["graph"][0] / hl["graph"][1], 3) if hl["graph"][1] else None,
+            "forwards": {"eager": hl["eager"][1], "graph": hl["graph"][1]}}
         fwd_per_step = args.num_inference_steps * (Btot / world if strong else B)   # candidate-forwards per GPU
         algo = ALGO_TFLOP_PER_FORWARD * (h * w) / (72 * 128) * fwd_per_step  # linear in pixels & candidates
         if not args.tiny:
@@ -342,12 +359,12 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def train_bench(args, rank, world, device):
+def train_bench(args, rank, world, device, dist_on=False):
     """BASELINE config 4: FTsvd/train_svd.py step (one sample per GPU and micro-batch, train_svd.sh:26; 576x1024x14 as
     train_svd.sh:22-24) on the served architecture with random-init weights and a synthetic latent batch.
     metric = training samples / s (one micro-batch per step, the optimiser on every one)."""
@@ -363,7 +380,7 @@ def train_bench(args, rank, world, device):
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     net = UNetTrain(cfg, random_state_dict_torch(cfg, 0, device, torch.float32), device, dtype=dtype)
     opt = None
-    if world > 1:
+    if dist_on:
         opt = ShardedAdamW(Trainer.optimizer_shapes(net), device,   # trainable AND live parameters only
                            lambda p, g, m, v, step, lr, b1, b2, eps, wd: net.hip.adamw_step(p, g, m, v, step, lr, b1, b2, eps, wd),
                            lr=1e-5)
@@ -379,7 +396,7 @@ def train_bench(args, rank, world, device):
                         torch.randn(1, 1, cfg.cross_attention_dim, generator=gen), 0.04, aid)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -392,7 +409,7 @@ def train_bench(args, rank, world, device):
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     if rank == 0:
@@ -407,10 +424,10 @@ def train_bench(args, rank, world, device):
                                    "kernel (orientation / split-K per shape " + ("from the schedule model" if args.no_autotune else
                                    "measured during warm-up") + "), LDS-tiled attention backward" +
                                    (" [TINY MODEL - INVALID]" if args.tiny else ""),
-                       "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if world > 1 else "single GPU"},
+                       "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if dist_on else "single GPU"},
             "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}),
             flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

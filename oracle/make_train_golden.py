@@ -10,6 +10,7 @@ cover every operator class on the path.  `oracle/train_oracle.py` must reproduce
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py          # scenario a: tests/golden/train_step_tiny.npz
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py extra    # scenarios b, c: train_step_tiny_bc.npz
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_train_golden.py full     # SERVED width: train_step_full_32x64.npz
 """
 import os
 import sys
@@ -42,12 +43,15 @@ FULL = ["conv_in.weight", "conv_out.bias", "time_embedding.linear_1.weight", "ad
         "down_blocks.0.downsamplers.0.conv.weight", "mid_block.attentions.0.proj_out.weight"]
 
 
-def main():
+def main(full_width: bool = False):
+    """full_width: the SERVED architecture (320 / 640 / 1280 / 1280, 5 / 10 / 20 / 20 heads, T = 14) at a 32 x 64 latent — the
+    same step, every gradient norm, and of the FULL tensors either the whole gradient (<= 16 384 elements) or its first 8
+    rows (the fixture stays ~1 MB; the un-stored rows are covered by the tensor's norm)."""
     ns = import_reference()
     from utils.svd_utils import apply_conditioning_dropout  # type: ignore  (reference)
 
     torch.set_num_threads(8)
-    cfg = UNetConfig.tiny(4)
+    cfg = UNetConfig() if full_width else UNetConfig.tiny(4)
     T, h, w = cfg.num_frames, 32, 64   # L3 is 4 x 8 = 32 sites: the attention backward kernels need S % 16 == 0
     m = ref_unet(ns, cfg, seed=7).float().train()
     for prm in m.parameters():
@@ -57,7 +61,7 @@ def main():
     noise = torch.from_numpy(rs.standard_normal((1, T, 4, h, w)).astype(np.float32))
     conditional_latents = torch.from_numpy(rs.standard_normal((1, 4, h, w)).astype(np.float32))
     encoder_hidden_states = torch.from_numpy(rs.standard_normal((1, 1, cfg.cross_attention_dim)).astype(np.float32))
-    actions = np.array([[4, 2, 1, 3]], dtype=np.int64)
+    actions = np.array([[4, 2, 1, 3] + ([1, 1, 3, 2, 1, 2, 3, 1, 1, 2] if full_width else [])], dtype=np.int64)[:, :T]
     sigmas = torch.tensor([1.7], dtype=torch.float32)           # one draw of rand_log_normal(loc=0.7, scale=1.6), fixed
     noise_aug_strength = 0.043                                   # one draw of rand_log_normal(loc=-3.0, scale=0.5), fixed
     random_p = torch.tensor([0.9])                               # conditioning dropout draw: keeps every condition
@@ -96,6 +100,14 @@ def main():
     loss = torch.mean((weighing.float() * (denoised_latents.float() - target.float()) ** 2).reshape(target.shape[0], -1), dim=1)
     loss = loss.mean()
     loss.backward()                                               # :962
+    pred_bf16 = None
+    if full_width:   # the reference's OWN bf16 forward of the same step: the yardstick for the 16-bit HIP step's prediction
+        import copy
+        with torch.no_grad():
+            mb = copy.deepcopy(m).to(torch.bfloat16)
+            pred_bf16 = mb(inp.bfloat16(), timesteps, ehs_d.bfloat16(), added_time_ids=added_time_ids.bfloat16(),
+                           added_action_ids=act_d.bfloat16()).sample.float().numpy()
+            del mb
 
     names, norms, full = [], [], {}
     for k, prm in m.named_parameters():
@@ -103,8 +115,11 @@ def main():
         names.append(k)
         norms.append(0.0 if g is None else float(g.double().norm()))
         if k in FULL:
-            full["grad__" + k.replace(".", "__")] = g.numpy()
-    missing = [k for k in FULL if "grad__" + k.replace(".", "__") not in full]
+            if full_width and g.numel() > 16384:
+                full["grad8__" + k.replace(".", "__")] = g.reshape(g.shape[0], -1)[:8].numpy().copy()
+            else:
+                full["grad__" + k.replace(".", "__")] = g.numpy()
+    missing = [k for k in FULL if not any(p + k.replace(".", "__") in full for p in ("grad__", "grad8__"))]
     assert not missing, missing
     # one AdamW step of the reference optimiser class on two tensors (torch.optim.AdamW, train_svd.py:653, 1123-1130)
     opt_names = ["conv_in.weight", "down_blocks.1.attentions.0.transformer_blocks.0.norm3.bias"]
@@ -112,14 +127,15 @@ def main():
     opt = torch.optim.AdamW([prms[k] for k in opt_names], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
     before = {k: prms[k].detach().clone() for k in opt_names}
     opt.step()
-    save("train_step_tiny.npz", weight_seed=np.array(7), latents=latents.numpy(), noise=noise.numpy(),
+    save("train_step_full_32x64.npz" if full_width else "train_step_tiny.npz", weight_seed=np.array(7), latents=latents.numpy(), noise=noise.numpy(),
          conditional_latents=conditional_latents.numpy(), encoder_hidden_states=encoder_hidden_states.numpy(),
          actions=actions, action_ids=action_ids.numpy(), sigmas=sigmas.numpy(), noise_aug_strength=np.array(noise_aug_strength),
          random_p=random_p.numpy(), dropout_prob=np.array(0.1), loss=np.array(float(loss)), model_pred=model_pred.detach().numpy(),
          grad_names=np.array(names), grad_norms=np.array(norms),
          adamw_names=np.array(opt_names), adamw_lr=np.array(1e-3),
          **{"adamw_before__" + k.replace(".", "__"): before[k].numpy() for k in opt_names},
-         **{"adamw_after__" + k.replace(".", "__"): prms[k].detach().numpy() for k in opt_names}, **full)
+         **{"adamw_after__" + k.replace(".", "__"): prms[k].detach().numpy() for k in opt_names}, **full,
+         **({"model_pred_bf16": pred_bf16} if pred_bf16 is not None else {}))
 
 
 def derived_inputs(g, which: str):
@@ -198,5 +214,7 @@ def extra():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
+        main(full_width=True)
     else:
         main()

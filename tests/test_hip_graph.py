@@ -1,0 +1,67 @@
+"""hipGraph replay of the UNet forward (pipeline.GraphedForward) against the eager loop: the same bytes.  GPU only.
+
+The C ABI allocates and synchronises nothing inside its entry points (include/wiw_svd.h conventions, SURVEY 8b "graph-capture
+safe"): this test is the proof — one forward (~1 100 launches at full size) is captured once per (candidates, h, w) and
+replayed for every Euler step and every later request of that shape."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _inputs(cfg, B, T, h, w, seed):
+    rs = np.random.RandomState(seed)
+    il = torch.from_numpy(rs.standard_normal((B, 4, h, w)).astype(np.float32))
+    ie = torch.from_numpy(rs.standard_normal((B, 1, cfg.cross_attention_dim)).astype(np.float32))
+    noise = torch.from_numpy(rs.standard_normal((B, T, 4, h, w)).astype(np.float32))
+    acts = np.stack([np.roll(np.array([4, 2, 1, 3][:T]), b) for b in range(B)])
+    acts[:, 0] = 4
+    return il, ie, noise, acts
+
+
+def test_graph_replay_is_bit_identical_and_reused_across_requests():
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 5), DEV)
+    eager, graphed = SVDDenoiser(unet, use_graph=False), SVDDenoiser(unet, use_graph=True)
+    T, h, w = 4, 16, 32
+    for B, seed in ((1, 0), (1, 1), (2, 2), (1, 3)):        # second and fourth request reuse the B = 1 graph
+        il, ie, noise, acts = _inputs(cfg, B, T, h, w, seed)
+        a = eager.denoise(il, ie, noise, acts, num_steps=3)
+        b = graphed.denoise(il, ie, noise, acts, num_steps=3)
+        assert graphed.graph_error is None, graphed.graph_error
+        assert torch.equal(a, b), f"graph replay differs from the eager loop (B={B}, seed={seed})"
+    assert set(graphed._graphs) == {(1, h, w), (2, h, w)}
+    assert graphed.host_launch["graph"][1] == 12 and graphed.host_launch["eager"][1] == 0
+    assert eager.host_launch["eager"][1] == 12
+
+
+def test_eager_steps_interleave_with_replays():
+    """bench.py records per-launch events on every n-th Euler step: those steps run eagerly on the graph's static buffers."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 6), DEV)
+    il, ie, noise, acts = _inputs(cfg, 1, 4, 16, 32, 7)
+    ref = SVDDenoiser(unet, use_graph=False).denoise(il, ie, noise, acts, num_steps=4)
+    den = SVDDenoiser(unet, use_graph=True)
+    prof = []
+
+    def toggle(i, _lat):     # after step i: arm events for odd steps
+        unet.hip.gemm_profile = prof if (i + 1) % 2 == 1 else None
+    out = den.denoise(il, ie, noise, acts, num_steps=4, callback=toggle)
+    unet.hip.gemm_profile = None
+    assert torch.equal(out, ref)
+    assert den.host_launch["graph"][1] == 2 and den.host_launch["eager"][1] == 2 and len(prof) > 0

@@ -128,3 +128,45 @@ def test_sharded_paths_over_rccl_two_ranks():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+
+
+def _torchrun_bench(extra, timeout=600):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 ... bench.py --gpus 1 ...` exactly as the driver launches
+    the N > 1 runs (rendezvous on 127.0.0.1, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher), with
+    WIW_FORCE_DIST=1 so that the ONE rank takes the multi-rank code path: env-driven `init_process_group("nccl")`, scatter /
+    gather of candidate slices (`parallel.sharded_denoise`) or the ZeRO-1 optimiser (`parallel.ShardedAdamW`), barrier +
+    max-over-ranks timing.  Returns the JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WIW_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", *extra]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_torchrun_takes_the_rccl_path_with_one_rank():
+    """the multi-GPU entry of bench.py run the way the driver runs it, on the one GPU a test box has."""
+    res = _torchrun_bench(["--tiny", "--height", "128", "--width", "256", "--num-inference-steps", "2", "--steps", "1",
+                           "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-kernel-events"])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and "rccl process group, 1 rank" in res["config"]["collectives"]
+    assert res["scaling"] == "weak" and res["config"]["candidates_per_gpu"] == 2
+    # strong-scaling form: a fixed request of 3 candidates sharded over the (one) rank
+    res = _torchrun_bench(["--tiny", "--height", "128", "--width", "256", "--num-inference-steps", "2", "--steps", "1",
+                           "--warmup", "0", "--total-candidates", "3", "--no-cpu-baseline", "--no-kernel-events"])
+    assert res["scaling"] == "strong" and res["value"] > 0
+
+
+def test_train_bench_under_torchrun_uses_the_sharded_optimizer():
+    res = _torchrun_bench(["--train", "--tiny", "--train-height", "256", "--train-width", "512", "--steps", "2", "--warmup", "1",
+                           "--no-autotune"])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and "ZeRO-1" in res["config"]["parallelism"]
+    assert np.isfinite(res["final_loss"])
