@@ -100,15 +100,6 @@ def main(full_width: bool = False):
     loss = torch.mean((weighing.float() * (denoised_latents.float() - target.float()) ** 2).reshape(target.shape[0], -1), dim=1)
     loss = loss.mean()
     loss.backward()                                               # :962
-    pred_bf16 = None
-    if full_width:   # the reference's OWN bf16 forward of the same step: the yardstick for the 16-bit HIP step's prediction
-        import copy
-        with torch.no_grad():
-            mb = copy.deepcopy(m).to(torch.bfloat16)
-            pred_bf16 = mb(inp.bfloat16(), timesteps, ehs_d.bfloat16(), added_time_ids=added_time_ids.bfloat16(),
-                           added_action_ids=act_d.bfloat16()).sample.float().numpy()
-            del mb
-
     names, norms, full = [], [], {}
     for k, prm in m.named_parameters():
         g = prm.grad
@@ -134,8 +125,7 @@ def main(full_width: bool = False):
          grad_names=np.array(names), grad_norms=np.array(norms),
          adamw_names=np.array(opt_names), adamw_lr=np.array(1e-3),
          **{"adamw_before__" + k.replace(".", "__"): before[k].numpy() for k in opt_names},
-         **{"adamw_after__" + k.replace(".", "__"): prms[k].detach().numpy() for k in opt_names}, **full,
-         **({"model_pred_bf16": pred_bf16} if pred_bf16 is not None else {}))
+         **{"adamw_after__" + k.replace(".", "__"): prms[k].detach().numpy() for k in opt_names}, **full)
 
 
 def derived_inputs(g, which: str):

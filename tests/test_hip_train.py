@@ -365,10 +365,14 @@ def test_unet_training_step_matches_reference_gradients(golden, dtype):
     pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
     mx, rms = _rel(pred, torch.from_numpy(g["model_pred"]))
     print(f"[f2] training forward vs the reference prediction: max_rel={mx:.2e} rms={rms:.2e}")
-    assert rms <= 3e-2
+    # Gates = ~3x the deviations measured on MI355X (round 3, profiles/r05o_train_tests.log): bf16 / fp16 prediction rms
+    # 1.39e-2 / 1.73e-3, loss 3e-5 / 6e-6 relative, gradient norms median 2.3e-3 / 2.3e-4 and 90 % 8.6e-3 / 1.1e-3, full
+    # gradients median 3.6e-2 / 4.9e-3 and worst 6.6e-2 / 7.6e-3
+    tiny_gate = {torch.bfloat16: (4e-2, 1e-3, 7e-3, 2.6e-2, 0.11, 0.20), torch.float16: (5e-3, 1e-4, 7e-4, 3.3e-3, 1.5e-2, 2.3e-2)}[dtype]
+    assert rms <= tiny_gate[0]
     loss, dpred = T.TrainStep(hip).loss_and_grad(pred, st)
     print(f"[f2] loss {float(loss):.6f} (reference {float(g['loss']):.6f})")
-    assert abs(float(loss) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+    assert abs(float(loss) - float(g["loss"])) <= tiny_gate[1] * float(g["loss"])
     # fp16: loss scaling (the reference trains fp16 under a GradScaler): without it the ~1e-5 activation gradients of the
     # mean loss fall below fp16's normal range and whole gradient tensors vanish
     grads = net.backward(dpred.reshape(pred.shape), loss_scale=1.0 if dtype == torch.bfloat16 else 2.0 ** 14)
@@ -396,9 +400,8 @@ def test_unet_training_step_matches_reference_gradients(golden, dtype):
             full.append((_rel(grads[name], torch.from_numpy(g[key]))[1], name))
     full.sort(reverse=True)
     print("[f2] full gradients (rms rel error): " + ", ".join(f"{n.split('.')[-2]}.{n.split('.')[-1]} {e:.1e}" for e, n in full))
-    k = 1.0 if dtype == torch.bfloat16 else 0.25                       # fp16 activations / gradients: 8x finer rounding
-    assert dev[len(dev) // 2][0] <= 2e-2 * k and dev[len(dev) // 10][0] <= 6e-2 * k
-    assert full[len(full) // 2][0] <= 5e-2 * k and full[0][0] <= 0.25 * k
+    assert dev[len(dev) // 2][0] <= tiny_gate[2] and dev[len(dev) // 10][0] <= tiny_gate[3]
+    assert full[len(full) // 2][0] <= tiny_gate[4] and full[0][0] <= tiny_gate[5]
 
 
 @pytest.mark.gpu
@@ -431,7 +434,7 @@ def test_unet_training_step_other_noise_levels_and_dropout_branches(golden, whic
     loss, dpred = T.TrainStep(hip).loss_and_grad(pred, st)
     ref_loss = float(e[f"{which}__loss"])
     print(f"[f2] scenario {which}: prediction rms {rms:.2e}, loss {float(loss):.6f} (reference {ref_loss:.6f})")
-    assert rms <= 3e-2 and abs(float(loss) - ref_loss) <= 2e-2 * ref_loss
+    assert rms <= 4.5e-2 and abs(float(loss) - ref_loss) <= 1e-3 * ref_loss      # measured 1.65e-2 / 1.52e-2 and 1.8e-4 / 1.3e-5
     grads = net.backward(dpred.reshape(pred.shape))
     is_dead = lambda n: ("transformer_blocks.0.norm2." in n) or (".attn2.to_q." in n) or (".attn2.to_k." in n) or \
         n.startswith("add_embedding.")  # noqa: E731
@@ -446,7 +449,7 @@ def test_unet_training_step_other_noise_levels_and_dropout_branches(golden, whic
         dev.append((abs(gn - nr) / max(nr, 1e-7), n))
     dev.sort(reverse=True)
     print("[f2] scenario %s gradient norms: median rel dev %.2e, 90%% %.2e, worst %s" % (which, dev[len(dev) // 2][0], dev[len(dev) // 10][0], dev[:2]))
-    assert dev[len(dev) // 2][0] <= 2e-2 and dev[len(dev) // 10][0] <= 6e-2
+    assert dev[len(dev) // 2][0] <= 8.5e-3 and dev[len(dev) // 10][0] <= 2.6e-2     # measured 2.8e-3 / 2.0e-3 and 8.7e-3 / 8.2e-3
     full = [(_rel(grads[k[len(which) + 8:].replace("__", ".")], torch.from_numpy(e[k]))[1], k) for k in e.files if k.startswith(f"{which}__grad__")]
     assert len(full) == 3 and max(f[0] for f in full) <= 0.25, full
 
@@ -509,37 +512,123 @@ def test_trainer_steps_reduce_the_loss_and_follow_adamw(golden):
     assert any("temporal_transformer_block" in k for k in moved4) and all(torch.equal(net4.master[k], net3.master[k]) for k in moved4)
 
 
+# Gates of the served-width step: ~3x the deviations measured on MI355X (printed by the test; profiles/README.md)
+# measured (profiles/r05o_train_tests.log): bf16 1.16e-2 | 2.0e-4 | 2.8e-3 | 3.7e-3 | ~1.0e-2 | 2.5e-2;  fp16 1.46e-3 | 2.3e-5 | 1.6e-4 | 3.5e-4 | ~1.4e-3 | 2.5e-3
+FULL_WIDTH_GATES = {   # dtype: (prediction rms vs fp32 reference, loss rel, grad-norm median, grad-norm 90th pct, full-grad median rms, worst)
+    torch.bfloat16: (3.5e-2, 1e-3, 8.5e-3, 1.2e-2, 3e-2, 8e-2),
+    torch.float16: (4.5e-3, 2e-4, 5e-4, 1.1e-3, 4.5e-3, 8e-3),
+}
+
+
 @pytest.mark.gpu
-def test_full_width_training_step_runs(golden):
-    """The served architecture (320/640/1280/1280, T = 14) through one forward + backward at a 32x64 latent: finite loss and
-    gradients for every live parameter, shapes as the checkpoint's.  (Parity is pinned on the tiny network above; this is
-    the memory / geometry check of the real widths: 160 / 320-column tiles, 5-20 heads, 2560-channel concat.)"""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_full_width_training_step_matches_reference_gradients(golden, dtype):
+    """The SERVED architecture (320/640/1280/1280, 5/10/20/20 heads, T = 14: 160 / 320-column tiles, 2560-channel concat, the
+    fused level-0 FeedForward's unfused training twin) through one training step at a 32x64 latent against the reference's
+    own `loss.backward()` on the same seeded weights and inputs (tests/golden/train_step_full_32x64.npz, written by
+    oracle/make_train_golden.py `full` from FTsvd's UNet class under autograd): loss, prediction, the gradient norm of every
+    live parameter, and 18 full (or first-8-row) gradients."""
     import wiw_amd  # noqa: F401
     from wiw_amd import train as T
     from wiw_amd.config import UNetConfig
     from wiw_amd.hip import Hip
-    from wiw_amd.train_unet import UNetTrain
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_full_32x64.npz")
+    cfg = UNetConfig()
+    hip = Hip(torch.device(DEV), dtype)
+    net = UNetTrain(cfg, random_state_dict(cfg, int(g["weight_seed"])), DEV, hip=hip)
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]),
+                        dropout_prob=float(g["dropout_prob"]), random_p=torch.from_numpy(g["random_p"]))
+    pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
+    ref = torch.from_numpy(g["model_pred"])
+    rms = _rel(pred, ref)[1]
+    print(f"[f2 full width {dtype}] prediction rms vs the fp32 reference {rms:.2e}")
+    gate = FULL_WIDTH_GATES[dtype]
+    assert rms <= gate[0]
+    loss, dpred = T.TrainStep(hip).loss_and_grad(pred, st)
+    print(f"[f2 full width] loss {float(loss):.6f} (reference {float(g['loss']):.6f})")
+    assert abs(float(loss) - float(g["loss"])) <= gate[1] * float(g["loss"])
+    grads = net.backward(dpred.reshape(pred.shape), loss_scale=1.0 if dtype == torch.bfloat16 else 2.0 ** 14)
+    torch.cuda.synchronize()
+    names, norms = [str(n) for n in g["grad_names"]], g["grad_norms"]
+    assert len(grads) == len(net.master) - 132
+    dev = []
+    for n, nr in zip(names, norms):
+        if Trainer.is_dead(n):
+            assert n not in grads, n
+            continue
+        assert n in grads and tuple(grads[n].shape) == tuple(net.master[n].shape) and torch.isfinite(grads[n]).all(), n
+        dev.append((abs(float(grads[n].double().norm()) - nr) / max(nr, 1e-7), n))
+    dev.sort(reverse=True)
+    print("[f2 full width] gradient norms vs the reference (%d live tensors): median rel dev %.2e, 90%% %.2e, worst %s" % (
+        len(dev), dev[len(dev) // 2][0], dev[len(dev) // 10][0], dev[:3]))
+    full = []
+    for key in g.files:
+        if key.startswith("grad__") or key.startswith("grad8__"):
+            name = key.split("__", 1)[1].replace("__", ".")
+            r = torch.from_numpy(g[key])
+            mine = grads[name] if key.startswith("grad__") else grads[name].reshape(grads[name].shape[0], -1)[:8]
+            full.append((_rel(mine.reshape(r.shape), r)[1], name))
+    full.sort(reverse=True)
+    print("[f2 full width] full gradients (rms rel error): " + ", ".join(f"{n.split('.')[-2]}.{n.split('.')[-1]} {e:.1e}" for e, n in full))
+    assert len(full) >= 18
+    assert dev[len(dev) // 2][0] <= gate[2] and dev[len(dev) // 10][0] <= gate[3]
+    assert full[len(full) // 2][0] <= gate[4] and full[0][0] <= gate[5]
+    print(f"[f2 full width] peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+
+@pytest.mark.gpu
+def test_576x1024_training_step_and_resume(tmp_path):
+    """BASELINE config 4's per-GPU work — one fine-tuning step of the served network on a 576x1024x14 clip (train_svd.sh:22-26) —
+    run by the test suite (not only by `bench.py --train`): two `Trainer` steps with finite, decreasing-in-expectation losses,
+    then checkpoint -> fresh Trainer -> resume: the third step is bit-identical to the uninterrupted run's third step."""
+    import time
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd import checkpoint as C
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.train_unet import Trainer, UNetTrain
     from wiw_amd.weights import random_state_dict_torch
 
     cfg = UNetConfig()
-    hip = Hip(torch.device(DEV))
-    net = UNetTrain(cfg, random_state_dict_torch(cfg, 0, torch.device(DEV), torch.float32), DEV, hip=hip)
-    gen = torch.Generator().manual_seed(0)
-    Tn, h, w = cfg.num_frames, 32, 64
+    dev = torch.device(DEV)
+    hip = Hip(dev)
+    gen = torch.Generator().manual_seed(3)
+    Tn, h, w = cfg.num_frames, 72, 128
     lat, noise = torch.randn(1, Tn, 4, h, w, generator=gen) * 0.8, torch.randn(1, Tn, 4, h, w, generator=gen)
     import svd_oracle as O
     aid = torch.from_numpy(O.action_ids_idx_encode(np.array([[4] + [1, 2, 1, 3] * 3 + [1]]))).float()
     st = T.prepare_step(lat, noise, 1.3, torch.randn(1, 4, h, w, generator=gen), torch.randn(1, 1, cfg.cross_attention_dim, generator=gen),
                         0.04, aid)
-    pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
-    loss, dpred = T.TrainStep(hip).loss_and_grad(pred, st)
-    grads = net.backward(dpred.reshape(pred.shape))
+    net = UNetTrain(cfg, random_state_dict_torch(cfg, 0, dev, torch.float32), DEV, hip=hip)
+    tr = Trainer(net, lr=1e-5)
+    l1 = tr.step(st)
     torch.cuda.synchronize()
-    assert torch.isfinite(loss) and len(grads) == len(net.master) - 132, len(grads)     # all but the dead parameters
-    bad = [k for k, v in grads.items() if not torch.isfinite(v).all() or tuple(v.shape) != tuple(net.master[k].shape)]
-    assert not bad, bad[:5]
-    print(f"[f2] full-width step at 32x64x14: loss {float(loss):.4f}, {len(grads)} gradients, peak memory "
-          f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    t0 = time.perf_counter()
+    l2 = tr.step(st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(l1) and np.isfinite(l2)
+    path = tr.save(str(tmp_path))
+    assert os.path.isfile(os.path.join(path, C.UNET_CONFIG_FILE))
+    l3 = tr.step(st)
+    ref = {k: net.master[k].clone() for k in ("conv_in.weight", "mid_block.attentions.0.proj_out.weight", "conv_out.bias")}
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    del tr, net
+    torch.cuda.empty_cache()
+    net2 = UNetTrain(cfg, random_state_dict_torch(cfg, 1, dev, torch.float32), DEV, hip=hip)     # other weights: all come from disk
+    tr2 = Trainer(net2, lr=1e-5)
+    tr2.load(path)
+    l3b = tr2.step(st)
+    print(f"[f2] 576x1024x14 step: losses {l1:.5f} {l2:.5f} {l3:.5f}; resumed third step {l3b:.5f}; {dt * 1e3:.0f} ms per step "
+          f"(schedule-model weight-gradient plans), peak {peak:.1f} GiB")
+    assert l3b == l3 and all(torch.equal(net2.master[k], v) for k, v in ref.items())
 
 
 @pytest.mark.gpu

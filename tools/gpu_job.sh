@@ -2,4 +2,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-echo "== train, forced dist, direct"; WIW_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 timeout 300 python bench.py --gpus 1 --train --tiny --train-height 128 --train-width 256 --steps 2 --warmup 1 --no-autotune > $O/train_direct.log 2>&1; grep -v "^$" $O/train_direct.log | tail -25
+echo "== train tests (measured deviations)"; timeout 1500 python -m pytest tests/test_hip_train.py -x -q -s -k "full_width or 576x1024 or matches_reference_gradients or other_noise" 2>&1 | grep "\[f2\|passed\|failed\|Error\|assert" | cut -c1-400 | tee $O/train_tests.log
+echo "== torchrun tests"; timeout 900 python -m pytest tests/test_hip_parallel.py -x -q 2>&1 | tail -3 | tee $O/parallel_tests.log
