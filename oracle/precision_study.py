@@ -38,19 +38,30 @@ from wiw_amd.weights import random_state_dict  # noqa: E402
 
 
 class Policy:
+    """res32: True (the whole residual stream in fp32), False, or a set of categories kept in fp32:
+    'tr' = the residual adds inside the transformer layers (proj_in output ... AlphaBlender), 'rb' = ResBlock outputs and
+    their AlphaBlender, 'io' = the stream between blocks (conv_in, down / upsampler outputs, transformer output + input)."""
+
     def __init__(self, dtype, res32):
-        self.dtype, self.res32 = dtype, res32
+        self.dtype = dtype
+        self.cats = {"tr", "rb", "io"} if res32 is True else (set() if not res32 else set(res32))
+        self.res32 = bool(self.cats)
+        self.cat = "io"
 
     def op(self, x):      # a tensor consumed as an MFMA operand / written by an operator inside a block
         return x.to(self.dtype).float() if self.dtype is not None else x
 
-    def res(self, x):     # a residual-stream tensor
-        return x if (self.res32 or self.dtype is None) else x.to(self.dtype).float()
+    def res(self, x, cat=None):     # a residual-stream tensor
+        keep = (cat or self.cat) in self.cats
+        return x if (keep or self.dtype is None) else x.to(self.dtype).float()
 
 
 def install(pol: Policy):
     """Re-state the block functions of svd_oracle with the storage roundings of the HIP path (same formulas, same order)."""
-    op, res = pol.op, pol.res
+    op = pol.op
+    res = lambda x: pol.res(x, 'io')  # noqa: E731
+    res_tr = lambda x: pol.res(x, 'tr')  # noqa: E731
+    res_rb = lambda x: pol.res(x, 'rb')  # noqa: E731
     sdget = lambda sd, k: sd[k]  # noqa: E731
 
     def linear(sd, p, x):
@@ -68,7 +79,7 @@ def install(pol: Policy):
         h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
         if p + ".conv_shortcut.weight" in sd:     # fused into conv2's implicit GEMM on the HIP path: operands are the 16-bit x
             x = F.conv2d(op(x), sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
-        return res(x + h)
+        return res_rb(x + h)
 
     def temporal_resnet_block(sd, p, x, temb, eps):
         h = gn_silu(sd, p + ".norm1", x, eps)
@@ -85,7 +96,7 @@ def install(pol: Policy):
         B = BF // T
         h5 = hs.reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4)
         ht = temporal_resnet_block(sd, p + ".temporal_res_block", h5, temb.reshape(B, T, -1), eps)
-        out = res(O.alpha_blend(sd, p + ".time_mixer", h5, ht))
+        out = res_rb(O.alpha_blend(sd, p + ".time_mixer", h5, ht))
         return out.permute(0, 2, 1, 3, 4).reshape(BF, C, H, W)
 
     def layer_norm(sd, p, x):
@@ -109,18 +120,18 @@ def install(pol: Policy):
         return linear(sd, p + ".net.2", op(val * F.gelu(gate)))
 
     def basic_transformer_block(sd, p, x, ehs, heads):
-        x = res(x + attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, heads))
-        x = res(x + attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), ehs, heads))     # (a per-item vector on the GPU)
-        x = res(x + geglu_ff(sd, p + ".ff", layer_norm(sd, p + ".norm3", x)))
+        x = res_tr(x + attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", x), None, heads))
+        x = res_tr(x + attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", x), ehs, heads))     # (a per-item vector on the GPU)
+        x = res_tr(x + geglu_ff(sd, p + ".ff", layer_norm(sd, p + ".norm3", x)))
         return x
 
     def temporal_transformer_block(sd, p, x, T, time_ctx, heads):
         BF, S, C = x.shape
         B = BF // T
         h = x.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
-        h = res(h + geglu_ff(sd, p + ".ff_in", layer_norm(sd, p + ".norm_in", h)))
-        h = res(h + attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", h), None, heads))
-        h = res(h + attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", h), time_ctx, heads))
+        h = res_tr(h + geglu_ff(sd, p + ".ff_in", layer_norm(sd, p + ".norm_in", h)))
+        h = res_tr(h + attention(sd, p + ".attn1", layer_norm(sd, p + ".norm1", h), None, heads))
+        h = res_tr(h + attention(sd, p + ".attn2", layer_norm(sd, p + ".norm2", h), time_ctx, heads))
         h = h + geglu_ff(sd, p + ".ff", layer_norm(sd, p + ".norm3", h))      # blended in the FF2 epilogue (fp32)
         return h.reshape(B, S, T, C).permute(0, 2, 1, 3).reshape(BF, S, C)
 
@@ -132,13 +143,13 @@ def install(pol: Policy):
         tc = tc[:, None].expand(B, S, tc.shape[-2], tc.shape[-1]).reshape(B * S, -1, ehs.shape[-1])
         h = gn_silu(sd, p + ".norm", x, 1e-6, silu=False)
         h = h.permute(0, 2, 3, 1).reshape(BF, S, C)
-        h = res(linear(sd, p + ".proj_in", h))
+        h = res_tr(linear(sd, p + ".proj_in", h))
         frame_idx = torch.arange(T).repeat(B)
         emb = O.timestep_mlp(sd, p + ".time_pos_embed", O.timestep_embedding(frame_idx, C))[:, None, :]
         hs = basic_transformer_block(sd, p + ".transformer_blocks.0", h, ehs, heads)
-        ht = temporal_transformer_block(sd, p + ".temporal_transformer_blocks.0", res(hs + emb), T, tc, heads)
-        h = res(O.alpha_blend(sd, p + ".time_mixer", hs, ht))
-        h = linear(sd, p + ".proj_out", op(h) if pol.res32 else h)     # an fp32 stream still enters a GEMM as a 16-bit operand
+        ht = temporal_transformer_block(sd, p + ".temporal_transformer_blocks.0", res_tr(hs + emb), T, tc, heads)
+        h = res_tr(O.alpha_blend(sd, p + ".time_mixer", hs, ht))
+        h = linear(sd, p + ".proj_out", op(h) if 'tr' in pol.cats else h)     # an fp32 stream still enters a GEMM as a 16-bit operand
         return res(h.reshape(BF, H, W, C).permute(0, 3, 1, 2) + x)
 
     saved = {}
@@ -152,7 +163,7 @@ def install(pol: Policy):
     conv2d = F.conv2d
 
     def conv2d_stream(x, w, b=None, **kw):
-        return res(conv2d(op(x) if pol.res32 else x, w, b, **kw))
+        return res(conv2d(op(x) if pol.cats else x, w, b, **kw))
     saved["_conv2d"] = conv2d
     O.F.conv2d = conv2d_stream
     _ = sdget
@@ -168,7 +179,7 @@ def uninstall(saved):
 def main():
     args = sys.argv[1:]
     dtype = torch.bfloat16 if "bf16" in args else torch.float16
-    which = [a for a in args if a in ("all16", "res32", "weights")] or ["weights", "all16", "res32"]
+    which = [a for a in args if a in ("all16", "res32", "weights", "tr", "rb", "io", "tr+rb", "tr+io", "rb+io")] or ["weights", "all16", "res32"]
     g = np.load(os.path.join(ROOT, "tests", "golden", "unet_full_16x32.npz"), allow_pickle=True)
     cfg = UNetConfig()
     sd = {k: torch.from_numpy(v).to(dtype).float() for k, v in random_state_dict(cfg, int(g["weight_seed"])).items()}
@@ -189,7 +200,7 @@ def main():
             if w == "weights":          # fp32 arithmetic and storage on the ROUNDED weights: the floor of any policy
                 report("weights", O.unet_forward(sd, cfg.as_dict(), *ins))
                 continue
-            saved = install(Policy(dtype, res32=(w == "res32")))
+            saved = install(Policy(dtype, res32=True if w == "res32" else (False if w == "all16" else w.split("+"))))
             try:
                 report(w, O.unet_forward(sd, cfg.as_dict(), *ins))
             finally:
