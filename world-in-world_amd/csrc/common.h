@@ -66,6 +66,65 @@ WIW_DEV float gelu_erf_f(float x) {
     return 0.5f * __builtin_fmaf(ax, erf_abs, x);
 }
 
+// gelu_erf_f on NP PACKED pairs at once, breadth first, the same arithmetic bit for bit.  One wave issues at most one VALU
+// instruction per ~5.4 cycles (8.5 when it depends on the previous one) packed or not (tools/ubench/valu_rate.hip), so the
+// cost of a GELU block is its instruction count: v_pk_* halves it and independent work per stage removes the dependency
+// stalls.  wiw_regp is an empty asm statement that reads and writes every pair of a stage — without it instruction
+// selection re-serialises the chains value by value (csrc/ffn.hip).
+template <int NP>
+WIW_DEV void wiw_regp(wiw_f32x2 (&a)[NP]) {
+    static_assert(NP == 4 || NP == 5 || NP == 8 || NP == 10, "add the operand list for this width");
+    if constexpr (NP == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    if constexpr (NP == 5) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
+    if constexpr (NP == 8)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    if constexpr (NP == 10)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                     "+v"(a[8]), "+v"(a[9]));
+}
+template <int NP>
+WIW_DEV void gelu_erf_pk(wiw_f32x2 (&x)[NP]) {
+    wiw_f32x2 ax[NP], z[NP], t[NP], e[NP], poly[NP];
+    const auto fma2 = [](wiw_f32x2 a, wiw_f32x2 b, wiw_f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+    const auto bc = [](float c) { return wiw_f32x2{c, c}; };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        ax[i] = wiw_f32x2{fabsf(x[i].x), fabsf(x[i].y)};
+        z[i] = ax[i] * 0.70710678118654752f;
+    }
+    wiw_regp(z);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { t[i] = fma2(bc(0.3275911f), z[i], bc(1.0f)); e[i] = (z[i] * -1.4426950408889634f) * z[i]; }
+    wiw_regp(t); wiw_regp(e);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        t[i] = wiw_f32x2{__builtin_amdgcn_rcpf(t[i].x), __builtin_amdgcn_rcpf(t[i].y)};
+        e[i] = wiw_f32x2{__builtin_amdgcn_exp2f(e[i].x), __builtin_amdgcn_exp2f(e[i].y)};
+    }
+    wiw_regp(t); wiw_regp(e);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = fma2(bc(1.061405429f), t[i], bc(-1.453152027f));
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = fma2(poly[i], t[i], bc(1.421413741f));
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = fma2(poly[i], t[i], bc(-0.284496736f));
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = fma2(poly[i], t[i], bc(0.254829592f));
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = -poly[i] * t[i];
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) poly[i] = fma2(poly[i], e[i], bc(1.0f));     // erf|x|
+    wiw_regp(poly);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = fma2(ax[i], poly[i], x[i]) * 0.5f;
+    wiw_regp(x);
+}
+
 WIW_DEV void unpack8(const uint4& v, float* f) {
     const wiw_f32x2 a = unpack2(v.x), b = unpack2(v.y), c = unpack2(v.z), d = unpack2(v.w);
     f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y; f[6] = d.x; f[7] = d.y;

@@ -38,6 +38,9 @@
 #include <type_traits>
 
 #include "common.h"
+#ifndef WIW_GE_PK
+#define WIW_GE_PK 1   // GEGLU epilogue on packed pairs, breadth first (0: value by value, the round-2 form)
+#endif
 
 // 256 x 320 tile variant (gemm_huge.hip)
 bool wiw_gemm_huge_ok(const WiwGemmArgs& a);
@@ -758,6 +761,29 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     char* wrow = stg + (mi * 16 + frow) * STG_ROWB_G + fq * 8;
+#if WIW_GE_PK
+                    // the 20 gates of these 16 rows as ten packed pairs, breadth first (gelu_erf_pk in common.h)
+                    wiw_f32x2 gg[10];
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        f32x4 g = acc[mi][ni + 5];
+                        if (LNF) ln_fold4(g, ni + 5, mi);          // t carries the bias
+                        else if (p.bias) { g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w; }
+                        gg[2 * ni] = wiw_f32x2{g[0], g[1]};
+                        gg[2 * ni + 1] = wiw_f32x2{g[2], g[3]};
+                    }
+                    gelu_erf_pk<10>(gg);
+#pragma unroll
+                    for (int ni = 0; ni < 5; ++ni) {
+                        f32x4 v = acc[mi][ni];
+                        if (LNF) ln_fold4(v, ni, mi);
+                        else if (p.bias) { v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w; }
+                        uint2 pk;
+                        pk.x = pack2bf(v[0] * gg[2 * ni].x, v[1] * gg[2 * ni].y);
+                        pk.y = pack2bf(v[2] * gg[2 * ni + 1].x, v[3] * gg[2 * ni + 1].y);
+                        *(uint2*)(wrow + ni * 32) = pk;
+                    }
+#else
 #pragma unroll
                     for (int ni = 0; ni < 5; ++ni) {
                         f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
@@ -775,6 +801,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                         pk.y = pack2bf(h23.x, h23.y);
                         *(uint2*)(wrow + ni * 32) = pk;
                     }
+#endif
                 }
                 wave_lds_sync();
 #pragma unroll

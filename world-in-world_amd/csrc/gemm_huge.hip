@@ -29,6 +29,10 @@
 #include <type_traits>
 
 #include "common.h"
+#ifndef WIW_GE_PK
+#define WIW_GE_PK 0   // 1: GEGLU epilogue on packed pairs, breadth first (gelu_erf_pk) — measured 3 % SLOWER here (K = 640: 595 vs
+                      // 577 us, K = 1280: 420 vs 415 us, profiles/r06a_geglu_epilogue_ab.txt; +3 % in the 128x160 kernel of gemm.hip)
+#endif
 
 namespace {
 
@@ -535,6 +539,29 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 #pragma unroll
                     for (int m2 = 0; m2 < 2; ++m2) {
                         char* wrow = stg + (m2 * 16 + frow) * HSTG_ROWB_G + fq * 8;
+#if WIW_GE_PK
+                        // the 20 gates of these 16 rows as two blocks of five packed pairs, breadth first (gelu_erf_pk in
+                        // common.h; ten pairs at once cost 55 more spilled registers next to the 160 accumulators)
+                        wiw_f32x2 ga[5], gb[5];
+#pragma unroll
+                        for (int ni = 0; ni < 5; ++ni) {
+                            f32x4 g = acc[hh * 2 + m2][ni + 5];
+                            if (p.bias) { g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w; }
+                            ga[ni] = wiw_f32x2{g[0], g[1]};
+                            gb[ni] = wiw_f32x2{g[2], g[3]};
+                        }
+                        gelu_erf_pk<5>(ga);
+                        gelu_erf_pk<5>(gb);
+#pragma unroll
+                        for (int ni = 0; ni < 5; ++ni) {
+                            f32x4 v = acc[hh * 2 + m2][ni];
+                            if (p.bias) { v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w; }
+                            uint2 pk;
+                            pk.x = pack2bf(v[0] * ga[ni].x, v[1] * ga[ni].y);
+                            pk.y = pack2bf(v[2] * gb[ni].x, v[3] * gb[ni].y);
+                            *(uint2*)(wrow + ni * 32) = pk;
+                        }
+#else
 #pragma unroll
                         for (int ni = 0; ni < 5; ++ni) {
                             f32x4 v = acc[hh * 2 + m2][ni], g = acc[hh * 2 + m2][ni + 5];
@@ -547,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                             pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
                             *(uint2*)(wrow + ni * 32) = pk;
                         }
+#endif
                     }
                     wave_lds_sync();
 #pragma unroll
