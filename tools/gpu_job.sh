@@ -2,9 +2,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-SHAPES="64512,5120,640,0,1 16128,10240,1280,0,1 258048,2560,320,0,1"
+echo "== tests"; timeout 900 python -m pytest tests/test_hip_temporal_block.py -q -m gpu 2>&1 | tail -3 | tee $O/tests.log
+WIW_TEMPORAL_RING=1 timeout 900 python -m pytest tests/test_hip_temporal_block.py -q -m gpu 2>&1 | tail -3 | tee -a $O/tests.log
 for r in 1 2; do
-echo "== GEGLU epilogue new (packed) round $r"; TILED=1 timeout 300 python tools/gemm_probe.py $SHAPES 2>&1 | tail -4 | tee -a $O/gepk_new.log
-echo "== GEGLU epilogue old round $r"; WIW_LIB=tools/ablate/libwiw_gepk0.so TILED=1 timeout 300 python tools/gemm_probe.py $SHAPES 2>&1 | tail -4 | tee -a $O/gepk_old.log
+echo "-- default"; ONLY_FUSED=1 timeout 300 python tools/temporal_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $O/temporal_default.log
+echo "-- ring forced"; WIW_TEMPORAL_RING=1 SHAPES="2,14,9216,5" ONLY_FUSED=1 timeout 300 python tools/temporal_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $O/temporal_ring.log
 done
-echo "== tests"; timeout 1500 python -m pytest tests/test_hip_kernels.py tests/test_hip_ffn.py tests/test_hip_unet.py tests/test_hip_fp16.py -x -q -m gpu 2>&1 | tail -4 | tee $O/tests.log
+echo "== wider tests"; timeout 1500 python -m pytest tests/test_hip_served_width.py tests/test_hip_fp16.py tests/test_hip_unet.py tests/test_hip_kernels.py -x -q -m gpu 2>&1 | tail -3 | tee -a $O/tests.log

@@ -37,8 +37,10 @@ def main():
     hip = H.Hip(dev)
     iters = int(os.environ.get("ITERS", "20"))
     only_fused = bool(os.environ.get("ONLY_FUSED"))
-    B, T = 2, 14
-    for S, heads in ((9216, 5), (2304, 10), (576, 20), (144, 20)):
+    shapes = [(2, 14, 9216, 5), (2, 14, 2304, 10), (2, 14, 576, 20), (2, 14, 144, 20)]
+    if os.environ.get("SHAPES"):   # "B,T,S,heads;..."  e.g. 1152,14,16,5: the L0 work with all frames of a site tile in one 2-MiB page
+        shapes = [tuple(int(v) for v in sp.split(",")) for sp in os.environ["SHAPES"].split(";")]
+    for B, T, S, heads in shapes:
         C = heads * 64
         M = B * T * S
         x = (torch.randn(M, C, device=dev) * 1.5 + 0.2).to(torch.bfloat16)
@@ -48,7 +50,7 @@ def main():
         o = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
         us_f = timeit(lambda: hip.temporal_attn_block(x, wg, fold, o, C, B, T, S, heads, 1e-5, 0.125), iters)
         flops = 2.0 * M * 3 * C * C + 2.0 * B * S * heads * (2 * T * T * 64)
-        line = f"S={S} C={C} M={M}: fused {us_f:8.1f} us  {flops / us_f / 1e6:7.1f} TFLOP/s"
+        line = f"B={B} T={T} S={S} C={C} M={M}: fused {us_f:8.1f} us  {flops / us_f / 1e6:7.1f} TFLOP/s"
         if not only_fused:
             wqkv = torch.cat([wq, wk, wv]).to(torch.bfloat16).contiguous()
             a = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
@@ -63,6 +65,17 @@ def main():
             us_c = timeit(chain, iters)
             line += f" | unfused chain {us_c:8.1f} us ({us_c / us_f:.2f}x)"
         print(line, flush=True)
+        if hasattr(hip.lib, "wiw_temporal_rtrace_read") and C <= 320 and not os.environ.get("WIW_TEMPORAL_RING"):
+            import ctypes as Ct
+            rb = (Ct.c_longlong * 128)()
+            hip.lib.wiw_temporal_rtrace_read.argtypes = [Ct.c_void_p]
+            assert hip.lib.wiw_temporal_rtrace_read(rb) == 0
+            t0 = min(rb[w * 16] for w in range(8))
+            nk = C // 64
+            for w in range(8):
+                t = [rb[w * 16 + i] for i in range(16)]
+                kt = " ".join(f"[ld+wait {t[2 + 2 * k] - t[1 + 2 * k]} mma {(t[3 + 2 * k] if k + 1 < nk else t[11]) - t[2 + 2 * k]}]" for k in range(nk))
+                print(f"   wave {w}: item starts at +{t[0] - t0}, K tiles {kt} | epilogue {t[12] - t[11]} | item {t[12] - t[0]}")
 
 
 if __name__ == "__main__":

@@ -43,6 +43,15 @@ WIW_DEV uint32_t pack2bf(float lo, float hi) {
 }
 #define WIW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
+// c + a.lo*b.lo + a.hi*b.hi on one packed 16-bit pair in ONE VALU instruction (v_dot2c_f32_bf16 / v_dot2c_f32_f16, fp32
+// products and sum) — row statistics straight from MFMA operand registers, no unpack
+WIW_DEV float dot2_acc(uint32_t a, uint32_t b, float c) {
+#ifdef WIW_F16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(wiw_h16x2, a), __builtin_bit_cast(wiw_h16x2, b), c, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wiw_bf16x2, a), __builtin_bit_cast(wiw_bf16x2, b), c, false);
+#endif
+}
 WIW_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); }
 WIW_DEV float silu_f(float x) {   // x * sigmoid(x) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; output is bf16)
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
