@@ -4,12 +4,14 @@
 // registers and no operand needs a transpose in LDS:
 //     S^T = K . Q^T        A = K rows (keys x d),      B = Q rows (queries x d)
 //     O^T = V^T . P^T      A = V^T rows (d x keys),    B = P^T  (from the S^T accumulator itself)
-// The MFMA C/D layout (lane l, reg r: row = 4*(l>>4) + r, col = l & 15) gives every lane 4 consecutive
-// KEYS of one QUERY (l & 15); two such fragments are exactly the 8-element B operand of the next
-// MFMA when the K index of that MFMA is enumerated as  key(q, e) = 16*(e>>2) + 4*q + (e&3)
-// (q = l>>4).  The V^T A operand is read from LDS with the same enumeration (two 8-byte reads), so
-// the contraction is consistent.  Query statistics live in the lanes that own the query column —
-// the O^T accumulator has the same column ownership, so rescaling needs no cross-lane traffic.
+// The MFMA C/D layout (lane l, reg r: row = 4*(l>>4) + r, col = l & 15) gives every lane 4 rows of one QUERY column
+// (l & 15) per fragment; two such fragments are the 8-element B operand of the next MFMA.  Spatial kernel: the K rows
+// are assigned to fragment rows so that those 8 values are 8 CONSECUTIVE keys (see the S^T loop), i.e. the natural K
+// enumeration, and the V^T A operand is one 16-byte LDS read.  Temporal kernel (<= 16 keys): row = key, the K index of
+// the second MFMA enumerated as key(q, e) = 16*(e>>2) + 4*q + (e&3) (q = l>>4).  Query statistics live in the lanes
+// that own the query column — the O^T accumulator has the same column ownership, so rescaling needs no cross-lane traffic.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -20,17 +22,44 @@ WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// v_max_f32 / v_max3_f32 without the canonicalising self-max hipcc puts in front of fmaxf (IEEE NaN quieting): the softmax
+// loop is VALU-ISSUE bound (tools/ubench/mfma_valu_overlap.hip: next to a streaming MFMA partner a wave gets ONE VALU issue
+// per MFMA, the rest costs ~5.4 cycles each), so every instruction of it counts.  A NaN score still ends in a NaN row
+// (its exp2 is NaN whatever the reference maximum is).
+WIW_DEV float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+WIW_DEV float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+WIW_DEV float xor16_max_raw(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+WIW_DEV float xor32_max_raw(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // ---------------------------------------------------------------------------------------------
-// Spatial flash attention.  Block = 4 waves = 128 queries of one (frame, head); KV tiles of 64 keys
+// Spatial flash attention.  Block = NWV waves = 32 * NWV queries of one (frame, head); KV tiles of 64 keys
 // double-buffered in LDS by LDS-DMA (K tile 8 KiB [key][d], V^T tile 8 KiB [d][key]).
 // ---------------------------------------------------------------------------------------------
-constexpr int QB = 128, KB = 64;
+constexpr int KB = 64;   // queries per block: 32 per wave, NWV = 4 or 8 waves
 constexpr int KV_STAGE = 16384;   // K tile + V^T tile
 
-__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
+// NWV = 4 in production; NWV = 8 (WIW_ATTN_8WAVES=1, S >= 2048) is the measured-slower A/B form, see the launcher.
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
                                                                const uint16_t* __restrict__ Vt, int64_t ldvt,
                                                                uint16_t* __restrict__ O, int ldo, int S, int heads,
                                                                int q_tiles, float scale_log2e, const char* zeros) {
+    constexpr int QB = NWV * 32;
+    constexpr int NI = 8 / NWV;        // 8-row DMA instructions per wave and operand tile (64 rows): 2 or 1
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,28 +90,28 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
     // 64 rows of QK for K, 128 bytes of a V^T row); only the last tile needs the clamped / zero-filled form.
     const int rsub = lane >> 3, pos = lane & 7;
     const int nkt = (S + KB - 1) / KB;
-    const char* kp[2];
-    const char* vp[2];
+    const char* kp[NI];
+    const char* vp[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 16 + i * 8 + rsub;            // row of the tile (key for K, d for V^T)
+    for (int i = 0; i < NI; ++i) {
+        const int r = (wave * NI + i) * 8 + rsub;          // row of the tile (key for K, d for V^T)
         kp[i] = (const char*)(QK + (row0 + r) * ldqk + k_col_off + h * 64 + (pos ^ (r & 7)) * 8);
         vp[i] = (const char*)(Vt + (int64_t)(h * 64 + r) * ldvt + row0 + (pos ^ ((r >> 1) & 7)) * 8);
     }
     const int64_t kstep = (int64_t)KB * ldqk * 2;
     auto issue = [&](int stage, int kt) {
-        char* sK = smem + stage * KV_STAGE + wave * 2 * 1024;
-        char* sV = smem + stage * KV_STAGE + 8192 + wave * 2 * 1024;
+        char* sK = smem + stage * KV_STAGE + wave * NI * 1024;
+        char* sV = smem + stage * KV_STAGE + 8192 + wave * NI * 1024;
         if ((kt + 1) * KB <= S) {   // full tile (wave-uniform)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 glds16(kp[i], sK + i * 1024);
                 glds16(vp[i], sV + i * 1024);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wave * 16 + i * 8 + rsub;
+            for (int i = 0; i < NI; ++i) {
+                const int r = (wave * NI + i) * 8 + rsub;
                 // K rows past the end re-read the last key (masked to -inf below); V^T chunks past the end read zeros
                 const int key = kt * KB + r;
                 const char* ksrc = key < S ? kp[i] : kp[i] - (int64_t)(key - (S - 1)) * ldqk * 2;
@@ -93,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         }
 #ifndef WIW_ATTN_STATIC_KV   // ablation build: every tile re-reads KV tile 0 (cache-hot operands)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { kp[i] += kstep; vp[i] += KB * 2; }
+        for (int i = 0; i < NI; ++i) { kp[i] += kstep; vp[i] += KB * 2; }
 #endif
     };
 
@@ -122,9 +151,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         f32x4 s[4][2];
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
-            const char* rowp = sK + (kf * 16 + fr) * 128;
-            const bf16x8 k0 = *(const bf16x8*)(rowp + (((0 + fq) ^ (fr & 7)) << 4));
-            const bf16x8 k1 = *(const bf16x8*)(rowp + (((4 + fq) ^ (fr & 7)) << 4));
+            // Which key sits in which row of a fragment is free.  Row i of fragment kf holds key
+            //     32*(kf>>1) + 8*(i>>2) + 4*(kf&1) + (i&3),
+            // so that the S^T accumulators of fragments 2ks, 2ks+1 of lane (query fr, fq) are the EIGHT CONSECUTIVE keys
+            // 32*ks + 8*fq .. +7: the P^T B operand of k-step ks in the natural K enumeration, and its V^T A operand is
+            // one aligned 16-byte LDS read (the round-2 row = key mapping needed two 8-byte pieces 32 B apart per
+            // operand: 24 v_mov per tile to assemble them).
+            const int krow = (kf >> 1) * 32 + (fr >> 2) * 8 + (kf & 1) * 4 + (fr & 3);
+            const char* rowp = sK + krow * 128;
+            const bf16x8 k0 = *(const bf16x8*)(rowp + (((0 + fq) ^ (krow & 7)) << 4));
+            const bf16x8 k1 = *(const bf16x8*)(rowp + (((4 + fq) ^ (krow & 7)) << 4));
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -142,26 +178,26 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kt * KB + kf * 16 + fq * 4 + r >= S) s[kf][f][r] = -INFINITY;
+                        if (kt * KB + (kf >> 1) * 32 + fq * 8 + (kf & 1) * 4 + r >= S) s[kf][f][r] = -INFINITY;
         }
         uint32_t pb[2][4][2];   // [query frag][key frag][2 dwords] = packed bf16x4 B operands of the K = 16 MFMAs
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-            float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), s[0][f][2]);   // chains of max(max(a, b), c) -> v_max3_f32
-            mx = fmaxf(fmaxf(mx, s[0][f][3]), s[1][f][0]);
-            mx = fmaxf(fmaxf(mx, s[1][f][1]), s[1][f][2]);
-            mx = fmaxf(fmaxf(mx, s[1][f][3]), s[2][f][0]);
-            mx = fmaxf(fmaxf(mx, s[2][f][1]), s[2][f][2]);
-            mx = fmaxf(fmaxf(mx, s[2][f][3]), s[3][f][0]);
-            mx = fmaxf(fmaxf(mx, s[3][f][1]), s[3][f][2]);
-            mx = fmaxf(mx, s[3][f][3]);
-            mx = xor16_max(mx);
-            mx = xor32_max(mx);
+            float ma = max3_raw(s[0][f][0], s[0][f][1], s[0][f][2]);   // two interleaved chains (dependent VALU: 8.5 cycles each)
+            float mb = max3_raw(s[2][f][0], s[2][f][1], s[2][f][2]);
+            ma = max3_raw(ma, s[0][f][3], s[1][f][0]);
+            mb = max3_raw(mb, s[2][f][3], s[3][f][0]);
+            ma = max3_raw(ma, s[1][f][1], s[1][f][2]);
+            mb = max3_raw(mb, s[3][f][1], s[3][f][2]);
+            float mx = max3_raw(ma, mb, s[1][f][3]);
+            mx = max_raw(mx, s[3][f][3]);
+            mx = xor16_max_raw(mx);
+            mx = xor32_max_raw(mx);
             // Lazy rescale: the running reference m_run only has to bound the exponents, not equal the maximum; it is
             // raised (and l, O rescaled) when some query of the wave exceeds it by more than 2^8 — after the first
             // tiles that is rare, so the 32-register rescale and its exp2 leave the steady-state loop.  The result
             // sum(p v) / sum(p) does not depend on the reference.
-            const float m_new = fmaxf(m_run[f], mx * scale_log2e);
+            const float m_new = max_raw(m_run[f], mx * scale_log2e);
             if (__builtin_amdgcn_ballot_w64(m_new > m_run[f] + 8.0f) != 0) {   // wave-uniform branch
                 const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
                 m_run[f] = m_new;
@@ -171,32 +207,27 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                     o[d][f][0] *= alpha; o[d][f][1] *= alpha; o[d][f][2] *= alpha; o[d][f][3] *= alpha;
                 }
             }
-            const float m_ref = m_run[f];
+            // p = exp2(s*c - m_ref): one PACKED fma per two scores; fma / exp2 / convert interleaved by the compiler
+            const wiw_f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_run[f], -m_run[f]};
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][0], scale_log2e, -m_ref));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][1], scale_log2e, -m_ref));
-                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][2], scale_log2e, -m_ref));
-                const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kf][f][3], scale_log2e, -m_ref));
-                pb[f][kf][0] = pack2bf(p0, p1);
-                pb[f][kf][1] = pack2bf(p2, p3);
+                const wiw_f32x2 t01 = __builtin_elementwise_fma(wiw_f32x2{s[kf][f][0], s[kf][f][1]}, c2, nm2);
+                const wiw_f32x2 t23 = __builtin_elementwise_fma(wiw_f32x2{s[kf][f][2], s[kf][f][3]}, c2, nm2);
+                pb[f][kf][0] = pack2bf(__builtin_amdgcn_exp2f(t01.x), __builtin_amdgcn_exp2f(t01.y));
+                pb[f][kf][1] = pack2bf(__builtin_amdgcn_exp2f(t23.x), __builtin_amdgcn_exp2f(t23.y));
             }
         }
-        // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps).  (K = 16 MFMAs would take the 8-byte LDS
-        // pieces and the packed S^T pairs as they are, without operand assembly moves, but v_mfma_f32_16x16x16_bf16
-        // runs at half the rate of the K = 32 form on gfx950: measured -3 %.)
+        // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps); both operands in the natural K enumeration
+        // thanks to the key permutation of the S^T fragments above
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int drow = d * 16 + fr;
-            const char* rowp = sV + drow * 128 + (fq & 1) * 8;
+            const char* rowp = sV + drow * 128;
             const int sw = (drow >> 1) & 7;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int c = ks * 4 + (fq >> 1);
-                const uint2 lo = *(const uint2*)(rowp + ((c ^ sw) << 4));
-                const uint2 hi = *(const uint2*)(rowp + (((c + 2) ^ sw) << 4));
                 union { uint32_t u[4]; bf16x8 v; } va;
-                va.u[0] = lo.x; va.u[1] = lo.y; va.u[2] = hi.x; va.u[3] = hi.y;
+                va.v = *(const bf16x8*)(rowp + (((ks * 4 + fq) ^ sw) << 4));   // keys 32*ks + 8*fq .. +7 of d row drow
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     union { uint32_t u[4]; bf16x8 v; } pv;
@@ -324,12 +355,22 @@ extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int
     WIW_REQUIRE(frames > 0 && S > 0 && heads > 0, "attn_spatial: bad sizes");
     WIW_REQUIRE(S % 8 == 0, "attn_spatial: S (= h*w of the level) must be a multiple of 8");
     WIW_REQUIRE(ldqk % 8 == 0 && k_col_off % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "attn_spatial: misaligned strides");
-    const int q_tiles = (S + QB - 1) / QB;
+    // 8 waves (256 queries) per staged KV tile halve the LDS-DMA instructions per flop but measured 9-10 % SLOWER at
+    // S = 9216 / 2304 (3.80 vs 3.45 ms, profiles/r06q_attn_probe.txt: twice the waves behind every tile barrier); A/B knob
+    static const bool want8 = getenv("WIW_ATTN_8WAVES") != nullptr;
+    const bool big = S >= 2048 && want8;
+    const int qb = big ? 256 : 128;
+    const int q_tiles = (S + qb - 1) / qb;
     const int64_t nb = (int64_t)q_tiles * heads * frames;
     WIW_REQUIRE(nb < (1ll << 31), "attn_spatial: grid too large");
-    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QK,
-                       ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
-                       (const char*)zeros);
+    if (big)
+        hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)QK,
+                           ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
+                           (const char*)zeros);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QK,
+                           ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
+                           (const char*)zeros);
     return wiw_check_launch("wiw_attn_spatial_bf16");
 }
 
