@@ -31,14 +31,15 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 8   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 9   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
                              6: WiwGemmArgs gained lnfold / ln_eps (WIW_EPI_LNFOLD);
                              7: the training entry points settled: wiw_colsum sums CONTIGUOUS row ranges, wiw_attn_bwd_bf16
                                 takes NULL transposes on its LDS-tiled path, wiw_gather_taps_t_bf16, wiw_wgrad_tn_bf16;
-                             8: wiw_ffn_geglu_bf16 (fused LayerNorm + GEGLU FeedForward of the C = 320 level) */
+                             8: wiw_ffn_geglu_bf16 (fused LayerNorm + GEGLU FeedForward of the C = 320 level);
+                             9: wiw_ema_step_f32 (EMAModel.step of --use_ema) */
 
 int wiw_abi_version(void);
 
@@ -332,6 +333,10 @@ int wiw_adamw_step(void* stream, float* p, const float* g, float* m, float* v, v
                    float beta2, float eps, float weight_decay, int step);
 int wiw_edm_loss_grad(void* stream, const float* pred, const float* noisy, const float* target, int64_t n, float sigma,
                       float* grad, float* partial, int n_partial);
+/* wiw_ema_step_f32: `EMAModel.step` of `--use_ema` (dp/training_utils.py:425-472, train_svd.py:979-980) on a flat fp32 range:
+ *   shadow -= one_minus_decay * (shadow - param), the three fp32 operations in that order (bit-identical to the reference's
+ *   `s_param.sub_(one_minus_decay * (s_param - param))`).  Pointers 16-byte aligned. */
+int wiw_ema_step_f32(void* stream, float* shadow, const float* param, int64_t n, float one_minus_decay);
 
 /* Backward building blocks of the same row (16-bit activations and activation gradients, fp32 parameter gradients; all
  * deterministic: fixed-order partials, no floating-point atomics).  The GEMM-shaped gradients (dX = dY . W, dW = dY^T . X) are

@@ -20,6 +20,8 @@ Fixtures written (all fp32 unless noted):
                            TransformerSpatioTemporalModel captured by forward hooks
   frontend_tiny.npz        AutoencoderKLTemporalDecoder encode-mode / decode and `_resize_with_antialiasing` (tiny random VAE)
   unet_schema.json         names + shapes of the served UNet's 1 438 state-dict tensors (reference class, meta device)
+  ema_steps.npz            EMAModel (--use_ema) stepped over a drifting tiny UNet: decays, parameter / shadow trajectories, the
+                           outcome of its save_pretrained (raises on the reference's UNet class)
   unet_full_16x32.npz      FULL-WIDTH UNet (320/640/1280/1280, 5/10/20/20 heads, T = 14 — the served architecture) forward
                            at latent 16x32, B=1 with CFG: fp32 reference output, the reference's own bf16 run, and the
                            reference run in fp32 with bf16-ROUNDED WEIGHTS (the error floor of any bf16-weight evaluation)
@@ -258,6 +260,60 @@ def gen_schema(ns):
         print(f"wrote {os.path.join(OUT, name)}")
 
 
+def gen_ema(ns):
+    """`--use_ema` (train_svd.py:566-568, 979-980, 588-589): the reference's EMAModel, built exactly as the training script
+    builds it, stepped 14 times over a drifting tiny UNet with a FROZEN subset (requires_grad False, as `--train_param_type
+    new` leaves most of the network).  Stored: the decay of every step, three parameters' trajectories and their shadows
+    after every step (fp32, bit patterns), and the config.json `ema_unet.save_pretrained` writes."""
+    import tempfile
+
+    from diffusers.training_utils import EMAModel
+
+    cfg = UNetConfig.tiny(4)
+    unet = ref_unet(ns, cfg, seed=5).float()
+    names = [n for n, _ in unet.named_parameters()]
+    small = [n for n, p in unet.named_parameters() if "action" in n and p.numel() <= 4096]
+    watch = ["conv_in.weight", "time_embedding.linear_1.bias", small[0]]
+    frozen = {"conv_in.weight"}
+    for n, p in unet.named_parameters():
+        p.requires_grad_(n not in frozen)
+    ema = EMAModel(unet.parameters(), model_cls=type(unet), model_config=unet.config)
+    g = torch.Generator().manual_seed(11)
+    params = dict(unet.named_parameters())
+    out = {"watch": np.array(watch), "frozen": np.array(sorted(frozen)), "decays": []}
+    for w in watch:
+        out[f"p0.{w}"] = params[w].detach().numpy().copy()
+    idx = {n: i for i, n in enumerate(names)}
+    for step in range(14):
+        with torch.no_grad():
+            for w in watch:
+                params[w].add_(0.05 * torch.randn(params[w].shape, generator=g))
+        ema.step(unet.parameters())
+        out["decays"].append(ema.cur_decay_value)
+        for w in watch:
+            out[f"p{step + 1}.{w}"] = params[w].detach().numpy().copy()
+            out[f"s{step + 1}.{w}"] = ema.shadow_params[idx[w]].detach().numpy().copy()
+    out["decays"] = np.array(out["decays"], np.float64)
+    # `ema_unet.save_pretrained` (train_svd.py:588-589) re-creates the model with `model_cls.from_config(model_config)`; on the
+    # reference's UNet class that raises (UnboundLocalError: `action_attention_dim`, unet_spatio_temporal_condition.py:193 — the
+    # saved config does not carry what __init__ branches on), i.e. `--use_ema` cannot write a checkpoint in the reference as it
+    # stands (train_svd.sh runs without it).  The outcome is recorded; the unet_ema/ layout of checkpoint.py follows
+    # EMAModel.save_pretrained's code (training_utils.py:390-403), not a produced file.
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            ema.save_pretrained(d)
+            with open(os.path.join(d, "config.json")) as f:
+                txt = f.read()
+        with open(os.path.join(OUT, "unet_ema_config_tiny.json"), "w") as f:
+            f.write(txt)
+        out["save_pretrained"] = np.array("ok")
+    except Exception as e:   # noqa: BLE001
+        out["save_pretrained"] = np.array(f"{type(e).__name__}: {e}")
+    out["state_keys"] = np.array(sorted(k for k in ema.state_dict() if k != "shadow_params"))
+    np.savez_compressed(os.path.join(OUT, "ema_steps.npz"), **out)
+    print(f"wrote {os.path.join(OUT, 'ema_steps.npz')}; save_pretrained: {out['save_pretrained']}; decays {out['decays'][:4]} ... {out['decays'][-1]}")
+
+
 def gen_pipeline(ns):
     from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
     from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
@@ -379,7 +435,7 @@ def main():
     ns = import_reference()
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
-                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema)
+                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

@@ -69,6 +69,12 @@ def _st_res(sd: SD, p: str, x, T: int):
 
 def vae_encode_mode(sd: SD, x: torch.Tensor, n_blocks: int = 4, layers_per_block: int = 2) -> torch.Tensor:
     """(B,3,H,W) in [-1,1] -> latent_dist.mode() (B,4,H/8,W/8); NOT multiplied by scaling_factor (pipeline:239)."""
+    return vae_encode_moments(sd, x, n_blocks, layers_per_block)[0]
+
+
+def vae_encode_moments(sd: SD, x: torch.Tensor, n_blocks: int = 4, layers_per_block: int = 2):
+    """(B,3,H,W) in [-1,1] -> (mean, logvar) of `vae.encode(x).latent_dist` (DiagonalGaussianDistribution: logvar clamped to
+    [-30, 20], dp/models/autoencoders/vae.py): what `.sample()` = mean + exp(0.5 logvar) eps uses (train_svd.py:86-95)."""
     h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
     for i in range(n_blocks):
         for j in range(layers_per_block):
@@ -82,7 +88,8 @@ def vae_encode_mode(sd: SD, x: torch.Tensor, n_blocks: int = 4, layers_per_block
     h = F.silu(_gn(sd, "encoder.conv_norm_out", h, 1e-6))
     h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
     m = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
-    return m[:, : m.shape[1] // 2]
+    L = m.shape[1] // 2
+    return m[:, :L], torch.clamp(m[:, L:], -30.0, 20.0)
 
 
 def vae_decode(sd: SD, z: torch.Tensor, num_frames: int, n_blocks: int = 4, layers_per_block: int = 2) -> torch.Tensor:

@@ -160,3 +160,59 @@ def test_hip_frontend_protocol(vae_pair):
     u8 = fe.decode_uint8(lat)
     assert u8.shape == (2, 4, 128, 256, 3) and u8.dtype == np.uint8
     assert np.abs(u8[0].astype(np.int16) - ref.astype(np.int16)).mean() < 0.5
+
+
+def test_vae_encode_moments_and_training_batch_from_pixels(vae_pair):
+    """The training front from PIXELS (train_svd.py:846-931): `VAEHIP.encode_moments` (mean | clamped logvar of latent_dist)
+    against the fp32 chain, and `train.batch_from_pixels` — sample() of the clip's frames x scaling_factor, rotated latent
+    noise, the noise-augmented first frame's sample as conditioning, CLIP of the past observation, EDM input scaling —
+    against the same composition on the oracle with the SAME random draws."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from wiw_amd import train as T
+    from wiw_amd.pipeline import action_ids_idx_encode, rotate_latent_noise
+    from wiw_amd.vae import HIPFrontend
+
+    vae, sd = vae_pair
+    nb, lpb = len(VCFG["block_out_channels"]), VCFG["layers_per_block"]
+    Tn, H, W = 4, 128, 256
+    px = torch.tanh(rnd(1, Tn, 3, H, W, seed=21))
+    mean, logvar = vae.encode_moments(px[0])
+    rmean, rlogvar = VO.vae_encode_moments(sd, px[0], nb, lpb)
+    (mx1, r1), (mx2, r2) = rel(mean, rmean), rel(logvar, rlogvar)
+    print(f"[parity] VAE encode_moments {Tn}x{H}x{W}: mean rms_rel={r1:.3e} logvar rms_rel={r2:.3e}")
+    assert mean.shape == (Tn, 4, H // 8, W // 8) and r1 <= 3e-2 and r2 <= 3e-2
+    assert torch.equal(mean.cpu(), vae.encode_mode(px[0]).cpu())          # the mean half is the serving path's mode(), bit for bit
+
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=1024)).eval()
+    fe = HIPFrontend(vae, clip, dtype=torch.float32, clip="torch")
+    acts = np.array([[1, 2, 1, 3]])
+    h, w = H // 8, W // 8
+    draws = dict(vae_eps=rnd(Tn, 4, h, w, seed=22), cond_eps=rnd(1, 4, h, w, seed=23), pixel_noise=rnd(1, 3, H, W, seed=24),
+                 latent_noise=rnd(1, Tn, 4, h, w, seed=25), sigma=1.7, cond_sigma=0.043)
+    past = torch.tanh(rnd(1, 1, 3, H, W, seed=26))
+    st = T.batch_from_pixels(fe, px, past, acts, draws=draws)
+    sf = vae.scaling_factor
+    lat = ((rmean + torch.exp(0.5 * rlogvar) * draws["vae_eps"]) * sf)[None]
+    noise = rotate_latent_noise(draws["latent_noise"], acts)
+    cm, cl = VO.vae_encode_moments(sd, px[0, 0:1] + draws["pixel_noise"] * 0.043, nb, lpb)
+    cond = cm + torch.exp(0.5 * cl) * draws["cond_eps"]
+    noisy = lat + noise * 1.7
+    inp = torch.cat([noisy / (1.7 ** 2 + 1) ** 0.5, cond.unsqueeze(1).repeat(1, Tn, 1, 1, 1)], dim=2)
+    (_, rt), (_, ri) = rel(st.target, lat), rel(st.unet_input, inp)
+    print(f"[parity] batch_from_pixels: target rms_rel={rt:.3e} unet_input rms_rel={ri:.3e}")
+    assert st.unet_input.shape == (1, Tn, 8, h, w) and rt <= 3e-2 and ri <= 3e-2
+    assert st.sigma == 1.7 and st.timestep == pytest.approx(0.25 * math.log(1.7)) and st.ehs.shape == (1, 1, 1024)
+    assert torch.equal(st.action_ids, torch.from_numpy(action_ids_idx_encode(acts)))
+    assert st.added_time_ids.tolist() == [[7.0, 127.0, pytest.approx(0.043)]]
+    # turn at frame 1 (action 2): the noise of frame 1 is frame 0's, rolled by W/16 latent columns (pipeline:750-786)
+    assert torch.equal((st.noisy - st.target)[0, 1], torch.roll((st.noisy - st.target)[0, 0], w // 16, dims=-1)) or \
+        torch.allclose((st.noisy - st.target)[0, 1], torch.roll((st.noisy - st.target)[0, 0], w // 16, dims=-1), atol=1e-5)
+    # drawn, not injected: a seeded generator reproduces itself and differs from another seed
+    a = T.batch_from_pixels(fe, px, past, acts, generator=torch.Generator().manual_seed(5))
+    b = T.batch_from_pixels(fe, px, past, acts, generator=torch.Generator().manual_seed(5))
+    c = T.batch_from_pixels(fe, px, past, acts, generator=torch.Generator().manual_seed(6))
+    assert torch.equal(a.unet_input, b.unet_input) and a.sigma == b.sigma and not torch.equal(a.unet_input, c.unet_input)

@@ -29,6 +29,8 @@ import torch
 
 UNET_FILE = os.path.join("unet", "diffusion_pytorch_model.safetensors")
 UNET_CONFIG_FILE = os.path.join("unet", "config.json")
+EMA_FILE = os.path.join("unet_ema", "diffusion_pytorch_model.safetensors")
+EMA_CONFIG_FILE = os.path.join("unet_ema", "config.json")
 DIFFUSERS_VERSION = "0.31.0"      # the vendored fork's version string (FTsvd/diffusers-private), as it writes it
 
 
@@ -94,10 +96,11 @@ def prune(output_dir: str, total_limit: Optional[int]):
 
 def save_checkpoint(output_dir: str, global_step: int, master: Optional[Dict[str, torch.Tensor]],
                     optimizer: Dict[str, torch.Tensor], meta: dict, rank: int = 0, sharded: bool = False,
-                    total_limit: Optional[int] = None, unet_config: Optional[dict] = None) -> str:
+                    total_limit: Optional[int] = None, unet_config: Optional[dict] = None, ema: Optional[dict] = None) -> str:
     """Write checkpoint-<global_step>.  master: the fp32 parameters (rank 0 writes them; pass None on other ranks);
     optimizer: flat name -> tensor dict (this rank's part when sharded); unet_config: `unet_config_dict(cfg)`, written as
-    unet/config.json next to the weights (the file set of `save_pretrained`).  Returns the directory."""
+    unet/config.json next to the weights (the file set of `save_pretrained`); ema: {"shadow": name -> tensor, "state": dict}
+    of `train_unet.EMAShadow` (`--use_ema`).  Returns the directory."""
     from safetensors.torch import save_file
 
     path = os.path.join(output_dir, f"checkpoint-{global_step}")
@@ -109,12 +112,33 @@ def save_checkpoint(output_dir: str, global_step: int, master: Optional[Dict[str
                 f.write(json.dumps(unet_config, indent=2, sort_keys=True) + "\n")
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump(dict(meta, global_step=int(global_step)), f, indent=1, sort_keys=True)
+    if rank == 0 and ema is not None:
+        # `ema_unet.save_pretrained(<dir>/unet_ema)` (train_svd.py:588-589): the averaged weights as a model directory whose
+        # config.json carries the EMA state next to the architecture (training_utils.py:390-403 registers it into the config)
+        os.makedirs(os.path.join(path, "unet_ema"), exist_ok=True)
+        save_file({k: v.detach().to("cpu", torch.float32).contiguous() for k, v in ema["shadow"].items()},
+                  os.path.join(path, EMA_FILE))
+        with open(os.path.join(path, EMA_CONFIG_FILE), "w") as f:
+            f.write(json.dumps(dict(unet_config or {}, **ema["state"]), indent=2, sort_keys=True) + "\n")
     name = f"optimizer_rank{rank}.safetensors" if sharded else "optimizer.safetensors"
     if rank == 0 or sharded:
         save_file({k: v.detach().to("cpu").contiguous() for k, v in optimizer.items()}, os.path.join(path, name))
     if rank == 0:
         prune(output_dir, total_limit)
     return path
+
+
+EMA_STATE_KEYS = ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power")
+
+
+def load_ema(path: str):
+    """-> (shadow parameters, EMA state) of `checkpoint-<n>/unet_ema` (`EMAModel.from_pretrained`, train_svd.py:600-604)."""
+    from safetensors.torch import load_file
+
+    shadow = load_file(os.path.join(path, EMA_FILE))
+    with open(os.path.join(path, EMA_CONFIG_FILE)) as f:
+        cfg = json.load(f)
+    return shadow, {k: cfg[k] for k in EMA_STATE_KEYS}
 
 
 def load_checkpoint(path: str, rank: int = 0, sharded: bool = False) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor], dict]:

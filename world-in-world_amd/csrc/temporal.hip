@@ -32,6 +32,9 @@
 #include "common.h"
 
 
+#ifndef WIW_T_ABLATE
+#define WIW_T_ABLATE 0    // resident form, timing experiments only: 1 = no epilogue, 2 = no A loads, 4 = no LDS reads of W, 8 = no row statistics
+#endif
 #ifndef WIW_T_STAGGER
 #define WIW_T_STAGGER 1   // resident form: waves 4..7 start half an item late (0: all waves in lock-step, A/B)
 #endif
@@ -604,7 +607,14 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
         const char* sW = smem + (step >> 1) * W_BYTES;
         const int sw = w_off ^ ((step & 1) << 6);
 #pragma unroll
-        for (int ni = hf * 6; ni < hf * 6 + 6; ++ni) fb[ni] = *(const bf16x8*)(sW + ni * 2048 + sw);
+        for (int ni = hf * 6; ni < hf * 6 + 6; ++ni) {
+#if WIW_T_ABLATE & 4
+            if (step == 0) fb[ni] = *(const bf16x8*)(sW + ni * 2048 + sw);
+            asm volatile("" : "+v"(fb[ni]));
+#else
+            fb[ni] = *(const bf16x8*)(sW + ni * 2048 + sw);
+#endif
+        }
     };
     // 12 MFMAs of one half + the LayerNorm statistics of site hf (8 v_dot2c) in their shadow
     auto mma_half = [&](const bf16x8 (&a)[2], auto half_tag) {
@@ -618,6 +628,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
                 else acc[mi][ni] = WIW_MFMA(a[mi], fb[ni], acc[mi][ni]);          // v
             }
         }
+#if !(WIW_T_ABLATE & 8)
         union { bf16x8 v; uint32_t u[4]; } x;
         x.v = a[hf];
 #pragma unroll
@@ -631,6 +642,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 VALU
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
         asm volatile("" : "+v"(sum1[hf]), "+v"(sum2[hf]));
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -662,8 +674,12 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
             // the next A tile (of this item, or tile 0 of the next one) into the other buffer, then wait for THIS tile:
             // younger in the vmcnt queue are those loads and, at kt = 0, the previous item's O stores
             int younger = kt == 0 ? pending_stores : 0;
+#if WIW_T_ABLATE & 2   // timing only: no A loads after the first tile (stale operands)
+            if (false) load_a(fa[P ^ 1], a_ofs, kt + 1);
+#else
             if (kt + 1 < nk) { load_a(fa[P ^ 1], a_ofs, kt + 1); younger += A_LD; }
             else if (has_next) { load_a(fa[P ^ 1], a_nxt, 0); younger += A_LD; }
+#endif
             wait_vmcnt_rt(younger);
             asm volatile("" : "+v"(fa[P][0][0]), "+v"(fa[P][0][1]), "+v"(fa[P][1][0]), "+v"(fa[P][1][1]));
             RTP(2 + 2 * kt);
@@ -685,8 +701,16 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
             if (kt + 1 < nk) ktile(std::integral_constant<int, START ^ 1>{}, kt + 1);
         }
         RTP(11);
+#if WIW_T_ABLATE & 1   // timing only: no attention epilogue (the accumulators are kept alive by an empty asm)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+        asm volatile("" ::"v"(sum1[0]), "v"(sum1[1]), "v"(sum2[0]), "v"(sum2[1]));
+#else
         const int b_cur = mt / p.tiles_per_batch, s0_cur = (mt - b_cur * p.tiles_per_batch) * 16;
         attention_epilogue<TP>(acc, sum1, sum2, fs, ostage + wave * STG_WAVE, p, b_cur, s0_cur, h, wave, lane);
+#endif
         RTP(12);
 #ifdef WIW_T_TRACE
         if (blockIdx.x == 0 && lane == 0 && r_ord == TR_ITEM)
@@ -694,7 +718,11 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
                 g_rtrace[wave][i] = *(volatile __attribute__((address_space(3))) long long*)(lptr_t)(rt_base + (wave * 16 + i) * 8);
         ++r_ord;
 #endif
+#if WIW_T_ABLATE & 1
+        pending_stores = 0;
+#else
         pending_stores = NST;
+#endif
         mt = mt_next;
         a_ofs[0] = a_nxt[0]; a_ofs[1] = a_nxt[1];
         return has_next;

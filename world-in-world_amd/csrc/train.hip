@@ -1366,6 +1366,38 @@ extern "C" int wiw_geglu_bwd(void* stream, const void* P, const void* dH, int64_
     return wiw_check_launch("wiw_geglu_bwd");
 }
 
+// EMAModel.step on a flat range: s -= omd * (s - p) with the three roundings of the reference's tensor expression (no fma
+// contraction), 16 bytes per lane, grid-stride
+WIW_DEV float ema_one(float s, float p, float omd) {
+    float d = omd * (s - p);
+    asm volatile("" : "+v"(d));   // the product is ROUNDED before the subtraction: no fma contraction across this point
+    return s - d;
+}
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ s, const float* __restrict__ p, int64_t n, float omd) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 sv = ((const float4*)s)[i];
+        const float4 pv = ((const float4*)p)[i];
+        sv.x = ema_one(sv.x, pv.x, omd); sv.y = ema_one(sv.y, pv.y, omd);
+        sv.z = ema_one(sv.z, pv.z, omd); sv.w = ema_one(sv.w, pv.w, omd);
+        ((float4*)s)[i] = sv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        s[i] = ema_one(s[i], p[i], omd);
+    }
+}
+
+extern "C" int wiw_ema_step_f32(void* stream, float* shadow, const float* param, int64_t n, float one_minus_decay) {
+    WIW_REQUIRE(shadow && param && n > 0, "ema_step: null pointer or n <= 0");
+    WIW_REQUIRE((((uintptr_t)shadow | (uintptr_t)param) & 15) == 0, "ema_step: pointers must be 16-byte aligned");
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, shadow, param, n, one_minus_decay);
+    return wiw_check_launch("wiw_ema_step_f32");
+}
+
 extern "C" int wiw_adamw_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step) {
     WIW_REQUIRE(p && g && m && v, "adamw: null pointer");

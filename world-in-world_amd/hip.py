@@ -120,6 +120,7 @@ EXPORTS = {
     "wiw_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                      C.c_float, C.c_float, C.c_float]),
     "wiw_transpose_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64]),
+    "wiw_ema_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "wiw_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     "wiw_edm_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
@@ -184,7 +185,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 8:
+        if self.lib.wiw_abi_version() != 9:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -401,6 +402,12 @@ class Hip:
         assert p16 is None or (p16.dtype == self.dtype and p16.numel() == p.numel())
         self._ck(self.lib.wiw_adamw_step(self._stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), lr, beta1, beta2,
                                          eps, weight_decay, step), "wiw_adamw_step")
+
+    def ema_step(self, shadow, param, one_minus_decay: float):
+        """EMAModel.step on flat fp32 tensors, in place: shadow -= one_minus_decay * (shadow - param)."""
+        assert shadow.dtype == param.dtype == torch.float32 and shadow.numel() == param.numel()
+        self._ck(self.lib.wiw_ema_step_f32(self._stream(), _p(shadow), _p(param), shadow.numel(), float(one_minus_decay)),
+                 "wiw_ema_step_f32")
 
     def edm_loss_grad(self, pred, noisy, target, sigma):
         """EDM loss of one sample (fp32 tensors of equal shape) and its gradient w.r.t. `pred`: returns (loss 0-d tensor, grad)."""

@@ -66,6 +66,60 @@ def prepare_step(latents: torch.Tensor, noise: torch.Tensor, sigma: float, cond_
     return StepInputs(inp, 0.25 * float(torch.log(torch.tensor(float(sigma)))), noisy, latents, float(sigma), tids, ehs, action_ids)
 
 
+@torch.no_grad()
+def batch_from_pixels(front, pixel_values: torch.Tensor, past_obs: torch.Tensor, actions, *, scaling_factor: Optional[float] = None,
+                      dropout_prob: Optional[float] = None, generator: Optional[torch.Generator] = None,
+                      draws: Optional[dict] = None) -> StepInputs:
+    """One training sample from PIXELS, as the reference's loop builds it (train_svd.py:846-931), on the HIP front end:
+        latents      = vae.encode(frames).latent_dist.sample() * scaling_factor            (:86-95, :856)
+        noise        = sample_latent_noise(actions, ...)                                    (:873; pipeline:750-786)
+        cond_sigma   = rand_log_normal(-3.0, 0.5); cond image = frame 0 + randn * cond_sigma   (:876-880)
+        cond_latents = vae.encode(cond image).latent_dist.sample()   [* scaling / scaling]   (:881-882)
+        sigma        = rand_log_normal(0.7, 1.6)                                             (:886)
+        ehs          = CLIP(resize_224(past_obs))   (norm_image + feature_extractor normalise + image_encoder, :893-894)
+    then `prepare_step` (noisy latents, EDM input scaling, conditioning dropout, t = 0.25 ln sigma).
+    front: `vae.HIPFrontend` (VAEHIP.encode_moments, CLIPVisionHIP).  pixel_values (1, T, 3, H, W) and past_obs (1, P, 3, H', W')
+    fp32 in [-1, 1]; actions (1, T) ints.  `draws` overrides the random draws (tests / replay): vae_eps (T, L, h, w), cond_eps
+    (1, L, h, w), pixel_noise (1, 3, H, W), latent_noise (1, T, L, h, w), sigma, cond_sigma (floats), random_p ((1,))."""
+    import numpy as np
+
+    from .pipeline import action_ids_idx_encode, rotate_latent_noise
+
+    d = dict(draws or {})
+    vae = front.vae
+    sf = float(vae.scaling_factor if scaling_factor is None else scaling_factor)
+    assert pixel_values.dim() == 5 and pixel_values.shape[0] == 1, "one sample per step, as the reference (train_svd.py:877)"
+    T = pixel_values.shape[1]
+    dev = vae.device
+    px = pixel_values[0].to(dev, torch.float32)
+
+    def randn(name, shape):
+        if name in d:
+            return torch.as_tensor(d[name], dtype=torch.float32).to(dev)
+        return torch.randn(shape, generator=generator).to(dev)
+
+    def sample(x, eps_name):                                   # DiagonalGaussianDistribution.sample(): mean + std * eps
+        mean, logvar = vae.encode_moments(x)
+        return mean + torch.exp(0.5 * logvar) * randn(eps_name, tuple(mean.shape))
+
+    latents = (sample(px, "vae_eps") * sf)[None]                                             # (1, T, L, h, w)
+    acts = np.asarray(actions).reshape(1, T)
+    noise = rotate_latent_noise(randn("latent_noise", tuple(latents.shape)), acts)
+    cond_sigma = float(d["cond_sigma"]) if "cond_sigma" in d else float(rand_log_normal([1], -3.0, 0.5, generator)[0])
+    cond_px = px[0:1] + randn("pixel_noise", tuple(px[0:1].shape)) * cond_sigma
+    cond_latents = sample(cond_px, "cond_eps")                                                # * sf / sf
+    sigma = float(d["sigma"]) if "sigma" in d else float(rand_log_normal([1], 0.7, 1.6, generator)[0])
+    po = past_obs.to(dev, torch.float32)
+    assert po.reshape(-1, *po.shape[-3:]).shape[0] == 1, "one past observation per sample (train_svd.sh; UNetTrain takes (1, 1, D))"
+    e = front._embed(po.reshape(-1, *po.shape[-3:]), None)                                    # (1, 1, D) fp32
+    ehs = e.reshape(1, 1, e.shape[-1])
+    action_ids = torch.from_numpy(action_ids_idx_encode(acts))
+    random_p = None
+    if dropout_prob is not None:
+        random_p = torch.as_tensor(d["random_p"]) if "random_p" in d else torch.rand(1, generator=generator)
+    return prepare_step(latents.cpu(), noise.cpu(), sigma, cond_latents.cpu(), ehs.cpu(), cond_sigma, action_ids, dropout_prob, random_p)
+
+
 # ------------------------------------------------------------------------------------------------
 # backward building blocks on the existing kernels (no new GEMM code: the gradients of a GEMM are GEMMs on transposed operands)
 # ------------------------------------------------------------------------------------------------

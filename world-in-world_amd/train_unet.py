@@ -569,6 +569,83 @@ class UNetTrain:
         return self.grads
 
 
+class EMAShadow:
+    """`diffusers.training_utils.EMAModel` as train_svd.py uses it (`--use_ema`, :566-568: every argument at its default, :979-980
+    one `step` per synchronised optimiser step): fp32 shadow copies of ALL parameters, updated by
+        shadow -= (1 - decay_t) * (shadow - param)          for parameters that train (`requires_grad`),
+        shadow  = param                                     for frozen ones (`--train_param_type`),
+    decay_t = min((1 + s) / (10 + s), decay) with s = optimization_step - update_after_step - 1 (0 while s <= 0; the warm-up
+    form 1 - (1 + s / inv_gamma) ** -power under `use_ema_warmup`), clamped below by min_decay (training_utils.py:405-422).
+    The update runs on `wiw_ema_step_f32` (the reference's three fp32 operations, bit for bit) when a `Hip` is given, else on
+    the same torch expression (CPU tests).  Every rank keeps the full shadow, as under the reference's ZeRO-1."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], trainable=None, hip=None, decay: float = 0.9999, min_decay: float = 0.0,
+                 update_after_step: int = 0, use_ema_warmup: bool = False, inv_gamma: float = 1.0, power: float = 2 / 3):
+        self.shadow = {k: v.detach().clone().to(torch.float32) for k, v in params.items()}
+        self.trainable = trainable or (lambda n: True)
+        self.hip = hip
+        self.decay, self.min_decay, self.update_after_step = float(decay), float(min_decay), int(update_after_step)
+        self.use_ema_warmup, self.inv_gamma, self.power = bool(use_ema_warmup), inv_gamma, power
+        self.optimization_step = 0
+        self.cur_decay_value = None
+        self._stored = None
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        if self.use_ema_warmup:
+            cur = 1 - (1 + step / self.inv_gamma) ** -self.power
+        else:
+            cur = (1 + step) / (10 + step)
+        return max(min(cur, self.decay), self.min_decay)
+
+    @torch.no_grad()
+    def step(self, params: Dict[str, torch.Tensor]) -> None:
+        self.optimization_step += 1
+        decay = self.get_decay(self.optimization_step)
+        self.cur_decay_value = decay
+        omd = 1 - decay
+        for k, s in self.shadow.items():
+            p = params[k]
+            if not self.trainable(k):
+                s.copy_(p)
+            elif self.hip is not None and s.is_cuda:
+                self.hip.ema_step(s.view(-1), p.reshape(-1), omd)
+            else:
+                s.sub_(omd * (s - p))
+
+    def state(self) -> dict:
+        """The non-tensor part of `EMAModel.state_dict()` — what `save_pretrained` registers into unet_ema/config.json."""
+        return {"decay": self.decay, "min_decay": self.min_decay, "optimization_step": self.optimization_step,
+                "update_after_step": self.update_after_step, "use_ema_warmup": self.use_ema_warmup, "inv_gamma": self.inv_gamma,
+                "power": self.power}
+
+    def load(self, shadow: Dict[str, torch.Tensor], state: dict) -> None:
+        assert set(shadow) == set(self.shadow), "unet_ema parameters do not match this architecture"
+        for k, v in shadow.items():
+            self.shadow[k].copy_(v)
+        for k, v in state.items():
+            setattr(self, k, v)
+
+    # validation under the averaged weights (train_svd.py:1004-1007, 1189-1191): store -> copy_to -> ... -> restore
+    @torch.no_grad()
+    def store(self, params: Dict[str, torch.Tensor]) -> None:
+        self._stored = {k: v.detach().clone() for k, v in params.items()}
+
+    @torch.no_grad()
+    def copy_to(self, params: Dict[str, torch.Tensor]) -> None:
+        for k, s in self.shadow.items():
+            params[k].copy_(s)
+
+    @torch.no_grad()
+    def restore(self, params: Dict[str, torch.Tensor]) -> None:
+        assert self._stored is not None, "restore() without store()"
+        for k, v in self._stored.items():
+            params[k].copy_(v)
+        self._stored = None
+
+
 class Trainer:
     """One fine-tuning step of the reference loop (`FTsvd/train_svd.py:844-970`) on one GPU, one sample per step:
         prepare_step -> UNetTrain.forward -> wiw_edm_loss_grad -> UNetTrain.backward -> AdamW -> refreshed 16-bit operands.
@@ -597,7 +674,7 @@ class Trainer:
 
     def __init__(self, net: "UNetTrain", lr: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  optimizer=None, loss_scale: Optional[float] = None, train_param_type: str = "full", grad_accum: int = 1,
-                 autotune: bool = False, scale_growth_interval: int = 2000):
+                 autotune: bool = False, scale_growth_interval: int = 2000, use_ema: bool = False, ema_kwargs: Optional[dict] = None):
         self.net, self.lr, self.betas, self.eps, self.wd = net, lr, betas, eps, weight_decay
         # `--gradient_accumulation_steps` (train_svd.sh:20 runs 4; accelerate averages the micro-batch losses, train_svd.py:
         # 864, 961-969): `step` is one micro-batch, the optimiser runs on every grad_accum-th call with the mean gradient
@@ -622,6 +699,8 @@ class Trainer:
         self._seen = None                                      # names that got a gradient in the previous step
         if optimizer is not None:
             optimizer.load(net.master)
+        # `--use_ema` (train_svd.py:566-568): requires_grad is the `--train_param_type` predicate, not the optimiser's subset
+        self.ema = EMAShadow(net.master, trainable=base, hip=net.hip, **(ema_kwargs or {})) if use_ema else None
 
     def save(self, output_dir: str, total_limit: Optional[int] = None) -> str:
         """`accelerator.save_state(checkpoint-<global_step>)` (train_svd.py:1032-1062): the fp32 parameters in the reference's
@@ -633,16 +712,17 @@ class Trainer:
         meta = {"micro": self._micro, "loss_scale": self.loss_scale, "good_steps": self._good_steps, "grad_accum": self.grad_accum,
                 "lr": self.lr, "wgrad_plans": {k: list(v) for k, v in wgrad_plans().items()}}
         ucfg = C.unet_config_dict(self.net.cfg) if hasattr(self.net, "cfg") else None     # unet/config.json, as save_pretrained
+        ema = None if self.ema is None else {"shadow": self.ema.shadow, "state": self.ema.state()}
         if self.opt is None:
             optim = {f"exp_avg.{k}": v for k, v in self.m.items()}
             optim.update({f"exp_avg_sq.{k}": v for k, v in self.v.items()})
             return C.save_checkpoint(output_dir, self.steps, self.net.master, optim, dict(meta, world=1), total_limit=total_limit,
-                                     unet_config=ucfg)
+                                     unet_config=ucfg, ema=ema)
         o = self.opt
         optim = {"master": o.master, "exp_avg": o.m, "exp_avg_sq": o.v}
         return C.save_checkpoint(output_dir, self.steps, self.net.master if o.rank == 0 else None, optim,
                                  dict(meta, world=o.world, opt_layout=o.layout_fingerprint()), rank=o.rank, sharded=True,
-                                 total_limit=total_limit, unet_config=ucfg)
+                                 total_limit=total_limit, unet_config=ucfg, ema=ema)
 
     def load(self, path: str) -> None:
         """Resume from a directory written by `save` (`checkpoint.resolve_resume` maps "latest" to one)."""
@@ -670,6 +750,8 @@ class Trainer:
         self.steps, self._micro, self.loss_scale = int(meta["global_step"]), int(meta["micro"]), float(meta["loss_scale"])
         self._good_steps = int(meta.get("good_steps", 0))
         self._acc, self._seen = {}, None
+        if self.ema is not None:                              # train_svd.py:600-604: the averaged weights resume from unet_ema/
+            self.ema.load(*C.load_ema(path))
         self.net.refresh()
 
     def _mean_grad(self, name: str, g: torch.Tensor) -> torch.Tensor:
@@ -720,6 +802,8 @@ class Trainer:
                 self.loss_scale *= 0.5
                 self._good_steps = 0
                 self._micro, self._acc = 0, {}
+                if self.ema is not None:                                   # the window is over (`accelerator.sync_gradients`): the
+                    self.ema.step(net.master)                              # reference steps the EMA on a skipped update too (:979)
                 return float(loss)
         self._micro += 1
         if self._micro % self.grad_accum != 0:                             # not the last micro-batch: accumulate, no update
@@ -749,6 +833,8 @@ class Trainer:
                 if p16 is None:
                     stale.add(name)
             net.refresh(stale)                                             # the re-laid-out operands (convolutions, padded inputs)
+            if self.ema is not None:
+                self.ema.step(net.master)
             return float(loss)
         else:
             if not overlapped:                                           # first step, or fp16 (un-scaled after the backward)
@@ -761,6 +847,8 @@ class Trainer:
                 if self.trainable(name):                                 # read back (torch.optim.AdamW skips them too)
                     net.master[name].copy_(self.opt.view(self.opt.params, name))
         net.refresh()
+        if self.ema is not None:
+            self.ema.step(net.master)
         return float(loss)
 
 

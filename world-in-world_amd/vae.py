@@ -120,6 +120,10 @@ class VAEHIP:
         wcomp = torch.einsum("om,mchw->ochw", wq[:L], wc).permute(0, 2, 3, 1)
         w["encoder.mean_conv.weight"] = wcomp.reshape(L, -1).to(bf).contiguous()
         w["encoder.mean_conv.bias"] = (wq[:L] @ self._t(sd, "encoder.conv_out.bias") + self._t(sd, "quant_conv.bias")[:L]).contiguous()
+        # both halves (mean | logvar) for `latent_dist.sample()`: the training front (train_svd.py:86-95)
+        wfull = torch.einsum("om,mchw->ochw", wq, wc).permute(0, 2, 3, 1)
+        w["encoder.moments_conv.weight"] = wfull.reshape(2 * L, -1).to(bf).contiguous()
+        w["encoder.moments_conv.bias"] = (wq @ self._t(sd, "encoder.conv_out.bias") + self._t(sd, "quant_conv.bias")).contiguous()
         # ---- decoder
         conv3("decoder.conv_in", cin_pad=CIN_PAD)
         for j in range(lpb):
@@ -256,11 +260,23 @@ class VAEHIP:
     def encode_mode(self, x: torch.Tensor) -> torch.Tensor:
         """x: fp32 (B, 3, H, W) in [-1, 1] -> latent_dist.mode() fp32 (B, L, H/8, W/8), NOT multiplied by
         scaling_factor (pipeline:239)."""
+        return self._encode(x, "encoder.mean_conv", self.latent_channels)
+
+    @torch.no_grad()
+    def encode_moments(self, x: torch.Tensor):
+        """x: fp32 (B, 3, H, W) in [-1, 1] -> (mean, logvar) of `vae.encode(x).latent_dist`, fp32 (B, L, H/8, W/8) each, logvar
+        clamped to [-30, 20] as DiagonalGaussianDistribution does (dp/models/autoencoders/vae.py): what `.sample()` needs
+        (train_svd.py:91)."""
+        L = self.latent_channels
+        m = self._encode(x, "encoder.moments_conv", 2 * L)
+        return m[:, :L].contiguous(), torch.clamp(m[:, L:], -30.0, 20.0).contiguous()
+
+    def _encode(self, x: torch.Tensor, head: str, L: int) -> torch.Tensor:
         hip, w, ch, lpb = self.hip, self.w, self.ch, self.lpb
         x = x.to(self.device, torch.float32).contiguous()
         B, Cx, H, W = x.shape
         if H % (8 * 8) or W % (8 * 8):
-            raise ValueError("VAEHIP.encode_mode needs H and W that are multiples of 64")
+            raise ValueError("VAEHIP.encode_* needs H and W that are multiples of 64")
         M = B * H * W
         h = hip.nchw_to_nhwc(x, B, Cx, H * W, 1.0, CIN_PAD, self._empty(M, CIN_PAD))
         h = self._conv3("encoder.conv_in", h, M, CIN_PAD, H, W)
@@ -278,9 +294,8 @@ class VAEHIP:
         h, C = self._res2d("encoder.mid_block.resnets.1", h, C, M, H, W)
         hn = hip.groupnorm(h, C, None, 0, M, H * W, w["encoder.conv_norm_out.weight"], w["encoder.conv_norm_out.bias"],
                            1e-6, True)
-        L = self.latent_channels
         y = self._empty(M, L, dtype=torch.float32)
-        self._conv3("encoder.mean_conv", hn, M, C, H, W, out=y, ldo=L, epilogue=EPI_OUT_F32)
+        self._conv3(head, hn, M, C, H, W, out=y, ldo=L, epilogue=EPI_OUT_F32)
         return y.reshape(B, H, W, L).permute(0, 3, 1, 2).contiguous()
 
     @torch.no_grad()
