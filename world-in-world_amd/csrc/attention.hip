@@ -21,6 +21,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef WIW_ATTN_ABLATE
+#define WIW_ATTN_ABLATE 0   // timing experiments only (results wrong): 1 no max / exp2 (P = bf16(S)), 2 no K/V DMA + no tile
+#endif                      // barrier (stale stage 0), 4 no P.V MFMAs, 8 no Q.K MFMAs
 
 // v_max_f32 / v_max3_f32 without the canonicalising self-max hipcc puts in front of fmaxf (IEEE NaN quieting): the softmax
 // loop is VALU-ISSUE bound (tools/ubench/mfma_valu_overlap.hip: next to a streaming MFMA partner a wave gets ONE VALU issue
@@ -144,8 +147,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
+#if WIW_ATTN_ABLATE & 2
+        const char* sK = smem;
+#else
         if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
         const char* sK = smem + (kt & 1) * KV_STAGE;
+#endif
         const char* sV = sK + 8192;
         // ---- S^T = K . Q^T  (4 key frags x 2 query frags x 2 d steps)
         f32x4 s[4][2];
@@ -163,9 +170,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_
             const bf16x8 k1 = *(const bf16x8*)(rowp + (((4 + fq) ^ (krow & 7)) << 4));
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
+#if WIW_ATTN_ABLATE & 8
+                s[kf][f] = f32x4{0.f, 1.f, 2.f, 3.f};
+                asm volatile("" : "+v"(s[kf][f]) : "v"(k0), "v"(k1));
+#else
                 f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
                 z = WIW_MFMA(k0, qf[f][0], z);
                 s[kf][f] = WIW_MFMA(k1, qf[f][1], z);
+#endif
             }
         }
         // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag.
@@ -181,6 +193,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_
                         if (kt * KB + (kf >> 1) * 32 + fq * 8 + (kf & 1) * 4 + r >= S) s[kf][f][r] = -INFINITY;
         }
         uint32_t pb[2][4][2];   // [query frag][key frag][2 dwords] = packed bf16x4 B operands of the K = 16 MFMAs
+#if WIW_ATTN_ABLATE & 1
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                pb[f][kf][0] = pack2bf(s[kf][f][0], s[kf][f][1]);
+                pb[f][kf][1] = pack2bf(s[kf][f][2], s[kf][f][3]);
+            }
+#else
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             float ma = max3_raw(s[0][f][0], s[0][f][1], s[0][f][2]);   // two interleaved chains (dependent VALU: 8.5 cycles each)
@@ -217,6 +238,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_
                 pb[f][kf][1] = pack2bf(__builtin_amdgcn_exp2f(t23.x), __builtin_amdgcn_exp2f(t23.y));
             }
         }
+#endif
         // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps); both operands in the natural K enumeration
         // thanks to the key permutation of the S^T fragments above
 #pragma unroll
@@ -233,13 +255,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_
                     union { uint32_t u[4]; bf16x8 v; } pv;
                     pv.u[0] = pb[f][2 * ks][0]; pv.u[1] = pb[f][2 * ks][1];
                     pv.u[2] = pb[f][2 * ks + 1][0]; pv.u[3] = pb[f][2 * ks + 1][1];
+#if WIW_ATTN_ABLATE & 4
+                    asm volatile("" : "+v"(o[d][f]) : "v"(va.v), "v"(pv.v));
+#else
                     o[d][f] = WIW_MFMA(va.v, pv.v, o[d][f]);
                     if (d == 0) l_acc[f] = WIW_MFMA(ones, pv.v, l_acc[f]);
+#endif
                 }
             }
         }
+#if !(WIW_ATTN_ABLATE & 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     }
     // ---- normalise and store: lane holds O[query fr][d = dfrag*16 + 4*fq + r]
 #pragma unroll
