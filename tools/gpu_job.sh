@@ -2,7 +2,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-for v in default aabl1 aabl2 aabl3 aabl12 aabl13 aabl15; do
-  if [ $v = default ]; then unset WIW_LIB; else export WIW_LIB=tools/ablate/libwiw_$v.so; fi
-  echo "-- $v"; timeout 300 python tools/attn_probe.py 2>&1 | grep -v amdgpu.ids | grep -i spatial | head -2 | tee -a $O/attn_ablate.log
-done
+timeout 600 python -m pytest tests/test_hip_gemm16.py -x -q -s 2>&1 | grep -v "^$" | tail -12 | tee $O/tests.log
+timeout 600 python tools/gemm16_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/gemm16_probe.log
