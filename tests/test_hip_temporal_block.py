@@ -145,3 +145,21 @@ def test_temporal_attn_block_matches_unfused_chain_north_star_shape():
     print(f"[parity] temporal_attn_block 18432x14x320: vs fp32 max_rel={mx:.3e} rms_rel={rms:.3e}; vs unfused HIP chain rms={rms_chain:.3e}")
     assert torch.isfinite(o.float()).all()
     assert mx <= 2e-2 and rms <= 8e-3 and rms_chain <= 1.2e-2
+
+
+@pytest.mark.gpu
+def test_ring_form_at_every_width_in_a_subprocess():
+    """C <= 320 takes the weight-resident kernel by default; the ring kernel serves the same shapes under WIW_TEMPORAL_RING=1
+    (the A/B knob).  The library reads the knob once per process, so the parity cases above are re-run in a child process
+    with it set: both forms stay pinned to the same reference."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("WIW_TEMPORAL_RING"):
+        pytest.skip("already the child process")
+    env = dict(os.environ, WIW_TEMPORAL_RING="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "test_temporal_attn_block", "-x"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
