@@ -2,4 +2,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 300 python tools/norm_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/norm_probe.log
+timeout 1200 python -m pytest tests/test_hip_temporal_block.py -q -m gpu 2>&1 | tail -4 | tee $O/tests.log
