@@ -193,3 +193,60 @@ def test_weight_gradient_plan_functions_return_launchable_plans():
     # a 320-wide dy against a wide x: operands swapped (3 x 128 columns instead of 2 x 256 rows); square / tall: not
     assert wgrad_default_plan(320, 1280, M0, False)[0] == 3 and wgrad_default_plan(320, 320, M0, False)[0] == 2
     assert wgrad_default_plan(2560, 320, M0, False)[0] == 2
+
+
+def test_batch_from_pixels_composition_on_a_cpu_front():
+    """`train.batch_from_pixels` (train_svd.py:846-931) with a CPU stand-in for the HIP front end (the oracle's VAE encoder, a
+    fixed embedding): the host logic — which draws are made, how the latents, the conditioning sample, the rotated noise, the
+    EDM input scaling, the time ids and the action ids are put together — against the formulas of the reference's loop.  The HIP
+    front end itself is pinned on the GPU (tests/test_hip_vae.py)."""
+    import vae_oracle as VO
+    import wiw_amd  # noqa: F401
+    from wiw_amd import frontend as FE
+    from wiw_amd import train as T
+    from wiw_amd.pipeline import action_ids_idx_encode, rotate_latent_noise
+
+    cfg = dict(block_out_channels=(32, 32, 64, 64), layers_per_block=1)
+    sd = {k: torch.from_numpy(v) for k, v in FE.vae_random_state_dict(3, **cfg).items()}
+
+    class Vae:
+        device, scaling_factor = torch.device("cpu"), 0.18215
+
+        def encode_moments(self, x):
+            return VO.vae_encode_moments(sd, x, len(cfg["block_out_channels"]), cfg["layers_per_block"])
+
+    class Front:
+        vae = Vae()
+
+        def _embed(self, x, clip_images):
+            assert x.shape == (1, 3, 64, 128) and clip_images is None
+            return torch.full((1, 1, 1024), 0.25)
+
+    g = torch.Generator().manual_seed(0)
+    Tn, H, W = 4, 64, 128
+    px = torch.tanh(torch.randn(1, Tn, 3, H, W, generator=g))
+    past = torch.tanh(torch.randn(1, 1, 3, H, W, generator=g))
+    acts = np.array([[1, 3, 1, 2]])
+    h, w = H // 8, W // 8
+    d = dict(vae_eps=torch.randn(Tn, 4, h, w, generator=g), cond_eps=torch.randn(1, 4, h, w, generator=g),
+             pixel_noise=torch.randn(1, 3, H, W, generator=g), latent_noise=torch.randn(1, Tn, 4, h, w, generator=g), sigma=0.8,
+             cond_sigma=0.05, random_p=torch.tensor([0.15]))
+    st = T.batch_from_pixels(Front(), px, past, acts, dropout_prob=0.1, draws=d)
+    m, lv = Front.vae.encode_moments(px[0])
+    lat = ((m + torch.exp(0.5 * lv) * d["vae_eps"]) * 0.18215)[None]
+    cm, cl = Front.vae.encode_moments(px[0, 0:1] + d["pixel_noise"] * 0.05)
+    cond = cm + torch.exp(0.5 * cl) * d["cond_eps"]
+    noise = rotate_latent_noise(d["latent_noise"], acts)
+    assert torch.allclose(st.target, lat, atol=1e-6) and torch.allclose(st.noisy, lat + 0.8 * noise, atol=1e-6)
+    # random_p = 0.15 with prob 0.1: in [prob, 3 prob) -> conditioning latents dropped, and < 2 prob -> image embedding zeroed
+    want = torch.cat([(lat + 0.8 * noise) / (0.8 ** 2 + 1) ** 0.5, torch.zeros(1, Tn, 4, h, w)], dim=2)
+    assert torch.allclose(st.unet_input, want, atol=1e-6) and float(st.ehs.abs().max()) == 0.0
+    assert st.timestep == pytest.approx(0.25 * np.log(0.8)) and st.added_time_ids.tolist() == [[7.0, 127.0, pytest.approx(0.05)]]
+    assert torch.equal(st.action_ids, torch.from_numpy(action_ids_idx_encode(acts)))
+    keep = T.batch_from_pixels(Front(), px, past, acts, dropout_prob=0.1, draws=dict(d, random_p=torch.tensor([0.9])))
+    assert torch.allclose(keep.unet_input[:, :, 4:], cond.unsqueeze(1).repeat(1, Tn, 1, 1, 1), atol=1e-6)
+    assert float(keep.ehs[0, 0, 0]) == 0.25
+    # every draw comes from the generator when none is injected: same seed, same batch
+    a = T.batch_from_pixels(Front(), px, past, acts, dropout_prob=0.1, generator=torch.Generator().manual_seed(4))
+    b = T.batch_from_pixels(Front(), px, past, acts, dropout_prob=0.1, generator=torch.Generator().manual_seed(4))
+    assert torch.equal(a.unet_input, b.unet_input) and a.sigma == b.sigma and torch.equal(a.ehs, b.ehs)
