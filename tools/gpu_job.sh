@@ -1,5 +1,5 @@
 #!/bin/bash
+# per-call GPU job of the current experiment (edited per call; see git log for earlier forms)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
-O=gpurun_out/$TAG; mkdir -p $O
-timeout 200 tools/ablate/lds_fill 2>&1 | tee $O/lds_fill.txt
+bash tools/profile_run.sh $TAG 2>&1 | tail -14
