@@ -92,7 +92,9 @@ class GraphedForward:
             unet.forward(self.x_in, self.emb, cond, h, w)
         torch.cuda.current_stream(unet.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: with a process group alive, RCCL's watchdog thread polls events from ANOTHER thread; in the
+        # default (global) mode such a call during the capture would invalidate it.  This thread only launches kernels.
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.v = unet.forward(self.x_in, self.emb, cond, h, w)
 
     def load(self, cond) -> None:
