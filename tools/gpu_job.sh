@@ -3,5 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 1500 python -m pytest tests/test_hip_graph.py tests/test_hip_parallel.py tests/test_hip_server.py -q -m gpu -x > $O/tests_full.log 2>&1
-grep -n "passed\|failed\|rror" $O/tests_full.log | tail -6
+for r in 1 2; do
+echo "-- default (126 VGPRs, 4 waves/SIMD)"; timeout 300 python tools/attn_probe.py 2>&1 | grep -i spatial | head -2 | tee -a $O/attn_default.log
+echo "-- min 5 waves/SIMD (96 VGPRs, 27 spilled)"; WIW_LIB=tools/ablate/libwiw_aw5.so timeout 300 python tools/attn_probe.py 2>&1 | grep -i spatial | head -2 | tee -a $O/attn_w5.log
+done

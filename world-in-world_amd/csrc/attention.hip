@@ -21,6 +21,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
 
 constexpr float LOG2E = 1.4426950408889634f;
+#ifndef WIW_ATTN_MIN_WAVES
+#define WIW_ATTN_MIN_WAVES 2   // launch-bounds hint (waves per SIMD); the kernel needs 126 VGPRs = 4 waves per SIMD on its own
+#endif                         // (5: capped at 96 VGPRs, 27 spilled in the tile loop: 7.2 instead of 3.5 ms at S = 9216)
 #ifndef WIW_ATTN_ABLATE
 #define WIW_ATTN_ABLATE 0   // timing experiments only (results wrong): 1 no max / exp2 (P = bf16(S)), 2 no K/V DMA + no tile
 #endif                      // barrier (stale stage 0), 4 no P.V MFMAs, 8 no Q.K MFMAs
@@ -57,7 +60,7 @@ constexpr int KV_STAGE = 16384;   // K tile + V^T tile
 
 // NWV = 4 in production; NWV = 8 (WIW_ATTN_8WAVES=1, S >= 2048) is the measured-slower A/B form, see the launcher.
 template <int NWV>
-__global__ __launch_bounds__(NWV * 64, 2) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
+__global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
                                                                const uint16_t* __restrict__ Vt, int64_t ldvt,
                                                                uint16_t* __restrict__ O, int ldo, int S, int heads,
                                                                int q_tiles, float scale_log2e, const char* zeros) {
