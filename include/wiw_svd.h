@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 9   /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 10  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -39,7 +39,9 @@ extern "C" {
                              7: the training entry points settled: wiw_colsum sums CONTIGUOUS row ranges, wiw_attn_bwd_bf16
                                 takes NULL transposes on its LDS-tiled path, wiw_gather_taps_t_bf16, wiw_wgrad_tn_bf16;
                              8: wiw_ffn_geglu_bf16 (fused LayerNorm + GEGLU FeedForward of the C = 320 level);
-                             9: wiw_ema_step_f32 (EMAModel.step of --use_ema) */
+                             9: wiw_ema_step_f32 (EMAModel.step of --use_ema);
+                             10: wiw_attn_spatial_lse_bf16 / wiw_attn_bwd_given_lse_bf16 (the training forward hands its row
+                                 log-sum-exp to the backward) */
 
 int wiw_abi_version(void);
 
@@ -375,6 +377,15 @@ int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H);
 int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt, const void* dOt,
                       int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd, float* lse, float* dsum, int seqs,
                       int S, int Sp, int heads, int head_dim, float scale);
+/*   wiw_attn_spatial_lse_bf16 / wiw_attn_bwd_given_lse_bf16 (ABI 10): the forward of the fine-tuning step (attention_processor.py:
+ *                       2383-2385 under autograd) writes lse[(seq * heads + h) * S + q] = log2 sum_k 2^(s_qk scale log2 e) next to O
+ *                       (fp32 sums of the un-rounded probabilities), and the backward takes it instead of recomputing it with a
+ *                       Q.K^T pass (spatial sequences: S % 32 == 0, S >= 128; `lse` is read-only there). */
+int wiw_attn_spatial_lse_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O, int ldo,
+                              int frames, int S, int heads, float scale, const void* zeros, float* lse);
+int wiw_attn_bwd_given_lse_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* O, const void* dO, int ldo,
+                                void* dQKV, int ldd, const float* lse, float* dsum, int seqs, int S, int heads, int head_dim,
+                                float scale);
 /*   wiw_gather_taps_bf16  im2col rows for the weight gradient of the implicit-GEMM convolutions: Xcol[m][tap*C + c] = X[src(m, tap)][c]
  *                       (zeros outside the image / clip); 9 taps (3x3 pad 1 over (H, Wd); stride 2: output (H, Wd), input
  *                       (2H, 2Wd)) or, with temporal != 0, 3 taps over T.

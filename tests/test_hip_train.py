@@ -1,5 +1,6 @@
 """First kernels of row f2 (the fine-tuning step): AdamW and the EDM loss + gradient, against torch / the reference-pinned
 fixture `tests/golden/train_step_tiny.npz`.  The operators' backward kernels do not exist yet."""
+import math
 import os
 
 import numpy as np
@@ -339,6 +340,25 @@ def test_attention_backward(seqs, S, heads):
         print(f"[f2] attention backward {seqs}x{S}x{heads} {name}: max_rel={mx:.2e} rms={rms:.2e}")
         assert mx <= 2e-2 and rms <= 8e-3, name
     assert torch.equal(dqkv, hip.attn_backward(qkv_d, O, dO_d, seqs, S, heads, 0.125))
+    if S % 32 == 0 and S >= 128:
+        # the forward hands its row log-sum-exp over (wiw_attn_spatial_lse_bf16 -> wiw_attn_bwd_given_lse_bf16): same O bit for
+        # bit, log2-domain lse against torch.logsumexp of the same 16-bit q, k, and the gradients the recomputing form gives
+        lse = torch.empty(seqs * heads * S, dtype=torch.float32, device=DEV)
+        O2 = torch.empty_like(O)
+        hip.attn_spatial(qkv_d, 3 * C, C, vt, M, O2, C, seqs, S, heads, 0.125, lse=lse)
+        assert torch.equal(O, O2)
+        sc = torch.einsum("bhqd,bhkd->bhqk", hd(qkv[:, :C]), hd(qkv[:, C:2 * C])) * 0.125
+        ref = (torch.logsumexp(sc, dim=-1) / math.log(2.0)).reshape(-1)
+        err = float((lse.cpu() - ref).abs().max())
+        print(f"[f2] forward log-sum-exp {seqs}x{S}x{heads}: max abs err (log2 domain) = {err:.2e}")
+        assert err <= 2e-4
+        d2 = hip.attn_backward(qkv_d, O, dO_d, seqs, S, heads, 0.125, lse=lse)
+        dm, dr = _rel(d2, dqkv.float().cpu())
+        print(f"[f2] backward with the forward's lse vs recomputed: max_rel={dm:.2e} rms={dr:.2e}")
+        assert dm <= 8e-3 and dr <= 1e-3            # the same kernel arithmetic from an lse that differs by fp32 roundoff
+        for name, sl in (("dQ", slice(0, C)), ("dK", slice(C, 2 * C)), ("dV", slice(2 * C, 3 * C))):
+            mx, rms = _rel(d2[:, sl], leaf.grad[:, sl])
+            assert mx <= 2e-2 and rms <= 8e-3, name
 
 
 @pytest.mark.gpu

@@ -3,6 +3,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 2400 python -m pytest tests -q -m gpu -x > $O/${TAG}_gpu_suite_full.log 2>&1
-grep -n "passed\|failed\|rror" $O/${TAG}_gpu_suite_full.log | tail -6
-echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1800 python -m pytest tests/test_hip_train.py -q -m gpu -x -s > $O/train_tests_full.log 2>&1
+grep -n "\[f2\] forward log\|\[f2\] backward with\|passed\|failed\|rror" $O/train_tests_full.log | tail -14
+echo "== train bench"; timeout 600 python bench.py --train --steps 3 --warmup 1 2>/dev/null | tail -1 | cut -c1-240 | tee $O/bench_train.log

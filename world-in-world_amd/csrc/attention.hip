@@ -59,11 +59,15 @@ constexpr int KB = 64;   // queries per block: 32 per wave, NWV = 4 or 8 waves
 constexpr int KV_STAGE = 16384;   // K tile + V^T tile
 
 // NWV = 4 in production; NWV = 8 (WIW_ATTN_8WAVES=1, S >= 2048) is the measured-slower A/B form, see the launcher.
-template <int NWV>
+// WLSE (the fine-tuning forward): also writes the row log-sum-exp in the log2 domain, lse[(frame * heads + h) * S + q] =
+// log2 sum_k 2^(s_qk c), from fp32 sums of the UN-rounded probabilities — what wiw_attn_bwd_bf16 otherwise recomputes with a
+// whole Q.K^T pass (train.hip, pass 1 of the dQ kernel).  32 more VALU adds per tile; the inference instantiation has none.
+template <int NWV, bool WLSE>
 __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
                                                                const uint16_t* __restrict__ Vt, int64_t ldvt,
                                                                uint16_t* __restrict__ O, int ldo, int S, int heads,
-                                                               int q_tiles, float scale_log2e, const char* zeros) {
+                                                               int q_tiles, float scale_log2e, const char* zeros,
+                                                               float* __restrict__ lse) {
     constexpr int QB = NWV * 32;
     constexpr int NI = 8 / NWV;        // 8-row DMA instructions per wave and operand tile (64 rows): 2 or 1
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_STAGE];
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
 #pragma unroll
         for (int f = 0; f < 2; ++f) o[d][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY};
+    float lsum[2] = {0.f, 0.f};   // WLSE: this lane's share of sum_k p (fp32, un-rounded)
     // Row sums ride on the matrix pipe: O^T gets a 65th "d" row whose V^T entries are all ones, i.e. one extra MFMA per
     // (key step, query frag) with a constant A operand.  Every register of l_acc[f] then holds sum_k P[k][query fr]
     // (of the bf16-rounded P the numerator uses), with no VALU adds in the loop and no cross-lane reduction at the end.
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
             if (__builtin_amdgcn_ballot_w64(m_new > m_run[f] + 8.0f) != 0) {   // wave-uniform branch
                 const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);   // first tile: exp2(-inf) = 0
                 m_run[f] = m_new;
+                if (WLSE) lsum[f] *= alpha;
                 l_acc[f][0] *= alpha; l_acc[f][1] *= alpha; l_acc[f][2] *= alpha; l_acc[f][3] *= alpha;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -237,8 +243,11 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
             for (int kf = 0; kf < 4; ++kf) {
                 const wiw_f32x2 t01 = __builtin_elementwise_fma(wiw_f32x2{s[kf][f][0], s[kf][f][1]}, c2, nm2);
                 const wiw_f32x2 t23 = __builtin_elementwise_fma(wiw_f32x2{s[kf][f][2], s[kf][f][3]}, c2, nm2);
-                pb[f][kf][0] = pack2bf(__builtin_amdgcn_exp2f(t01.x), __builtin_amdgcn_exp2f(t01.y));
-                pb[f][kf][1] = pack2bf(__builtin_amdgcn_exp2f(t23.x), __builtin_amdgcn_exp2f(t23.y));
+                const float p0 = __builtin_amdgcn_exp2f(t01.x), p1 = __builtin_amdgcn_exp2f(t01.y);
+                const float p2 = __builtin_amdgcn_exp2f(t23.x), p3 = __builtin_amdgcn_exp2f(t23.y);
+                if (WLSE) lsum[f] += (p0 + p1) + (p2 + p3);
+                pb[f][kf][0] = pack2bf(p0, p1);
+                pb[f][kf][1] = pack2bf(p2, p3);
             }
         }
 #endif
@@ -277,6 +286,10 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
     for (int f = 0; f < 2; ++f) {
         const float inv = 1.0f / l_acc[f][0];
         const int qi = qt * QB + wave * 32 + f * 16 + fr;
+        if (WLSE) {   // the four fq lanes of a query column hold disjoint keys
+            const float tot = xor32_sum(xor16_sum(lsum[f]));
+            if (qi < S && fq == 0) lse[((int64_t)n * heads + h) * S + qi] = m_run[f] + __builtin_amdgcn_logf(tot);
+        }
         if (qi < S) {
             uint16_t* dst = O + (row0 + qi) * ldo + h * 64 + fq * 4;
 #pragma unroll
@@ -379,9 +392,8 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
 
 }  // namespace
 
-extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
-                                     int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
-                                     const void* zeros) {
+static int attn_spatial_launch(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O, int ldo,
+                               int frames, int S, int heads, float scale, const void* zeros, float* lse) {
     WIW_REQUIRE(QK && Vt && O && zeros, "attn_spatial: null pointer");
     WIW_REQUIRE(frames > 0 && S > 0 && heads > 0, "attn_spatial: bad sizes");
     WIW_REQUIRE(S % 8 == 0, "attn_spatial: S (= h*w of the level) must be a multiple of 8");
@@ -389,20 +401,33 @@ extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int
     // 8 waves (256 queries) per staged KV tile halve the LDS-DMA instructions per flop but measured 9-10 % SLOWER at
     // S = 9216 / 2304 (3.80 vs 3.45 ms, profiles/r06q_attn_probe.txt: twice the waves behind every tile barrier); A/B knob
     static const bool want8 = getenv("WIW_ATTN_8WAVES") != nullptr;
-    const bool big = S >= 2048 && want8;
+    const bool big = S >= 2048 && want8 && lse == nullptr;
     const int qb = big ? 256 : 128;
     const int q_tiles = (S + qb - 1) / qb;
     const int64_t nb = (int64_t)q_tiles * heads * frames;
     WIW_REQUIRE(nb < (1ll << 31), "attn_spatial: grid too large");
-    if (big)
-        hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, (const uint16_t*)QK,
-                           ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
-                           (const char*)zeros);
-    else
-        hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)QK,
-                           ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,
-                           (const char*)zeros);
+#define WIW_ATTN_LAUNCH(NW, WL)                                                                                                    \
+    hipLaunchKernelGGL((attn_spatial_kernel<NW, WL>), dim3((unsigned)nb), dim3(NW * 64), 0, (hipStream_t)stream, (const uint16_t*)QK, \
+                       ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,            \
+                       (const char*)zeros, lse)
+    if (lse) WIW_ATTN_LAUNCH(4, true);
+    else if (big) WIW_ATTN_LAUNCH(8, false);
+    else WIW_ATTN_LAUNCH(4, false);
+#undef WIW_ATTN_LAUNCH
     return wiw_check_launch("wiw_attn_spatial_bf16");
+}
+
+extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
+                                     int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
+                                     const void* zeros) {
+    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, zeros, nullptr);
+}
+
+extern "C" int wiw_attn_spatial_lse_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
+                                         int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
+                                         const void* zeros, float* lse) {
+    WIW_REQUIRE(lse, "attn_spatial_lse: null lse pointer");
+    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, zeros, lse);
 }
 
 extern "C" int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, int ldo, int batch, int T,

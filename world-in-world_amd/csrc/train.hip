@@ -851,7 +851,7 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
                                                                  const uint16_t* __restrict__ O, const uint16_t* __restrict__ dO, int ldo,
                                                                  uint16_t* __restrict__ dQKV, int ldd, float* __restrict__ LSE,
                                                                  float* __restrict__ Dsum, int S, int heads, int q_blocks, float scale,
-                                                                 float scale_log2e) {
+                                                                 float scale_log2e, int lse_given) {
     static_assert(D == 64, "head_dim 64");
     __shared__ __attribute__((aligned(16))) uint16_t Ks[32 * ATB_ROW];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[32 * ATB_ROW];
@@ -889,10 +889,11 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
     const uint16_t* gk = QKV + (row0 + lr) * ld + k_off + h * D + lc;
     const uint16_t* gv = QKV + (row0 + lr) * ld + v_off + h * D + lc;
     const int nk = S / 32;
-    // ---- pass 1: row log-sum-exp (log2 domain) over all keys
+    // ---- pass 1: row log-sum-exp (log2 domain) over all keys — skipped (block-uniformly) when the forward attention has
+    // already written it (wiw_attn_spatial_lse_bf16): a whole Q.K^T pass less
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     uint4 r0 = *(const uint4*)gk, r1;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < (lse_given ? 0 : nk); ++kt) {
         __syncthreads();
         *(uint4*)(Ks + lr * ATB_ROW + lc) = r0;
         __syncthreads();
@@ -933,9 +934,10 @@ __global__ __launch_bounds__(256) WIW_DQ_OCC void attn_bwd_dq_tiled_kernel(const
     float lse2[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        lse2[qt] = m_run[qt] + __builtin_amdgcn_logf(l_run[qt]);
+        if (lse_given) lse2[qt] = LSE[(seq * heads + h) * S + (active ? q0 + qt * 16 + fr : 0)];
+        else lse2[qt] = m_run[qt] + __builtin_amdgcn_logf(l_run[qt]);
         if (active && fq == 0) {
-            LSE[(seq * heads + h) * S + q0 + qt * 16 + fr] = lse2[qt];
+            if (!lse_given) LSE[(seq * heads + h) * S + q0 + qt * 16 + fr] = lse2[qt];
             Dsum[(seq * heads + h) * S + q0 + qt * 16 + fr] = dsum[qt];
         }
     }
@@ -1229,10 +1231,11 @@ extern "C" int wiw_row_map_bf16(void* stream, const void* X, int mode, int64_t o
 namespace {
 }  // namespace
 
-extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
-                                 const void* dOt, int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd,
-                                 float* lse, float* dsum, int seqs, int S, int Sp, int heads, int head_dim, float scale) {
+static int attn_bwd_launch(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
+                           const void* dOt, int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd,
+                           float* lse, float* dsum, int seqs, int S, int Sp, int heads, int head_dim, float scale, int lse_given) {
     const bool tiled = S == Sp && S % 32 == 0 && S >= 128;   // the LDS-tiled kernels read Q, K, dO row-major only
+    WIW_REQUIRE(!lse_given || tiled, "attn_bwd: a given log-sum-exp is taken by the LDS-tiled kernels only (S == Sp, S % 32 == 0, S >= 128)");
     WIW_REQUIRE(QKV && O && dO && dQKV && lse && dsum && (tiled || (Qt && Kt && dOt)), "attn_bwd: null pointer");
     WIW_REQUIRE(seqs > 0 && S > 0 && heads > 0 && Sp >= S && Sp % 16 == 0, "attn_bwd: bad sizes (Sp % 16 == 0)");
     WIW_REQUIRE(head_dim == 64, "attn_bwd: head_dim 64 only");
@@ -1248,7 +1251,7 @@ extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_of
         const int64_t grid = (int64_t)seqs * heads * blocks128;
         hipLaunchKernelGGL((attn_bwd_dq_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
                            v_off, (const uint16_t*)O, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum, S, heads, blocks128,
-                           scale, scale * LOG2E_);
+                           scale, scale * LOG2E_, lse_given);
         hipLaunchKernelGGL((attn_bwd_dkv_tiled_kernel<64>), dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)QKV, ld, k_off,
                            v_off, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse, dsum, S, heads, blocks128, scale,
                            scale * LOG2E_);
@@ -1261,6 +1264,20 @@ extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_of
                        v_off, (const uint16_t*)Qt, (const uint16_t*)dOt, ldt, (const uint16_t*)dO, ldo, (uint16_t*)dQKV, ldd, lse,
                        dsum, S, Sp, heads, tiles, total, scale, scale * LOG2E_);
     return wiw_check_launch("wiw_attn_bwd_bf16");
+}
+
+extern "C" int wiw_attn_bwd_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* Qt, const void* Kt,
+                                 const void* dOt, int64_t ldt, const void* O, const void* dO, int ldo, void* dQKV, int ldd,
+                                 float* lse, float* dsum, int seqs, int S, int Sp, int heads, int head_dim, float scale) {
+    return attn_bwd_launch(stream, QKV, ld, k_off, v_off, Qt, Kt, dOt, ldt, O, dO, ldo, dQKV, ldd, lse, dsum, seqs, S, Sp, heads,
+                           head_dim, scale, 0);
+}
+
+extern "C" int wiw_attn_bwd_given_lse_bf16(void* stream, const void* QKV, int ld, int k_off, int v_off, const void* O, const void* dO,
+                                           int ldo, void* dQKV, int ldd, const float* lse, float* dsum, int seqs, int S, int heads,
+                                           int head_dim, float scale) {
+    return attn_bwd_launch(stream, QKV, ld, k_off, v_off, nullptr, nullptr, nullptr, 0, O, dO, ldo, dQKV, ldd, (float*)lse, dsum, seqs,
+                           S, S, heads, head_dim, scale, 1);
 }
 
 extern "C" int wiw_geglu_fwd(void* stream, const void* P, int64_t rows, int Ch, void* H) {

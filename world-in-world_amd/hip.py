@@ -90,6 +90,11 @@ EXPORTS = {
     "wiw_gemm_bf16": (C.c_int, [C.c_void_p, C.POINTER(WiwGemmArgs)]),
     "wiw_attn_spatial_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "wiw_attn_spatial_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "wiw_attn_bwd_given_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_float]),
     "wiw_attn_temporal_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_float]),
     "wiw_temporal_attn_block_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -185,7 +190,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 9:
+        if self.lib.wiw_abi_version() != 10:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -268,8 +273,14 @@ class Hip:
         self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode, (M, N, K, epilogue)))
         return out
 
-    def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale):
+    def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, lse=None):
+        """lse (training forward): fp32 [frames * heads * S], receives the row log-sum-exp (log2 domain) for `attn_backward`."""
         # algorithmic work: Q.K^T and P.V, 2*S*S*64 each per (frame, head); bytes: Q, K, V read + O written (bf16)
+        if lse is not None:
+            assert lse.dtype == torch.float32 and lse.numel() == frames * heads * S
+            self._ck(self.lib.wiw_attn_spatial_lse_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo, frames, S,
+                                                        heads, scale, self.zeros.data_ptr(), _p(lse)), "wiw_attn_spatial_lse_bf16")
+            return O
         self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
             self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
                                            frames, S, heads, scale, self.zeros.data_ptr()), "wiw_attn_spatial_bf16"))
@@ -476,13 +487,22 @@ class Hip:
         s = self.colsum(unit_cs, units, 2 * Cn, parts=1)
         return dX, s[Cn:], s[:Cn]
 
-    def attn_backward(self, qkv, O, dO, seqs, S, heads, scale, Sp=None):
+    def attn_backward(self, qkv, O, dO, seqs, S, heads, scale, Sp=None, lse=None):
         """Self-attention backward for the fused q|k|v layout: qkv [seqs*Sp, 3C], O / dO [seqs*Sp, C] (C = heads*64; sequences
-        of S rows at a row stride of Sp, Sp % 16 == 0, default Sp = S) -> d_qkv [seqs*Sp, 3C] (padding rows zero)."""
+        of S rows at a row stride of Sp, Sp % 16 == 0, default Sp = S) -> d_qkv [seqs*Sp, 3C] (padding rows zero).
+        lse: the forward's row log-sum-exp (`attn_spatial(..., lse=...)`), spatial sequences only — skips its recomputation."""
         Sp = S if Sp is None else Sp
         Cn, M = heads * 64, seqs * Sp
         assert Sp % 16 == 0 and qkv.shape == (M, 3 * Cn) and O.shape == (M, Cn) and dO.shape == (M, Cn)
         dt, dev = self.dtype, self.device
+        if lse is not None:
+            assert Sp == S and S % 32 == 0 and S >= 128 and lse.numel() == seqs * heads * S
+            dqkv = torch.empty(M, 3 * Cn, dtype=dt, device=dev)
+            dsum = torch.empty_like(lse)
+            self._ck(self.lib.wiw_attn_bwd_given_lse_bf16(self._stream(), _p(qkv), 3 * Cn, Cn, 2 * Cn, _p(O), _p(dO), Cn, _p(dqkv),
+                                                          3 * Cn, _p(lse), _p(dsum), seqs, S, heads, 64, scale),
+                     "wiw_attn_bwd_given_lse_bf16")
+            return dqkv
         Qt = Kt = dOt = None
         if not (Sp == S and S % 32 == 0 and S >= 128):      # the one-wave-per-tile form reads transposed copies; the LDS-tiled
             Qt, Kt, dOt = (torch.empty(Cn, M, dtype=dt, device=dev) for _ in range(3))   # kernels transpose in their LDS reads

@@ -368,12 +368,15 @@ class UNetTrain:
         vt = torch.empty(C, M, dtype=self.dt, device=self.device)
         hip.transpose(qkv, 3 * C, 2 * C, M, C, vt, M)
         o = torch.empty(M, C, dtype=self.dt, device=self.device)
-        hip.attn_spatial(qkv, 3 * C, C, vt, M, o, C, seqs, S, heads, 0.125)
+        # the forward keeps its row log-sum-exp (4 bytes per row and head) for the backward where the LDS-tiled backward kernels
+        # serve the sequence (the spatial levels down to 8 x 16 latents): one Q.K^T pass less per layer in the step
+        lse = torch.empty(seqs * heads * S, dtype=torch.float32, device=self.device) if (S % 32 == 0 and S >= 128) else None
+        hip.attn_spatial(qkv, 3 * C, C, vt, M, o, C, seqs, S, heads, 0.125, lse=lse)
 
         def bwd():
             do = tape.take(o, self.dt)
             if do is not None:
-                tape.add(qkv, hip.attn_backward(qkv, o, do, seqs, S, heads, 0.125))
+                tape.add(qkv, hip.attn_backward(qkv, o, do, seqs, S, heads, 0.125, lse=lse))
         tape.ops.append(bwd)
         return o
 
