@@ -1,8 +1,10 @@
 #!/bin/bash
-# per-call GPU job of the current experiment (edited per call; see git log for earlier forms)
+# Per-call GPU job: `gpurun -- 'bash tools/gpu_job.sh TAG'`.  This file is edited for every experiment (its history is in
+# git); the committed form is the round-end check: full GPU suite, smoke, default bench line -> gpurun_out/TAG/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 1800 python -m pytest tests/test_hip_train.py -q -m gpu -x -s > $O/train_tests_full.log 2>&1
-grep -n "\[f2\] forward log\|\[f2\] backward with\|passed\|failed\|rror" $O/train_tests_full.log | tail -14
-echo "== train bench"; timeout 600 python bench.py --train --steps 3 --warmup 1 2>/dev/null | tail -1 | cut -c1-240 | tee $O/bench_train.log
+timeout 2400 python -m pytest tests -q -m gpu -x > $O/${TAG}_gpu_suite_full.log 2>&1
+grep -n "passed\|failed\|rror" $O/${TAG}_gpu_suite_full.log | tail -6
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo "== bench"; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json; cut -c1-260 $O/${TAG}_bench.json
