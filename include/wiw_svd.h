@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 10  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 11  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -41,7 +41,10 @@ extern "C" {
                              8: wiw_ffn_geglu_bf16 (fused LayerNorm + GEGLU FeedForward of the C = 320 level);
                              9: wiw_ema_step_f32 (EMAModel.step of --use_ema);
                              10: wiw_attn_spatial_lse_bf16 / wiw_attn_bwd_given_lse_bf16 (the training forward hands its row
-                                 log-sum-exp to the backward) */
+                                 log-sum-exp to the backward);
+                             11: the fp32 residual stream: WIW_EPI_RES1_F32 / WIW_EPI_RES2_F32, WIW_EPI_OUT_F32 on vectorised
+                                 stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
+                                 wiw_cast_f32_to_16 */
 
 int wiw_abi_version(void);
 
@@ -103,7 +106,16 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
        WIW_EPI_GELU = 8,        /* y = gelu_erf(y)           (CLIP ViT-H MLP, transformers `gelu`) */
        WIW_EPI_QUICK_GELU = 16, /* y = y * sigmoid(1.702 y)  (OpenAI CLIP `quick_gelu`) */
        WIW_W_TILED = 32,        /* W is pre-tiled for the LDS-DMA stream (above) */
-       WIW_EPI_LNFOLD = 64      /* A is the un-normalised LayerNorm input, W = W * gamma, lnfold = [s | t] (above) */ };
+       WIW_EPI_LNFOLD = 64,     /* A is the un-normalised LayerNorm input, W = W * gamma, lnfold = [s | t] (above) */
+       /* The fp32 RESIDUAL STREAM (ABI 11).  The reference keeps its latents and Euler update in fp32
+        * (scheduling_euler_discrete.py:635,673) and evaluates the UNet in fp16 (eval_inference.py:294); a 16-bit
+        * library that also ROUNDS the residual stream x + f(x) after every block is 1.2e-3 (fp16) from the reference's
+        * fp32 output on the served architecture, with the stream kept in fp32 it is below north_star's 1e-3
+        * (oracle/precision_study.py).  res1 / res2 are then fp32 [M][ldr] and, with WIW_EPI_OUT_F32, so is
+        * `out`; MFMA operands stay 16-bit.  Launches with any of these three bits run the 256x160 / 128x160 tiles with
+        * a fragment-layout epilogue: fp32 accumulator + bias + vector + residuals, ONE rounding (none for fp32 out),
+        * 16-byte accesses (N, ldo, ldr1, ldr2 % 4 == 0; no GEGLU / SiLU / GELU). */
+       WIW_EPI_RES1_F32 = 128, WIW_EPI_RES2_F32 = 256 };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -112,8 +124,8 @@ typedef struct WiwGemmArgs {
     void* out;           /* bf16 (or fp32 with WIW_EPI_OUT_F32) [M][ldo] */
     const float* bias;   /* [N] or NULL */
     const float* rowvec; /* [M / rows_per_vec][rowvec_ld] or NULL */
-    const void* res1;    /* bf16 [M][ldr1] or NULL */
-    const void* res2;    /* bf16 [M][ldr2] or NULL */
+    const void* res1;    /* bf16 [M][ldr1] (fp32 with WIW_EPI_RES1_F32) or NULL */
+    const void* res2;    /* bf16 [M][ldr2] (fp32 with WIW_EPI_RES2_F32) or NULL */
     const void* zeros;   /* >= 16 bytes of device zeros (source of padding taps) */
     const void* A3;      /* bf16 [rows_in][C3] or NULL (second half of the fused shortcut segment, CONV3X3 only) */
     int32_t M, N, K;
@@ -226,6 +238,15 @@ int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, in
 int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
                               int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
                               int silu, void* out);
+/* ABI 11, fp32 residual stream: the same two passes over fp32 inputs X1 / X2 (fp32 [rows][C1], [rows][C2]); the
+ * normalised output stays 16-bit.  `raw16` (NULL or 16-bit [rows][C1 + C2]) additionally receives the ROUNDED raw input
+ * (concatenated): the MFMA operand of ResnetBlock2D's 1x1 conv_shortcut (resnet.py:311-318), which reads the block input
+ * itself — one extra write in a pass that holds the value in registers anyway, instead of a cast pass. */
+int wiw_groupnorm_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
+                              int rows_per_unit, int rows_per_block, float* stats, float* scratch);
+int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
+                                    int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
+                                    int silu, void* out, void* raw16);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim with an optional fused pre-add of a per-row-group vector:
@@ -237,6 +258,12 @@ int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* 
  * ---------------------------------------------------------------------------------------------- */
 int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma, const float* beta,
                        float eps, const float* addvec, int addvec_ld, int rows_per_vec, void* sum_out, void* out);
+/* ABI 11, fp32 residual stream: X fp32 [rows][C], out 16-bit (no pre-add: the vectors ride in the producing GEMM). */
+int wiw_layernorm_f32in(void* stream, const float* X, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                        void* out);
+/* ABI 11: out[i] = round16(X[i]), n % 8 == 0 — the 16-bit MFMA operand of a stream tensor that enters a convolution
+ * directly (Downsample2D / Upsample2D inputs, downsampling.py:132-150, upsampling.py:142-186). */
+int wiw_cast_f32_to_16(void* stream, const float* X, int64_t n, void* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Conditioning embedding rows (unet:464-487, micro_cond, no-grad path) with the SiLU of

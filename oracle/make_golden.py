@@ -27,6 +27,8 @@ Fixtures written (all fp32 unless noted):
                            reference run in fp32 with bf16-ROUNDED WEIGHTS (the error floor of any bf16-weight evaluation)
   pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
+  pipeline_full_16x32.npz  the same __call__ for the FULL 25 steps with the served-width UNet at a 16x32 latent (T = 14):
+                           final latents + every 5th step, fp32 and fp32-on-16-bit-rounded-weights (`pipeline_full`, ~10 min)
 """
 import os
 import sys
@@ -402,6 +404,82 @@ def gen_pipeline(ns):
          latents_out_ref_bf16=np.stack(results_bf16))
 
 
+def gen_pipeline_full(ns):
+    """`StableVideoDiffusionPipeline.__call__` (pipeline_stable_video_diffusion.py:383-638) for the FULL 25 steps with the
+    SERVED-WIDTH UNet (320/640/1280/1280, T = 14, weights = seed 4 as in unet_full_16x32.npz) at a 16x32 latent, B = 1 with
+    CFG, output_type='latent' (a served-width reference TRAJECTORY, not only one forward).  Tiny random
+    VAE / CLIP supply the conditioning, which is captured at the UNet boundary.  Stored: the conditioning, the noise, the
+    latents after every 5th step and the final latents — for the reference in fp32, and for the reference in fp32 ARITHMETIC on
+    fp16- / bf16-ROUNDED WEIGHTS (the same-weights yardstick of a 16-bit build)."""
+    from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    pl = ns.pipeline_module
+    cfg = UNetConfig()
+    torch.manual_seed(0)
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=(32, 64, 64, 64), down_block_types=("DownEncoderBlock2D",) * 4,
+                                       layers_per_block=1, latent_channels=4, force_upcast=True, scaling_factor=0.18215).eval()
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=cfg.cross_attention_dim)).eval()
+    H, W, T, steps = 128, 256, cfg.num_frames, 25
+    rs = np.random.RandomState(31)
+    img = Image.fromarray(rs.randint(0, 256, size=(H, W, 3), dtype=np.uint8))
+    acts = np.array([[4, 1, 2, 1, 3, 1, 2, 1, 3, 1, 2, 1, 3, 1]], dtype=np.int64)   # SURVEY 8d: [4] + cycle([1, 2, 1, 3])
+    img_noise = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    lat_noise = rs.standard_normal((1, T, 4, H // 8, W // 8)).astype(np.float32)
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    out = {}
+    cond = {}
+    for tag, rnd in (("", None), ("_fp16_weights", torch.float16), ("_bf16_weights", torch.bfloat16)):
+        unet = ref_unet(ns, cfg, seed=4)
+        if rnd is not None:
+            for prm in unet.parameters():
+                prm.data = prm.data.to(rnd).to(torch.float32)
+        pipe = StableVideoDiffusionPipeline(vae=vae, image_encoder=clip, unet=unet, scheduler=make_scheduler(ns),
+                                            feature_extractor=CLIPImageProcessor())
+        pipe.set_progress_bar_config(disable=True)
+        queue = [img_noise, lat_noise]
+        orig = pl.randn_tensor
+        pl.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.from_numpy(queue.pop(0).copy()).to(dtype)
+        cap, traj = {}, {}
+        o_vae, o_img = pipe._encode_vae_image, pipe._encode_image
+
+        def enc_vae(*a, **k):
+            r = o_vae(*a, **k)
+            cap["il"] = r.detach().clone()
+            return r
+
+        def enc_img(*a, **k):
+            r = o_img(*a, **k)
+            cap["ie"] = r.detach().clone()
+            return r
+
+        def on_step(pipe_, i, t, kw):
+            if (i + 1) % 5 == 0:
+                traj[i + 1] = kw["latents"].detach().clone()
+            print(f"  pipeline_full{tag}: step {i + 1}/{steps}", flush=True)
+            return kw
+
+        pipe._encode_vae_image, pipe._encode_image = enc_vae, enc_img
+        try:
+            with torch.no_grad():
+                lat = pipe([img], height=H, width=W, num_frames=T, fps=7, motion_bucket_id=127, noise_aug_strength=0.02,
+                           num_inference_steps=steps, added_action_ids=aid, output_type="latent",
+                           callback_on_step_end=on_step, callback_on_step_end_tensor_inputs=["latents"]).frames
+        finally:
+            pl.randn_tensor = orig
+        assert not queue
+        assert float(cap["il"][0].abs().max()) == 0.0 and float(cap["ie"][0].abs().max()) == 0.0
+        if not cond:
+            cond = dict(image_latents=cap["il"][1:].numpy(), image_embeddings=cap["ie"][1:].numpy())
+        out["latents_out" + tag] = lat.numpy()
+        out["trajectory" + tag] = np.stack([traj[k][0].numpy() for k in sorted(traj)])
+    save("pipeline_full_16x32.npz", weight_seed=np.array(4), num_steps=np.array(steps), actions=acts, latent_noise=lat_noise,
+         trajectory_steps=np.array([5, 10, 15, 20, 25]), **cond, **out)
+
+
 def gen_frontend(ns):
     """VAE encode (mode) / temporal decode and the CLIP antialias resize of the reference, tiny random VAE."""
     from diffusers import AutoencoderKLTemporalDecoder
@@ -435,7 +513,8 @@ def main():
     ns = import_reference()
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
-                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema)
+                pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
+                pipeline_full=gen_pipeline_full)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

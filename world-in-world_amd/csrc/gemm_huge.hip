@@ -72,10 +72,19 @@ template <int MODE, bool GE, bool SK>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;       // wave (wm, wn) owns rows wm*64.., columns wn*160.. of the block tile
-    const int frow = lane & 15, fq = lane >> 4;
+    // Everything per-lane is re-derived from an OPAQUE copy of the lane id at the top of every tile and of every epilogue.
+    // Without this hipcc hoists ~50 loop-invariant per-lane address registers out of the tile loop and, at the 256-VGPR
+    // limit (160 accumulators), spills them around the K loop: 208-284 bytes of scratch per lane in round 3, whose
+    // write-back was the 1.6-1.7x WRITE_SIZE excess of every instantiation of this kernel.
+    int frow, fq, rsub, chunk;
+    auto rederive = [&]() {
+        asm volatile("" : "+v"(lane));
+        frow = lane & 15; fq = lane >> 4; rsub = lane >> 3; chunk = (lane & 7) ^ (rsub & 7);
+    };
+    rederive();
 
     // ---- tile schedule: per-XCD sm x sn super-tiles (identical to gemm.hip, with this tile shape)
     const int Nt = (p.N + HN - 1) / HN;
@@ -125,8 +134,6 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 
     // ---- loader state
-    const int rsub = lane >> 3;
-    const int chunk = (lane & 7) ^ (rsub & 7);
     const char* const Ab = (const char*)p.A;
     const char* const A2b = (const char*)p.A2;
     const char* const A3b = (const char*)p.A3;
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         const int tile_n = t % Nt;
         const int m0 = (SK ? (t / Nt) % Mt1 : t / Nt) * HM;
         const int64_t out_slab = SK ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;
+        rederive();
         setup_loader(t);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         // ---- epilogue, part 1: bias + first pass operands, then the next tile's first K tile, then the 4 passes
         constexpr int ITEMS_P = 6, ITEMS_G = 3;
         constexpr int CHr = GE ? 10 : 20, RPSr = GE ? 6 : 3;
+        rederive();
         // 64 lanes = RPSr rows x CHr chunks + 4 surplus lanes; the surplus lanes (and the row slots past the 16th row of
         // a pass, below) DUPLICATE a valid lane's work — same address, same data — instead of storing to the dump page:
         // with streaming stores the dump writes were real HBM traffic (+17 % on the output stream, PMC WRITE_SIZE).
@@ -401,7 +410,40 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             }
         };
         c0 = float4{0.f, 0.f, 0.f, 0.f}; c1 = c0; rv0[0] = c0; rv0[1] = c0; rv1[0] = c0; rv1[1] = c0;
+        // q1 is written and read under `if (r1)`: without an unconditional definition in THIS iteration the compiler carries
+        // its 48 registers across the tile loop (and spills them around the K loop)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < ITEMS_P; ++k) q1[b][k] = uint4{0u, 0u, 0u, 0u};
+        if (GE) {
+#pragma unroll
+            for (int ni = 0; ni < 10; ++ni) bvf[ni] = float4{0.f, 0.f, 0.f, 0.f};   // same reason (read under `if (p.bias)`)
+        }
         const bool rv_fast = p.rowvec != nullptr && (p.rows_per_vec % 16) == 0;
+        // per-wave staging area: in the ring stage that held the LAST K tile (every wave has finished reading it: the
+        // lagging group passed its last read before the leading group's closing barrier); the next tile's first K tile
+        // goes to the other stage
+        char* const stg = smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE;
+        // plain path, step (a) of a 16-row pass: fragment layout -> 16-bit rows in LDS (lane owns row frow, columns
+        // 16*ni + 4*fq .. +3).  Pass 0 is staged BEFORE the epilogue's global loads are issued: its 40 accumulator
+        // registers are free by the time the 40 registers of bias / per-frame vector / residual rows arrive (with the loads
+        // first the kernel peaked at 160 + 40 + addresses and spilled)
+        auto stage_pass = [&](auto mi_tag) {
+            constexpr int mi = decltype(mi_tag)::value;
+            char* wrow = stg + frow * HSTG_ROWB + fq * 8;
+#pragma unroll
+            for (int ni = 0; ni < 10; ++ni) {
+                f32x4 v = acc[mi][ni];
+                if (scale_acc) { v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha; }
+                uint2 pk;
+                pk.x = pack2bf(v[0], v[1]);
+                pk.y = pack2bf(v[2], v[3]);
+                *(uint2*)(wrow + ni * 32) = pk;
+            }
+            wave_lds_sync();
+        };
+        if (!GE && !SK) stage_pass(IC<0>{});
         if (GE) {
             if (p.bias) {
 #pragma unroll
@@ -447,41 +489,16 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 }
             }
         } else {
-            char* stg = smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE;
             uint4* dump = g_dump_h + (blockIdx.x & 511) * 64 + lane;
+            // plain path, step (b) of a 16-row pass: row-major, 8 consecutive columns per lane, bias / vector / residual math
+            // in fp32, 16-byte streaming stores (unconditional: invalid lanes hit the dump page)
             auto pass = [&](auto mi_tag) {
                 constexpr int mi = decltype(mi_tag)::value;
                 constexpr int pb = mi & 1;
                 constexpr int RPS = GE ? 6 : 3;
                 constexpr int ITEMS = GE ? ITEMS_G : ITEMS_P;
                 const int mrow0 = mw0 + mi * 16;
-                char* wrow = stg + frow * HSTG_ROWB + fq * 8;
-                if (GE) {
-#pragma unroll
-                    for (int ni = 0; ni < 5; ++ni) {
-                        f32x4 v = acc[mi][ni], g = acc[mi][ni + 5];
-                        if (p.bias) {
-                            v[0] += bvf[ni].x; v[1] += bvf[ni].y; v[2] += bvf[ni].z; v[3] += bvf[ni].w;
-                            g[0] += bvf[ni + 5].x; g[1] += bvf[ni + 5].y; g[2] += bvf[ni + 5].z; g[3] += bvf[ni + 5].w;
-                        }
-                        uint2 pk;
-                        pk.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
-                        pk.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
-                        *(uint2*)(wrow + ni * 32) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int ni = 0; ni < 10; ++ni) {
-                        f32x4 v = acc[mi][ni];
-                        if (scale_acc) { v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha; }
-                        uint2 pk;
-                        pk.x = pack2bf(v[0], v[1]);
-                        pk.y = pack2bf(v[2], v[3]);
-                        *(uint2*)(wrow + ni * 32) = pk;
-                    }
-                }
-                wave_lds_sync();
-                if (!GE && mi < 3) {   // operands of the next pass behind this pass's math
+                if (!GE && mi < 3) {   // operands of the next pass behind this pass's math (the other buffer)
                     if (rv_fast) load_rv(IC<(mi + 1) & 3>{});
                     if (r1) load_q1(IC<(mi + 1) & 3>{});
                 }
@@ -594,7 +611,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 pass32(IC<0>{}); pass32(IC<1>{});
                 pending_stores = 10;
             } else {
-                pass(IC<0>{}); pass(IC<1>{}); pass(IC<2>{}); pass(IC<3>{});
+                pass(IC<0>{});                                  // pass 0 was staged in part 1
+                stage_pass(IC<1>{}); pass(IC<1>{});
+                stage_pass(IC<2>{}); pass(IC<2>{});
+                stage_pass(IC<3>{}); pass(IC<3>{});
                 if (r2 == nullptr) pending_stores = 4 * ITEMS_P;
             }
         }

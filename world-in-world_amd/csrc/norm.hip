@@ -24,6 +24,30 @@ constexpr int GROUPS = 32;
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_MAXC = 4096;
 
+// 8 consecutive channels starting at element offset `off` of a 16-bit (F32IN = false: one 16-byte load, returned packed)
+// or fp32 (two 16-byte loads) tensor.  The fp32 form serves the fp32 residual stream (ABI 11).
+template <bool F32IN> struct Raw8 { uint4 a; };
+template <> struct Raw8<true> { float4 a, b; };
+template <bool F32IN>
+WIW_DEV Raw8<F32IN> load_raw8(const void* base, int64_t off) {
+    Raw8<F32IN> r;
+    if constexpr (F32IN) {
+        const float* p = (const float*)base + off;
+        r.a = *(const float4*)p; r.b = *(const float4*)(p + 4);
+    } else {
+        r.a = *(const uint4*)((const uint16_t*)base + off);
+    }
+    return r;
+}
+template <bool F32IN>
+WIW_DEV void raw8_to_f(const Raw8<F32IN>& r, float* f) {
+    if constexpr (F32IN) {
+        f[0] = r.a.x; f[1] = r.a.y; f[2] = r.a.z; f[3] = r.a.w; f[4] = r.b.x; f[5] = r.b.y; f[6] = r.b.z; f[7] = r.b.w;
+    } else {
+        unpack8(r.a, f);
+    }
+}
+
 // (na, ma, Ma) <- merge with (nb, mb, Mb);  counts are exact small integers held in fp32
 WIW_DEV void chan_merge(float& na, float& ma, float& Ma, float nb, float mb, float Mb) {
     if (nb <= 0.f) return;
@@ -34,8 +58,9 @@ WIW_DEV void chan_merge(float& na, float& ma, float& Ma, float nb, float mb, flo
     na = n;
 }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restrict__ X1, int C1,
-                                                        const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
+template <bool F32IN>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ X1, int C1,
+                                                        const void* __restrict__ X2, int C2, int rows_per_unit,
                                                         int rows_per_block, float* __restrict__ partials) {
     __shared__ float red[256][17];          // per-thread (mean[8], M2[8]); 17: skewed banks
     __shared__ float chan[2][GN_MAXC];      // per-channel block (mean, M2)
@@ -61,34 +86,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s2[j] = wiw_f32x2{0.f, 0.f}; q2[j] = s2[j]; p2[j] = s2[j]; }
         int cnt = 0;
-        auto accum = [&](const uint4& raw) {
-            const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
+        auto pairs = [&](const Raw8<F32IN>& raw, wiw_f32x2* v) {
+            if constexpr (F32IN) {
+                v[0] = wiw_f32x2{raw.a.x, raw.a.y}; v[1] = wiw_f32x2{raw.a.z, raw.a.w};
+                v[2] = wiw_f32x2{raw.b.x, raw.b.y}; v[3] = wiw_f32x2{raw.b.z, raw.b.w};
+            } else {
+                v[0] = unpack2(raw.a.x); v[1] = unpack2(raw.a.y); v[2] = unpack2(raw.a.z); v[3] = unpack2(raw.a.w);
+            }
+        };
+        auto accum = [&](const Raw8<F32IN>& raw) {
+            wiw_f32x2 v[4];
+            pairs(raw, v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const wiw_f32x2 d = unpack2(u[j]) - p2[j];
+                const wiw_f32x2 d = v[j] - p2[j];
                 s2[j] += d;
                 q2[j] = __builtin_elementwise_fma(d, d, q2[j]);
             }
         };
         if (active) {
-            const uint16_t* src;
+            const void* src;
             int ld, coff;
             if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
             int r = r0 + rl;
-            {   // pivot = first row (re-read below: L1 hit)
-                const uint4 raw = *(const uint4*)(src + (base_row + r) * ld + coff);
-                p2[0] = unpack2(raw.x); p2[1] = unpack2(raw.y); p2[2] = unpack2(raw.z); p2[3] = unpack2(raw.w);
-            }
-            for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent 16-byte loads in flight per thread
-                uint4 raw[4];
+            pairs(load_raw8<F32IN>(src, (base_row + r) * ld + coff), p2);   // pivot = first row (re-read below: L1 hit)
+            for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent (pairs of) 16-byte loads in flight per thread
+                Raw8<F32IN> raw[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (base_row + r + u * rp) * ld + coff);
+                for (int u = 0; u < 4; ++u) raw[u] = load_raw8<F32IN>(src, (base_row + r + u * rp) * ld + coff);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) accum(raw[u]);
                 cnt += 4;
             }
             for (; r < r1; r += rp) {
-                accum(*(const uint4*)(src + (base_row + r) * ld + coff));
+                accum(load_raw8<F32IN>(src, (base_row + r) * ld + coff));
                 ++cnt;
             }
         }
@@ -217,12 +248,13 @@ __global__ void gn_finalize_kernel(const float* __restrict__ stats, const float*
 // apply: grid = (row_splits, units) like the statistics kernel; a thread keeps the scale/shift of its 8 channels in
 // registers and walks rows with 32-bit index arithmetic only (no per-element division).
 // FUSED: `ab` is the raw statistics buffer [units][32][2]; scale / shift are derived here (no finalize launch).
-template <bool FUSED>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ X1, int C1,
-                                                        const uint16_t* __restrict__ X2, int C2, int rows_per_unit,
+template <bool FUSED, bool F32IN = false>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ X1, int C1,
+                                                        const void* __restrict__ X2, int C2, int rows_per_unit,
                                                         int rows_per_block, const float* __restrict__ ab, int silu,
                                                         uint16_t* out, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float inv_count, float eps) {
+                                                        const float* __restrict__ beta, float inv_count, float eps,
+                                                        uint16_t* raw16) {
     const int tid = threadIdx.x;
     const int C = C1 + C2;
     const int chunks = C >> 3;
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
         const int chunk = cbase + ci;
         if (chunk >= chunks) break;
         const int c0 = chunk * 8;
-        const uint16_t* src;
+        const void* src;
         int ld, coff;
         if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
         float4 a0, a1, b0, b1;
@@ -264,13 +296,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
         }
         int r = r0 + rl;
         for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent loads in flight per thread
-            uint4 raw[4];
+            Raw8<F32IN> raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (base_row + r + u * rp) * ld + coff);
+            for (int u = 0; u < 4; ++u) raw[u] = load_raw8<F32IN>(src, (base_row + r + u * rp) * ld + coff);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float f[8];
-                unpack8(raw[u], f);
+                raw8_to_f<F32IN>(raw[u], f);
+                if (F32IN && raw16) *(uint4*)(raw16 + (base_row + r + u * rp) * C + c0) = pack8(f);
                 f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
                 f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
                 if (silu) {
@@ -282,7 +315,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
         }
         for (; r < r1; r += rp) {
             float f[8];
-            unpack8(*(const uint4*)(src + (base_row + r) * ld + coff), f);
+            raw8_to_f<F32IN>(load_raw8<F32IN>(src, (base_row + r) * ld + coff), f);
+            if (F32IN && raw16) *(uint4*)(raw16 + (base_row + r) * C + c0) = pack8(f);
             f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
             f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
             if (silu) {
@@ -303,8 +337,8 @@ constexpr int LN_RUN = 8;      // consecutive rows per wave
 
 // NCH = 16-byte chunk passes per row (C <= NCH * 512), R = rows whose loads are in flight together (8 at C <= 512):
 // at C = 320 one row is only 640 B; with 1 / 4 / 8 rows in flight per wave the kernel streams 2.7 / 3.0 / 4.3 TB/s.
-template <int NCH, int R>
-__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ X, int64_t rows, int C,
+template <int NCH, int R, bool F32IN = false>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ X, int64_t rows, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float eps, const float* __restrict__ addvec, int addvec_ld,
                                                          int rows_per_vec, uint16_t* sum_out, uint16_t* out) {
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
       const int64_t run1 = run0 + LN_RUN < rows ? run0 + LN_RUN : rows;
       for (int64_t rowg = run0; rowg < run1; rowg += R) {
         float v[R][NCH][8];
-        uint4 raw[R][NCH];
+        Raw8<F32IN> raw[R][NCH];
         // ---- all loads of the R rows first
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -337,7 +371,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 const int chunk = lane + k * 64;
-                if (chunk < chunks) raw[r][k] = *(const uint4*)(X + row * C + chunk * 8);
+                if (chunk < chunks) raw[r][k] = load_raw8<F32IN>(X, row * C + chunk * 8);
             }
         }
         float s[R];
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
             for (int k = 0; k < NCH; ++k) {
                 const int chunk = lane + k * 64;
                 if (chunk < chunks) {
-                    unpack8(raw[r][k], v[r][k]);
+                    raw8_to_f<F32IN>(raw[r][k], v[r][k]);
                     if (addvec) {
                         v[r][k][0] += a0[k].x; v[r][k][1] += a0[k].y; v[r][k][2] += a0[k].z; v[r][k][3] += a0[k].w;
                         v[r][k][4] += a1[k].x; v[r][k][5] += a1[k].y; v[r][k][6] += a1[k].z; v[r][k][7] += a1[k].w;
@@ -452,11 +486,29 @@ extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const v
     WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats: bad rows");
     int units, splits, rows_per_block;
     gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1, C1,
-                       (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, scratch);
+    hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, X1, C1, X2, C2,
+                       rows_per_unit, rows_per_block, scratch);
     hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits,
                        rows_per_unit, rows_per_block, C / GROUPS, stats);
     return wiw_check_launch("wiw_groupnorm_stats");
+}
+
+extern "C" int wiw_groupnorm_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
+                                         int rows_per_unit, int rows_per_block_in, float* stats, float* scratch) {
+    WIW_REQUIRE(X1 && stats && scratch, "groupnorm_stats_f32in: null pointer");
+    WIW_REQUIRE(rows_per_block_in >= 0, "groupnorm_stats_f32in: rows_per_block must be >= 0 (0 = default)");
+    WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_stats_f32in: X2 iff C2 > 0");
+    const int C = C1 + C2;
+    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0 && C <= GN_MAXC,
+                "groupnorm_stats_f32in: channels must be %8, C %32 and C <= 4096");
+    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats_f32in: bad rows");
+    int units, splits, rows_per_block;
+    gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
+    hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const void*)X1, C1,
+                       (const void*)X2, C2, rows_per_unit, rows_per_block, scratch);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits,
+                       rows_per_unit, rows_per_block, C / GROUPS, stats);
+    return wiw_check_launch("wiw_groupnorm_stats_f32in");
 }
 
 extern "C" int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta,
@@ -482,15 +534,15 @@ extern "C" int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const v
     if (splits < 1) splits = 1;
     const int rows_per_block = (rows_per_unit + splits - 1) / splits;
     splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1,
-                       C1, (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, ab, silu, (uint16_t*)out, nullptr, nullptr,
-                       0.f, 0.f);
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3(splits, units), dim3(256), 0, (hipStream_t)stream, X1, C1, X2, C2,
+                       rows_per_unit, rows_per_block, ab, silu, (uint16_t*)out, nullptr, nullptr, 0.f, 0.f, nullptr);
     return wiw_check_launch("wiw_groupnorm_apply");
 }
 
-extern "C" int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
-                                         int rows_per_unit, const float* stats, const float* gamma, const float* beta,
-                                         float eps, int silu, void* out) {
+namespace {
+template <bool F32IN>
+int gn_apply_stats_launch(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows, int rows_per_unit,
+                          const float* stats, const float* gamma, const float* beta, float eps, int silu, void* out, void* raw16) {
     WIW_REQUIRE(X1 && stats && gamma && beta && out, "groupnorm_apply_stats: null pointer");
     WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_apply_stats: X2 iff C2 > 0");
     const int C = C1 + C2;
@@ -504,10 +556,22 @@ extern "C" int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, c
     const int rows_per_block = (rows_per_unit + splits - 1) / splits;
     splits = (rows_per_unit + rows_per_block - 1) / rows_per_block;
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / GROUPS));
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X1,
-                       C1, (const uint16_t*)X2, C2, rows_per_unit, rows_per_block, stats, silu, (uint16_t*)out, gamma, beta,
-                       inv_count, eps);
+    hipLaunchKernelGGL((gn_apply_kernel<true, F32IN>), dim3(splits, units), dim3(256), 0, (hipStream_t)stream, X1, C1, X2, C2,
+                       rows_per_unit, rows_per_block, stats, silu, (uint16_t*)out, gamma, beta, inv_count, eps, (uint16_t*)raw16);
     return wiw_check_launch("wiw_groupnorm_apply_stats");
+}
+}  // namespace
+
+extern "C" int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                                         int rows_per_unit, const float* stats, const float* gamma, const float* beta,
+                                         float eps, int silu, void* out) {
+    return gn_apply_stats_launch<false>(stream, X1, C1, X2, C2, rows, rows_per_unit, stats, gamma, beta, eps, silu, out, nullptr);
+}
+
+extern "C" int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
+                                               int rows_per_unit, const float* stats, const float* gamma, const float* beta,
+                                               float eps, int silu, void* out, void* raw16) {
+    return gn_apply_stats_launch<true>(stream, X1, C1, X2, C2, rows, rows_per_unit, stats, gamma, beta, eps, silu, out, raw16);
 }
 
 extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma,
@@ -519,11 +583,27 @@ extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int
     WIW_REQUIRE(sum_out == nullptr || addvec != nullptr, "layernorm: sum_out requires addvec");
     const dim3 grid(grid_for(rows, 4 * LN_RUN, 256 * 8));   // <= 8 blocks per CU, grid-stride over runs of LN_RUN rows
 #define WIW_LN_LAUNCH(NCH, R)                                                                                        \
-    hipLaunchKernelGGL((layernorm_kernel<NCH, R>), grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X, rows, C, \
+    hipLaunchKernelGGL((layernorm_kernel<NCH, R, false>), grid, dim3(256), 0, (hipStream_t)stream, X, rows, C,        \
                        gamma, beta, eps, addvec, addvec_ld, rows_per_vec, (uint16_t*)sum_out, (uint16_t*)out)
     if (C <= 512) WIW_LN_LAUNCH(1, 8);
     else if (C <= 1024) WIW_LN_LAUNCH(2, 2);
     else WIW_LN_LAUNCH(4, 1);
 #undef WIW_LN_LAUNCH
     return wiw_check_launch("wiw_layernorm_bf16");
+}
+
+extern "C" int wiw_layernorm_f32in(void* stream, const float* X, int64_t rows, int C, const float* gamma, const float* beta,
+                                   float eps, void* out) {
+    WIW_REQUIRE(X && gamma && beta && out, "layernorm_f32in: null pointer");
+    WIW_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= LN_MAXCH * 64 * 8, "layernorm_f32in: C must be %8 and <= 2048");
+    const dim3 grid(grid_for(rows, 4 * LN_RUN, 256 * 8));
+    // fp32 rows are twice as long: half as many rows in flight per wave keep the register budget of the 16-bit kernels
+#define WIW_LN_LAUNCH(NCH, R)                                                                                             \
+    hipLaunchKernelGGL((layernorm_kernel<NCH, R, true>), grid, dim3(256), 0, (hipStream_t)stream, (const void*)X, rows, C, \
+                       gamma, beta, eps, (const float*)nullptr, 0, 1, (uint16_t*)nullptr, (uint16_t*)out)
+    if (C <= 512) WIW_LN_LAUNCH(1, 4);
+    else if (C <= 1024) WIW_LN_LAUNCH(2, 2);
+    else WIW_LN_LAUNCH(4, 1);
+#undef WIW_LN_LAUNCH
+    return wiw_check_launch("wiw_layernorm_f32in");
 }
