@@ -41,6 +41,20 @@ MODE_NAMES = {0: "gemm_kernel<dense>", 1: "gemm_kernel<conv3x3>", 2: "gemm_kerne
               3: "gemm_kernel<conv3x3_up>", 4: "gemm_kernel<conv_t3>"}
 
 
+# the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK>
+# = the 256x320 tile (gemm_huge.hip), gemm_kernel<MODE, WAVES, STAGES, GEGLU, LNFOLD, F32E> = the 256x160 / 128x160 tiles
+MODE_TEMPLATES = {
+    0: ["gemm_huge_kernel<0, false, false>", "gemm_huge_kernel<0, true, false>", "gemm_kernel<0, 8, 3, false, false, false>",
+        "gemm_kernel<0, 8, 3, true, false, false>", "gemm_kernel<0, 4, 2, false, false, false>",
+        "gemm_kernel<0, 4, 2, true, false, false>"],
+    1: ["gemm_huge_kernel<1, false, false>", "gemm_huge_kernel<1, false, true>", "gemm_kernel<1, 8, 3, false, false, false>",
+        "gemm_kernel<1, 4, 2, false, false, false>", "splitk_reduce_kernel"],
+    2: ["gemm_huge_kernel<2, false, false>", "gemm_kernel<2, 8, 3, false, false, false>", "gemm_kernel<2, 4, 2, false, false, false>"],
+    3: ["gemm_huge_kernel<3, false, false>", "gemm_kernel<3, 8, 3, false, false, false>", "gemm_kernel<3, 4, 2, false, false, false>"],
+    4: ["gemm_huge_kernel<4, false, false>", "gemm_kernel<4, 8, 3, false, false, false>", "gemm_kernel<4, 4, 2, false, false, false>"],
+}
+
+
 def synth_actions(B, T):
     base = [4] + [[1, 2, 1, 3][i % 4] for i in range(T - 1)]  # exercises both rolls
     return np.tile(np.array(base, dtype=np.int64), (B, 1))
@@ -117,6 +131,12 @@ def main():
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
                     help="16-bit storage / MFMA operand type: bf16 (BASELINE's, libwiwsvd.so) or fp16 (the reference's "
                          "served default, libwiwsvd_f16.so)")
+    ap.add_argument("--residual-fp32", action="store_true",
+                    help="UNetHIP(residual_fp32=True): the residual stream in fp32 (with --dtype fp16 the configuration within "
+                         "1e-3 of the reference's fp32 evaluation, DESIGN.md 5)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extra` legs the default single-GPU line appends after its timed region (B = 8 rollout = "
+                         "BASELINE config 2's per-GPU work, fp16 and fp16 + fp32-residual rollouts, a 2-step --train leg)")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -141,6 +161,7 @@ def main():
                          "decode, PIL post-processing) through server.worker.SVDWorker; reported as 'end_to_end'")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,7 +183,13 @@ def main():
 
     import wiw_amd  # noqa: F401
     if args.train:
-        return train_bench(args, rank, world, device, dist_on)
+        line = train_bench(args, rank, world, device, dist_on)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from wiw_amd.config import UNetConfig
     from wiw_amd.parallel import sharded_denoise
     from wiw_amd.pipeline import SVDDenoiser
@@ -173,7 +200,10 @@ def main():
     T = cfg.num_frames
     h, w = args.height // 8, args.width // 8
     sd = random_state_dict_torch(cfg, 0, device, torch.float32)
-    unet = UNetHIP(cfg, sd, device, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16)
+    unet = UNetHIP(cfg, sd, device, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16,
+                   residual_fp32=True if args.residual_fp32 else None)
+    # what THIS box gives a pure-MFMA loop and a device copy (outside the timed region): the pool's boxes differ by +-5 %
+    box = unet.hip.calibrate_box() if rank == 0 else None
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
@@ -255,6 +285,7 @@ def main():
             "metric": "denoised frames/sec (576x1024x14, 25 steps)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            **({"residual_stream": "fp32"} if unet.res32 else {}),
             "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
                                    f"CFG on, " + (f"{Btot} candidates in total" if strong else f"{B} candidate(s)/GPU") + ", random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}",
@@ -262,6 +293,9 @@ def main():
         }
         # host time spent enqueueing one UNet forward (~1 100 launches through ctypes, or one hipGraphLaunch): measured around the
         # calls of the timed region, no synchronisation inside; the event-carrying steps are the eager sample
+        res["box"] = {"mfma_peak_measured": box["mfma_tflops"], "mfma_peak_unit": "TFLOP/s", "hbm_copy_GBps": box["copy_GBps"],
+                      "cus": box["cus"], "what": "a ~50 ms launch of back-to-back MFMAs on register operands (8 waves per CU) and a "
+                      "1 GiB device copy (read + write bytes), measured on this box before the timed region"}
         hl = den.host_launch
         res["host_launch"] = {
             "hip_graph": (not args.no_graph) and den.graph_error is None,
@@ -303,8 +337,10 @@ def main():
             traffic, traffic_src = pmc_traffic(dom)
             tsec, fl, cnt = by_mode[dom]
             ach = fl / tsec / 1e12
-            res["roofline"] = {"kernel": MODE_NAMES[dom], "bound": "mfma", "achieved": round(ach, 1),
+            res["roofline"] = {"kernel": MODE_NAMES[dom], "templates": MODE_TEMPLATES.get(dom, []), "bound": "mfma",
+                               "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                               "frac_of_box_peak": round(ach / box["mfma_tflops"], 4),
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
                                "share_of_timed_region": round(tsec / (dt * ev_frac), 3)}
@@ -352,6 +388,9 @@ def main():
                         f.write(f"family={k} " + " ".join(f"{a}={b}" for a, b in v.items()) + "\n")
         if args.end_to_end and world == 1 and not args.tiny:
             res["end_to_end"] = end_to_end(den, unet, device, B, args)
+        if (world == 1 and not dist_on and not args.no_extras and not args.tiny and B == 1 and not strong and
+                (args.height, args.width, args.num_inference_steps) == (576, 1024, 25) and not args.residual_fp32):
+            res["extra"] = extras(args, cfg, unet, device, req, time.perf_counter() - t_start)
         if sd_cpu is not None:
             try:
                 res["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, min(os.cpu_count() or 1, 32), device, unet.dtype)
@@ -412,9 +451,10 @@ def train_bench(args, rank, world, device, dist_on=False):
     if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    line = None
     if rank == 0:
         assert np.isfinite(loss)
-        print(json.dumps({
+        line = ({
             "metric": "fine-tuning samples/sec (train_svd.py step: fwd + bwd + AdamW)", "value": round(world * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -425,11 +465,76 @@ def train_bench(args, rank, world, device, dist_on=False):
                                    "measured during warm-up") + "), LDS-tiled attention backward" +
                                    (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "parallelism": f"data-parallel x{world}, ZeRO-1 (reduce-scatter + all-gather)" if dist_on else "single GPU"},
-            "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)}),
-            flush=True)
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+            "final_loss": round(float(loss), 5), "peak_memory_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1)})
+    del tr, net, opt
+    torch.cuda.empty_cache()
+    return line
+
+
+def extras(args, cfg, unet, device, req, elapsed):
+    """Legs appended to the default single-GPU line AFTER its timed region: numbers the driver's clock
+    otherwise never sees.  Each leg is guarded; none touches `value`.
+      batch8      one 25-step rollout of 8 candidates on this GPU = the per-GPU work of BASELINE configs 2 / 3
+      fp16        one rollout with the fp16 library (the reference's served dtype, eval_inference.py:294)
+      fp16_res32  the same with the residual stream in fp32: the configuration gated at <= 1e-3 vs the reference's fp32 output
+      train       2 fine-tuning steps at 576x1024x14 (BASELINE config 4's per-GPU work)"""
+    import copy
+
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict_torch
+
+    out = {}
+    T, h, w = cfg.num_frames, args.height // 8, args.width // 8
+    budget = 240.0     # seconds of bench wall clock after which no further leg starts
+
+    def timed_rollout(den, r, n):
+        den.denoise(r["image_latents"], r["image_embeddings"], r["noise"], r["actions"], num_steps=2)    # warm (capture) pass
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        lat = den.denoise(r["image_latents"], r["image_embeddings"], r["noise"], r["actions"], num_steps=args.num_inference_steps)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(lat).all()
+        return {"frames_per_s": round(n * T / dt, 4), "seconds_per_rollout": round(dt, 3), "candidates": n}
+
+    t0 = time.perf_counter()
+
+    def left():
+        return budget - elapsed - (time.perf_counter() - t0)
+
+    try:
+        if left() > 60:
+            g = torch.Generator(device="cpu").manual_seed(4321)
+            r8 = dict(image_latents=torch.randn(8, 4, h, w, generator=g).to(device),
+                      image_embeddings=torch.randn(8, 1, cfg.cross_attention_dim, generator=g).to(device),
+                      noise=torch.randn(8, T, 4, h, w, generator=g).to(device), actions=synth_actions(8, T))
+            out["batch8"] = timed_rollout(SVDDenoiser(unet, use_graph=False), r8, 8)
+            del r8
+            torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        out["batch8"] = {"error": f"{type(e).__name__}: {e}"}
+    if args.dtype == "bf16":
+        for name, r32 in (("fp16", False), ("fp16_res32", True)):
+            try:
+                if left() > 30:
+                    u = UNetHIP(cfg, random_state_dict_torch(cfg, 0, device, torch.float32), device, dtype=torch.float16,
+                                residual_fp32=r32)
+                    out[name] = timed_rollout(SVDDenoiser(u, use_graph=True), req, 1)
+                    del u
+                    torch.cuda.empty_cache()
+            except Exception as e:   # noqa: BLE001
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        if left() > 45:
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.no_autotune = 2, 1, True
+            tl = train_bench(a2, 0, 1, device, False)
+            out["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "peak_memory_GiB")}
+    except Exception as e:   # noqa: BLE001
+        out["train"] = {"error": f"{type(e).__name__}: {e}"}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
 
 
 def end_to_end(den, unet, device, B, args):

@@ -44,7 +44,7 @@ extern "C" {
                                  log-sum-exp to the backward);
                              11: the fp32 residual stream: WIW_EPI_RES1_F32 / WIW_EPI_RES2_F32, WIW_EPI_OUT_F32 on vectorised
                                  stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
-                                 wiw_cast_f32_to_16 */
+                                 wiw_cast_f32_to_16, wiw_calib_mfma */
 
 int wiw_abi_version(void);
 
@@ -181,7 +181,9 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  *   Wqkv : bf16 [heads*192][C], TILED as described for wiw_gemm_bf16 (WIW_W_TILED);  rows of head h = [to_q rows h*64.. | to_k rows | to_v rows], each row multiplied by the
  *          LayerNorm weight gamma (W' = W * gamma, rounded to bf16): the kernel runs its MFMAs on the raw rows of X
  *   fold : fp32 [heads][512]    per head: s[192] = sum_k W'[n][k] (of the bf16-rounded W'), t[192] = sum_k W[n][k]*beta[k],
- *          128 floats of padding;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd
+ *          then 32 words holding 64 16-bit ONES (ABI 11: the operand row with which the kernel takes both row moments of
+ *          the LayerNorm on the matrix pipe, one extra MFMA per site and k-step; `unet.pack_temporal_qkv` writes them), then
+ *          96 zero words;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd
  *          of each row are accumulated inside the kernel from the operand fragments, eps as given)
  *   O    : bf16 [batch*T*S][ldo], columns h*64 + d.   1 <= T <= 14; all pointers 16-byte aligned; ldo % 8 == 0.
  * ---------------------------------------------------------------------------------------------- */
@@ -264,6 +266,10 @@ int wiw_layernorm_f32in(void* stream, const float* X, int64_t rows, int C, const
 /* ABI 11: out[i] = round16(X[i]), n % 8 == 0 — the 16-bit MFMA operand of a stream tensor that enters a convolution
  * directly (Downsample2D / Upsample2D inputs, downsampling.py:132-150, upsampling.py:142-186). */
 int wiw_cast_f32_to_16(void* stream, const float* X, int64_t n, void* out);
+/* ABI 11, measurement only (bench.py `box`): `blocks` workgroups of 8 waves issue `iters` x 8 back-to-back MFMAs
+ * (v_mfma_f32_16x16x32, register operands, no memory traffic) per wave: blocks * 8 * iters * 8 * 16384 flop.  Timed by the
+ * caller; what this box's clocks give the matrix pipe (the pool's boxes differ by +-5 %). */
+int wiw_calib_mfma(void* stream, int blocks, int iters, float* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Conditioning embedding rows (unet:464-487, micro_cond, no-grad path) with the SiLU of

@@ -28,7 +28,8 @@ Fixtures written (all fp32 unless noted):
   pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
   pipeline_full_16x32.npz  the same __call__ for the FULL 25 steps with the served-width UNet at a 16x32 latent (T = 14):
-                           final latents + every 5th step, fp32 and fp32-on-16-bit-rounded-weights (`pipeline_full`, ~10 min)
+                           final latents + every 5th step, fp32 and fp32-on-16-bit-rounded-weights (`pipeline_full`, ~1 h)
+  pipeline_config0_32x32.npz  BASELINE config 0 (256x256x8, 10 steps) through the same __call__, served-width UNet built for 8 frames
 """
 import os
 import sys
@@ -405,6 +406,18 @@ def gen_pipeline(ns):
 
 
 def gen_pipeline_full(ns):
+    _gen_pipeline_served(ns, "pipeline_full_16x32.npz", UNetConfig(), 128, 256, 25, 31, (5, 10, 15, 20, 25))
+
+
+def gen_pipeline_config0(ns):
+    """BASELINE.json configs[0]: the single 256x256x8-frame rollout, 10 EDM steps, of FTsvd/eval_inference.py on the CPU
+    diffusers pipeline — here with the served-width UNet built for 8 frames (action_input_channel = num_frames for
+    navigation, eval_inference.py:116-125), random-init (seed 4).  Same contents as pipeline_full_16x32.npz."""
+    _gen_pipeline_served(ns, "pipeline_config0_32x32.npz", UNetConfig(num_frames=8, action_input_channel=8), 256, 256, 10, 33,
+                         (2, 4, 6, 8, 10))
+
+
+def _gen_pipeline_served(ns, fname, cfg, H, W, steps, seed, keep):
     """`StableVideoDiffusionPipeline.__call__` (pipeline_stable_video_diffusion.py:383-638) for the FULL 25 steps with the
     SERVED-WIDTH UNet (320/640/1280/1280, T = 14, weights = seed 4 as in unet_full_16x32.npz) at a 16x32 latent, B = 1 with
     CFG, output_type='latent' (a served-width reference TRAJECTORY, not only one forward).  Tiny random
@@ -416,17 +429,16 @@ def gen_pipeline_full(ns):
     from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
 
     pl = ns.pipeline_module
-    cfg = UNetConfig()
     torch.manual_seed(0)
     vae = AutoencoderKLTemporalDecoder(block_out_channels=(32, 64, 64, 64), down_block_types=("DownEncoderBlock2D",) * 4,
                                        layers_per_block=1, latent_channels=4, force_upcast=True, scaling_factor=0.18215).eval()
     clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
                                                           num_attention_heads=2, image_size=224, patch_size=32,
                                                           projection_dim=cfg.cross_attention_dim)).eval()
-    H, W, T, steps = 128, 256, cfg.num_frames, 25
-    rs = np.random.RandomState(31)
+    T = cfg.num_frames
+    rs = np.random.RandomState(seed)
     img = Image.fromarray(rs.randint(0, 256, size=(H, W, 3), dtype=np.uint8))
-    acts = np.array([[4, 1, 2, 1, 3, 1, 2, 1, 3, 1, 2, 1, 3, 1]], dtype=np.int64)   # [4] + cycle([1, 2, 1, 3])
+    acts = np.array([([4] + [1, 2, 1, 3] * 4)[:T]], dtype=np.int64)   # [4] + cycle([1, 2, 1, 3])
     img_noise = rs.standard_normal((1, 3, H, W)).astype(np.float32)
     lat_noise = rs.standard_normal((1, T, 4, H // 8, W // 8)).astype(np.float32)
     aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
@@ -457,9 +469,9 @@ def gen_pipeline_full(ns):
             return r
 
         def on_step(pipe_, i, t, kw):
-            if (i + 1) % 5 == 0:
+            if (i + 1) in keep:
                 traj[i + 1] = kw["latents"].detach().clone()
-            print(f"  pipeline_full{tag}: step {i + 1}/{steps}", flush=True)
+            print(f"  {fname}{tag}: step {i + 1}/{steps}", flush=True)
             return kw
 
         pipe._encode_vae_image, pipe._encode_image = enc_vae, enc_img
@@ -476,8 +488,8 @@ def gen_pipeline_full(ns):
             cond = dict(image_latents=cap["il"][1:].numpy(), image_embeddings=cap["ie"][1:].numpy())
         out["latents_out" + tag] = lat.numpy()
         out["trajectory" + tag] = np.stack([traj[k][0].numpy() for k in sorted(traj)])
-    save("pipeline_full_16x32.npz", weight_seed=np.array(4), num_steps=np.array(steps), actions=acts, latent_noise=lat_noise,
-         trajectory_steps=np.array([5, 10, 15, 20, 25]), **cond, **out)
+    save(fname, weight_seed=np.array(4), num_steps=np.array(steps), num_frames=np.array(T), actions=acts, latent_noise=lat_noise,
+         trajectory_steps=np.array(keep), **cond, **out)
 
 
 def gen_frontend(ns):
@@ -514,7 +526,7 @@ def main():
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
                 pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
-                pipeline_full=gen_pipeline_full)
+                pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

@@ -97,8 +97,8 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
     if args.weight_dtype not in names:
         raise SystemExit(f"--weight_dtype {args.weight_dtype!r}: the HIP path serves bfloat16 or float16")
     dtype = names[args.weight_dtype]
-    unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype)
-    den = SVDDenoiser(unet, use_graph=True if args.hip_graph else None)    # None: env WIW_GRAPH=1
+    unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype, residual_fp32=True if args.residual_fp32 else None)
+    den = SVDDenoiser(unet, use_graph=bool(args.hip_graph))   # graph replay by default, as bench.py measures
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)
     # VAE and CLIP on the HIP kernels (vae.py, clip.py: HIPFrontend builds `CLIPVisionHIP` from the `transformers` module's
     # weights).  There is no PyTorch / MIOpen route in the product (the VAE alone needed > 6 minutes per decode on a fresh

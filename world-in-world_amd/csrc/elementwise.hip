@@ -179,6 +179,56 @@ extern "C" int wiw_transpose_bf16(void* stream, const void* X, int64_t ldx, int 
     return wiw_check_launch("wiw_transpose_bf16");
 }
 
+namespace {
+// out[i] = round16(X[i]): the 16-bit MFMA operand of an fp32 residual-stream tensor (ABI 11); 8 values per thread
+__global__ __launch_bounds__(256) void cast_f32_to_16_kernel(const float* __restrict__ X, int64_t n8, uint16_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = *(const float4*)(X + i * 8), b = *(const float4*)(X + i * 8 + 4);
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        *(uint4*)(out + i * 8) = pack8(f);
+    }
+}
+}  // namespace
+
+extern "C" int wiw_cast_f32_to_16(void* stream, const float* X, int64_t n, void* out) {
+    WIW_REQUIRE(X && out && n > 0 && n % 8 == 0, "cast_f32_to_16: n must be a positive multiple of 8");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(cast_f32_to_16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, n / 8, (uint16_t*)out);
+    return wiw_check_launch("wiw_cast_f32_to_16");
+}
+
+namespace {
+// Box calibration (bench.py `box.mfma_peak_measured`): nothing but back-to-back MFMAs on register operands — 8 independent
+// accumulators per wave, 8 waves per CU (two per SIMD), one block per CU.  What THIS box's clocks give the matrix pipe; the
+// boxes of the pool differ by +-5 % on every kernel, and a reader can normalise a bench line by this number.
+__global__ __launch_bounds__(512, 2) void calib_mfma_kernel(int iters, float* out) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = (short)(WIW_ONE16 + ((lane + e) & 3)); b[e] = (short)(WIW_ONE16 - ((lane * 3 + e) & 3)); }
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = WIW_MFMA(a, b, acc[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (s == 12345.678f) out[0] = s;   // never true: keeps the loop alive
+}
+}  // namespace
+
+/* Box calibration: `blocks` blocks of 8 waves run `iters` x 8 MFMAs (16x16x32, 16 384 flop each) per wave; the caller times
+ * it with events: flops = blocks * 8 * iters * 8 * 16384. */
+extern "C" int wiw_calib_mfma(void* stream, int blocks, int iters, float* out) {
+    WIW_REQUIRE(blocks > 0 && iters > 0 && out != nullptr, "calib_mfma: bad arguments");
+    hipLaunchKernelGGL(calib_mfma_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, iters, out);
+    return wiw_check_launch("wiw_calib_mfma");
+}
+
 extern "C" int wiw_fill_f32(void* stream, float* p, int64_t n, float value) {
     WIW_REQUIRE(p != nullptr && n > 0, "fill: bad args");
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, p, n, value);

@@ -89,13 +89,79 @@ WIW_DEV void wave_lds_sync() {   // order this wave's LDS writes before its foll
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// fp32-stream epilogue (F32E instantiations; WIW_EPI_OUT_F32 / _RES1_F32 / _RES2_F32 on aligned shapes): straight from the
+// fragment layout — a lane holds 4 CONSECUTIVE columns of one row, the four fq lanes of a row 16 consecutive columns, so every
+// access is 16 bytes per lane (8 for a 16-bit tensor) in 64-byte row runs.  fp32 accumulator + bias + vector + residuals,
+// rounded ONCE (not at all for an fp32 output): no 16-bit staging in between, which is what a residual stream in fp32 is
+// for.  The residual rows of both 16-row passes are requested before the first pass's math.
+WIW_DEV void wiw_epilogue_f32(const WiwGemmArgs& p, const f32x4 (&acc)[2][10], int m0, int n0, int wave, int frow, int fq,
+                              int64_t out_slab, bool out_f32, bool r1_f32, bool r2_f32) {
+    float4 rr1[2][10], rr2[10];
+    auto ld4 = [&](const void* base, bool f32, int64_t off) -> float4 {
+        if (f32) return *(const float4*)((const float*)base + off);
+        const uint2 u = *(const uint2*)((const uint16_t*)base + off);
+        const wiw_f32x2 a = unpack2(u.x), b = unpack2(u.y);
+        return float4{a.x, a.y, b.x, b.y};
+    };
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wave * 32 + mi * 16 + frow;
+#pragma unroll
+        for (int ni = 0; ni < 10; ++ni) {
+            const int n = n0 + ni * 16 + fq * 4;
+            rr1[mi][ni] = (p.res1 && m < p.M && n < p.N) ? ld4(p.res1, r1_f32, (int64_t)m * p.ldr1 + n) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wave * 32 + mi * 16 + frow;
+        const bool m_ok = m < p.M;
+        const int mc = m_ok ? m : p.M - 1;
+        const float* rv = p.rowvec ? p.rowvec + (int64_t)(mc / p.rows_per_vec) * p.rowvec_ld : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < 10; ++ni) {
+            const int n = n0 + ni * 16 + fq * 4;
+            rr2[ni] = (p.res2 && m_ok && n < p.N) ? ld4(p.res2, r2_f32, (int64_t)m * p.ldr2 + n) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ni = 0; ni < 10; ++ni) {
+            const int n = n0 + ni * 16 + fq * 4;
+            if (m_ok && n < p.N) {
+                f32x4 v = acc[mi][ni];
+                if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (rv) { const float4 b = *(const float4*)(rv + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+                {
+                    const float4 f = rr1[mi][ni];     // zeros without res1
+                    v[0] += p.beta1 * f.x; v[1] += p.beta1 * f.y; v[2] += p.beta1 * f.z; v[3] += p.beta1 * f.w;
+                    const float4 g = rr2[ni];
+                    v[0] += p.beta2 * g.x; v[1] += p.beta2 * g.y; v[2] += p.beta2 * g.z; v[3] += p.beta2 * g.w;
+                }
+                if (out_f32) {
+                    float* d = (float*)p.out + out_slab + (int64_t)m * p.ldo + n;
+                    __builtin_nontemporal_store(v[0], d); __builtin_nontemporal_store(v[1], d + 1);
+                    __builtin_nontemporal_store(v[2], d + 2); __builtin_nontemporal_store(v[3], d + 3);
+                } else {
+                    uint32_t* d = (uint32_t*)((uint16_t*)p.out + (int64_t)m * p.ldo + n);
+                    __builtin_nontemporal_store(pack2bf(v[0], v[1]), d);
+                    __builtin_nontemporal_store(pack2bf(v[2], v[3]), d + 1);
+                }
+            }
+        }
+    }
+}
+
 // LNF (WIW_EPI_LNFOLD, dense mode): the A operand is the RAW input x of a LayerNorm over K = C1 and W holds W * gamma:
 //     LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n,   s_n = sum_k W'[n][k],  t_n = sum_k W[n][k] beta[k] + bias_n
 // (exact; p.lnfold = [s | t], fp32).  Every wave owns whole rows (32 rows x all 160 columns), so it accumulates the row
 // sums / sums of squares of its rows from the A fragments it feeds to the MFMAs anyway, and the fold is applied to the
 // fp32 accumulators in the fragment layout BEFORE the first 16-bit rounding.  The LayerNorm pass (one read + one write
 // of the activation) and the normalised tensor disappear.
-template <int MODE, int NW, int STAGES, bool GE, bool LNF = false>
+// F32E: the instantiation that serves the fp32 residual stream (ABI 11: WIW_EPI_OUT_F32 / _RES1_F32 / _RES2_F32 on aligned
+// shapes) — ONLY the vectorised fragment-layout epilogue is compiled into it, and it is compiled into no other instantiation
+// (in the common one its 120 residual registers cost every launch 240-300 bytes of scratch per lane).
+template <int MODE, int NW, int STAGES, bool GE, bool LNF = false, bool F32E = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, const int stagger) {
     constexpr int BM = NW * 32;
     constexpr int A_BYTES = BM * BK * 2;
@@ -411,8 +477,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     const int n_valid = geglu ? p.n_out : p.N;
     const uint16_t* r1 = (const uint16_t*)p.res1;
     const uint16_t* r2 = (const uint16_t*)p.res2;
+    // fp32 residual stream (ABI 11): res1 / res2 / out in fp32 -> the vectorised fragment-layout epilogue below
+    const bool r1_f32 = (p.epilogue & WIW_EPI_RES1_F32) != 0, r2_f32 = (p.epilogue & WIW_EPI_RES2_F32) != 0;
     // staged (fast) epilogue: bf16 output on 16-byte aligned rows; everything else takes the direct path
-    const bool staged = !out_f32 && !do_silu && act == 0 && (n_valid % 8 == 0) && (p.ldo % 8 == 0) &&
+    const bool staged = !F32E && !out_f32 && !r1_f32 && !r2_f32 && !do_silu && act == 0 && (n_valid % 8 == 0) && (p.ldo % 8 == 0) &&
                         (r1 == nullptr || p.ldr1 % 8 == 0) && (r2 == nullptr || p.ldr2 % 8 == 0) &&
                         ((((uintptr_t)p.bias | (uintptr_t)p.rowvec) & 15) == 0) && (p.rowvec_ld % 4 == 0);
 
@@ -650,7 +718,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         };
 
         // ---- epilogue, part 2 (per wave, no block barrier)
-        if (staged) {
+        if constexpr (F32E) {
+            wiw_epilogue_f32(p, acc, m0, n0, wave, frow, fq, out_slab, out_f32, r1_f32, r2_f32);
+        } else if (staged) {
             char* stg = smem + st_e * STAGE_BYTES + wave * STG_WAVE;
             uint4* dump = g_dump + (blockIdx.x & 511) * 64 + lane;
             auto half_pass = [&](auto ge_tag, auto mi_tag) {
@@ -865,8 +935,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                                 if (act == WIW_EPI_GELU) y = gelu_erf_f(y);
                                 else if (act == WIW_EPI_QUICK_GELU)   // x * sigmoid(1.702 x)
                                     y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * y));
-                                if (r1) y += p.beta1 * bf2f(r1[(int64_t)m * p.ldr1 + n]);
-                                if (r2) y += p.beta2 * bf2f(r2[(int64_t)m * p.ldr2 + n]);
+                                if (r1) y += p.beta1 * (r1_f32 ? ((const float*)p.res1)[(int64_t)m * p.ldr1 + n] : bf2f(r1[(int64_t)m * p.ldr1 + n]));
+                                if (r2) y += p.beta2 * (r2_f32 ? ((const float*)p.res2)[(int64_t)m * p.ldr2 + n] : bf2f(r2[(int64_t)m * p.ldr2 + n]));
                             }
                         }
                         if (ok) {
@@ -906,8 +976,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const WiwGemmArgs p)
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
     }
     const float* rv = p.rowvec ? p.rowvec + (m / p.rows_per_vec) * p.rowvec_ld + n : nullptr;
-    const uint16_t* r1 = p.res1 ? (const uint16_t*)p.res1 + m * p.ldr1 + n : nullptr;
-    const uint16_t* r2 = p.res2 ? (const uint16_t*)p.res2 + m * p.ldr2 + n : nullptr;
+    const bool r1_f32 = (p.epilogue & WIW_EPI_RES1_F32) != 0, r2_f32 = (p.epilogue & WIW_EPI_RES2_F32) != 0;
+    const uint16_t* r1 = p.res1 ? (const uint16_t*)p.res1 + (m * p.ldr1 + n) * (r1_f32 ? 2 : 1) : nullptr;
+    const uint16_t* r2 = p.res2 ? (const uint16_t*)p.res2 + (m * p.ldr2 + n) * (r2_f32 ? 2 : 1) : nullptr;
     const bool do_silu = (p.epilogue & WIW_EPI_SILU) != 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -916,8 +987,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const WiwGemmArgs p)
         if (rv) y += rv[e];
         y *= p.alpha;
         if (do_silu) y = silu_f(y);
-        if (r1) y += p.beta1 * bf2f(r1[e]);
-        if (r2) y += p.beta2 * bf2f(r2[e]);
+        if (r1) y += p.beta1 * (r1_f32 ? ((const float*)r1)[e] : bf2f(r1[e]));
+        if (r2) y += p.beta2 * (r2_f32 ? ((const float*)r2)[e] : bf2f(r2[e]));
         v[e] = y;
     }
     if (p.epilogue & WIW_EPI_OUT_F32) {
@@ -929,7 +1000,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const WiwGemmArgs p)
     }
 }
 
-template <int MODE, int NW, int STAGES, bool GE, bool LNF = false>
+template <int MODE, int NW, int STAGES, bool GE, bool LNF = false, bool F32E = false>
 int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     constexpr int BM = NW * 32;
     constexpr int SMEM = STAGES * (BM * BK * 2 + B_BYTES) + (LNF ? 2 * 2 * BN * 4 : 0);   // + two parities of s | t
@@ -938,7 +1009,7 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_kernel<MODE, NW, STAGES, GE, LNF, F32E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -953,7 +1024,7 @@ int launch_cfg(hipStream_t s, const WiwGemmArgs& a, int blocks_per_cu) {
     if (tiles < grid) grid = tiles >= 64 ? (tiles / 8) * 8 : tiles;   // keep the per-XCD super-tile schedule usable
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     const int stagger = stg_env ? atoi(stg_env) : 0;
-    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE, LNF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_kernel<MODE, NW, STAGES, GE, LNF, F32E>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16");
 }
 
@@ -973,7 +1044,7 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
         WiwGemmArgs g = a;
         g.out = a.workspace; g.ldo = a.N;
         g.bias = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.res2 = nullptr;
-        g.alpha = 1.0f; g.epilogue = WIW_EPI_OUT_F32 | (a.epilogue & WIW_W_TILED);
+        g.alpha = 1.0f; g.epilogue = WIW_EPI_OUT_F32 | (a.epilogue & WIW_W_TILED);   // (the fp32-residual bits belong to pass 2)
         // tile: 256 x 320 when N fills it, every K range keeps >= 10 K tiles and the ranges give (nearly) every CU an
         // item; else 256 x 160.   WIW_GEMM_TILE=huge|big overrides (A/B).
         static const char* force_sk = getenv("WIW_GEMM_TILE");
@@ -997,6 +1068,15 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
             wiw_set_error("gemm: the LayerNorm fold is a dense-mode epilogue");
             return WIW_EINVAL;
         }
+    }
+    // fp32 residual stream (ABI 11): the F32E instantiation on aligned shapes (everything else with these bits: the scalar
+    // direct path of the common instantiation)
+    if ((a.epilogue & (WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32 | WIW_EPI_OUT_F32)) &&
+        !(a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)) && a.N % 4 == 0 && a.ldo % 4 == 0 &&
+        (a.res1 == nullptr || a.ldr1 % 4 == 0) && (a.res2 == nullptr || a.ldr2 % 4 == 0) &&
+        ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) == 0) && a.rowvec_ld % 4 == 0) {
+        const bool big_f = force ? (force[0] != 's') : use_big_tile(a);
+        return big_f ? launch_cfg<MODE, 8, 3, false, false, true>(s, a, 1) : launch_cfg<MODE, 4, 2, false, false, true>(s, a, 2);
     }
     if ((!force || force[0] == 'h') && wiw_gemm_huge_ok(a)) return wiw_gemm_huge_launch(s, a);   // gemm_huge.hip
     const bool big = force ? (force[0] != 's') : use_big_tile(a);
@@ -1036,6 +1116,11 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     }
     WIW_REQUIRE(a.rowvec == nullptr || a.rows_per_vec > 0, "gemm: rows_per_vec must be > 0 with rowvec");
     WIW_REQUIRE(a.ldo > 0, "gemm: ldo must be positive");
+    if (a.epilogue & (WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) {
+        WIW_REQUIRE(!(a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_LNFOLD)), "gemm: fp32 residuals do not go with GEGLU / LayerNorm-fold epilogues");
+        WIW_REQUIRE(!(a.epilogue & WIW_EPI_RES1_F32) || a.res1 != nullptr, "gemm: WIW_EPI_RES1_F32 without res1");
+        WIW_REQUIRE(!(a.epilogue & WIW_EPI_RES2_F32) || a.res2 != nullptr, "gemm: WIW_EPI_RES2_F32 without res2");
+    }
     if (a.epilogue & WIW_EPI_GEGLU) {
         WIW_REQUIRE(a.N % BN == 0 && a.n_out > 0 && a.n_out <= a.N / 2, "gemm: GEGLU needs N % 160 == 0 and n_out");
         WIW_REQUIRE(a.rowvec == nullptr && a.res1 == nullptr && a.res2 == nullptr, "gemm: GEGLU takes bias only");

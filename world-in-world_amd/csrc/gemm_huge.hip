@@ -655,7 +655,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
 // (nearly) every CU one.  Everything else stays on gemm.hip's tiles.
 bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
-    if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)) return false;
+    if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) return false;
     // partial last N tile (the VAE's 256 / 512-channel layers): only without GEGLU and when 320-wide tiles idle no more
     // MFMA columns than 160-wide ones would
     if (a.N % HN != 0 && (ge || ((a.N + HN - 1) / HN) * HN > ((a.N + 159) / 160) * 160)) return false;

@@ -20,6 +20,7 @@ A_DENSE, A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_CONV3X3_S2P = 0, 1,
 EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
 EPI_LNFOLD = 64  # epilogue bit: A is the raw LayerNorm input, W = W * gamma, lnfold = [s | t] (include/wiw_svd.h)
+EPI_RES1_F32, EPI_RES2_F32 = 128, 256   # epilogue bits: res1 / res2 are fp32 (the fp32 residual stream, ABI 11)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
 FFN_C, FFN_HIDDEN = 320, 1280   # the one shape wiw_ffn_geglu_bf16 is built for
@@ -118,6 +119,13 @@ EXPORTS = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "wiw_layernorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "wiw_groupnorm_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
+    "wiw_groupnorm_apply_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "wiw_layernorm_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "wiw_cast_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "wiw_calib_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wiw_emb_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
     "wiw_prep_unet_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -190,7 +198,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 10:
+        if self.lib.wiw_abi_version() != 11:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -255,6 +263,12 @@ class Hip:
         a.rowvec_ld, a.rows_per_vec = rowvec_ld, rows_per_vec
         a.alpha, a.beta1, a.beta2 = alpha, beta1, beta2
         a.epilogue = epilogue | (W_TILED if isinstance(W, TiledW) else 0)
+        # fp32 residual stream (ABI 11): an fp32 res1 / res2 tensor sets its bit; an fp32 `out` needs EPI_OUT_F32 from the caller
+        if res1 is not None and res1.dtype == torch.float32:
+            a.epilogue |= EPI_RES1_F32
+        if res2 is not None and res2.dtype == torch.float32:
+            a.epilogue |= EPI_RES2_F32
+        assert (out.dtype == torch.float32) == bool(a.epilogue & EPI_OUT_F32), "gemm: fp32 out <=> EPI_OUT_F32"
         if lnfold is not None:
             a.epilogue |= EPI_LNFOLD
             a.lnfold, a.ln_eps = lnfold.data_ptr(), ln_eps
@@ -351,10 +365,15 @@ class Hip:
         buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
         return buf[: units * 64], buf[units * 64:]
 
-    def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False):
+    def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False, raw16=None):
         """statistics (deterministic, no atomics) -> fused finalize + apply; returns the normalised (and SiLU'd) bf16
-        tensor [rows, C1+C2].  clip=True: the unit is a whole clip (T frames), see gn_rows_per_block."""
-        if os.environ.get("WIW_GN_UNFUSED"):   # A/B knob for profiling
+        tensor [rows, C1+C2].  clip=True: the unit is a whole clip (T frames), see gn_rows_per_block.
+        fp32 residual stream (ABI 11): fp32 X1 (and X2) select the fp32-input kernels; `raw16` (16-bit [rows, C1 + C2]) then
+        also receives the rounded raw input (the operand of the 1x1 conv_shortcut)."""
+        f32in = X1.dtype == torch.float32
+        assert X2 is None or (X2.dtype == torch.float32) == f32in, "groupnorm: X1 and X2 must have one dtype"
+        assert raw16 is None or f32in, "groupnorm: raw16 only with fp32 inputs"
+        if os.environ.get("WIW_GN_UNFUSED") and not f32in:   # A/B knob for profiling
             return self.groupnorm_unfused(X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out, clip)
         Ct = C1 + C2
         rpb = self.gn_rows_per_block(rows_per_unit, clip)
@@ -364,6 +383,13 @@ class Hip:
         s = self._stream()
 
         def launch():
+            if f32in:
+                self._ck(self.lib.wiw_groupnorm_stats_f32in(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
+                                                            scratch.data_ptr()), "wiw_groupnorm_stats_f32in")
+                self._ck(self.lib.wiw_groupnorm_apply_stats_f32in(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
+                                                                  _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr(),
+                                                                  _p(raw16)), "wiw_groupnorm_apply_stats_f32in")
+                return
             self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
                                                   scratch.data_ptr()), "wiw_groupnorm_stats")
             self._ck(self.lib.wiw_groupnorm_apply_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
@@ -371,7 +397,7 @@ class Hip:
                      "wiw_groupnorm_apply_stats")
 
         # algorithmic bytes: the input is read twice (statistics, apply) and the output written once (bf16)
-        self._timed("groupnorm", 0.0, 6.0 * rows * Ct, launch)
+        self._timed("groupnorm", 0.0, ((10.0 if f32in else 6.0) + (2.0 if raw16 is not None else 0.0)) * rows * Ct, launch)
         return out
 
     def groupnorm_unfused(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False):
@@ -396,10 +422,55 @@ class Hip:
                   out=None):
         if out is None:
             out = torch.empty((rows, Cn), dtype=self.dtype, device=self.device)
+        if X.dtype == torch.float32:    # fp32 residual stream (ABI 11)
+            assert addvec is None and sum_out is None, "layernorm: the fp32-input kernel takes no pre-add"
+            self._timed("layernorm", 0.0, 6.0 * rows * Cn, lambda: self._ck(
+                self.lib.wiw_layernorm_f32in(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, out.data_ptr()),
+                "wiw_layernorm_f32in"))
+            return out
         self._timed("layernorm", 0.0, (6.0 if sum_out is not None else 4.0) * rows * Cn, lambda: self._ck(
             self.lib.wiw_layernorm_bf16(self._stream(), _p(X), rows, Cn, _p(gamma), _p(beta), eps, _p(addvec),
                                         addvec_ld, rows_per_vec, _p(sum_out), out.data_ptr()), "wiw_layernorm_bf16"))
         return out
+
+    def cast16(self, X, out=None):
+        """fp32 tensor -> this library's 16-bit type (the MFMA operand of an fp32 residual-stream tensor)."""
+        assert X.dtype == torch.float32 and X.numel() % 8 == 0
+        if out is None:
+            out = torch.empty(X.shape, dtype=self.dtype, device=self.device)
+        self._timed("cast16", 0.0, 6.0 * X.numel(), lambda: self._ck(
+            self.lib.wiw_cast_f32_to_16(self._stream(), _p(X), X.numel(), out.data_ptr()), "wiw_cast_f32_to_16"))
+        return out
+
+    def calibrate_box(self, target_ms: float = 50.0):
+        """What THIS box gives (bench.py `box`): a pure-MFMA launch of ~target_ms (register operands, one 8-wave block per CU)
+        and a 1 GiB device copy, both timed with events.  -> dict(mfma_tflops, copy_GBps, cus)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        out = torch.zeros(4, dtype=torch.float32, device=self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def run(iters):
+            e0.record()
+            self._ck(self.lib.wiw_calib_mfma(self._stream(), cus, iters, out.data_ptr()), "wiw_calib_mfma")
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        run(1000)                                   # code load
+        ms = run(20000)
+        iters = max(20000, int(20000 * target_ms / max(ms, 1e-3)))
+        ms = min(run(iters), run(iters))
+        tf = cus * 8.0 * iters * 8 * 16384 / (ms * 1e-3) / 1e12
+        src = torch.empty(1 << 28, dtype=torch.float32, device=self.device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0.record()
+        for _ in range(4):
+            dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        gbps = 4 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        return {"mfma_tflops": round(tf, 1), "copy_GBps": round(gbps, 1), "cus": cus}
 
     def transpose(self, X, ldx, c0, rows, Cn, Y, ldy):
         """Y[c][r] = X[r][c0 + c] (bf16)."""

@@ -154,7 +154,9 @@ class SVDDenoiser:
         hw = h * w
         gf = None
         if self.use_graph and self.graph_error is None:
-            gf = self._graphs.get((B, h, w))
+            gf = self._graphs.pop((B, h, w), None)
+            if gf is not None:
+                self._graphs[(B, h, w)] = gf     # re-insert: dict order = recency, eviction below is least-recently-used
             if gf is None:
                 prof = (self.hip.gemm_profile, self.hip.kernel_profile)      # (bench.py may have armed per-launch events for
                 self.hip.gemm_profile = self.hip.kernel_profile = None       # the first step: not inside a capture)

@@ -323,9 +323,13 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--weight_dtype", type=str, default="bfloat16")
     ap.add_argument("--num_inference_steps", type=int, default=30)
     ap.add_argument("--port", type=int, default=0, help="> 0: standalone TCP server instead of the manager pipe loop")
-    ap.add_argument("--hip_graph", action="store_true",
-                    help="replay the UNet forward from a captured hipGraph (one per candidate count; same bytes, ~20 ms less host "
-                         "work per forward; a captured shape pins ~6 GB of HBM per candidate at 576x1024)")
+    ap.add_argument("--hip_graph", action=argparse.BooleanOptionalAction, default=True,
+                    help="replay the UNet forward from a captured hipGraph (one per candidate count; same bytes, ~12 ms less host "
+                         "work per forward; a captured shape pins ~6 GB of HBM per candidate at 576x1024).  ON by default — the "
+                         "mode bench.py measures; --no-hip_graph launches eagerly")
+    ap.add_argument("--residual_fp32", action="store_true",
+                    help="keep the UNet's residual stream in fp32 (UNetHIP(residual_fp32=True)): with --weight_dtype float16 the "
+                         "configuration that is within 1e-3 of the reference's fp32 evaluation (DESIGN.md 5); slower")
     ap.add_argument("--batch_size", type=int, default=0)
     ap.add_argument("--coalesce_candidates", type=int, default=0,
                     help="> 0: batch requests of different clients into one GPU call of up to this many candidates")

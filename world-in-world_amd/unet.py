@@ -77,7 +77,9 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
     weight folded in (W' = bf16(W * gamma)), and per head the fold vectors s = sum_k W'[n][k] (of the ROUNDED weights,
     so the fold is exact for what the MFMAs multiply), t = sum_k W[n][k] * beta[k]:
-        LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n."""
+        LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n.
+    fold[h] = [s (192) | t (192) | 32 words of 16-bit ONES | zeros] fp32 words: the 128 bytes of ones are the "frame slot 15"
+    operand row with which the kernel takes the LayerNorm row moments on the matrix pipe (temporal.hip, WIW_T_MFMA_STATS)."""
     C = wq.shape[1]
     heads = C // 64
     wp = torch.stack([m.float().reshape(heads, 64, C) for m in (wq, wk, wv)], dim=1).reshape(heads * 192, C)
@@ -85,6 +87,8 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     fold = torch.zeros(heads, 512, dtype=torch.float32, device=wp.device)
     fold[:, :192] = wg.float().sum(dim=1).reshape(heads, 192)
     fold[:, 192:384] = (wp @ beta.float()).reshape(heads, 192)
+    one16 = 0x3C00 if dtype == torch.float16 else 0x3F80
+    fold.view(torch.int32)[:, 384:416] = one16 * 0x10001
     # the kernel streams the weight in the tiled layout of hip.TiledW (1-KiB blocks, one contiguous KiB per DMA instruction)
     return (tile_weight(wg) if tiled else wg), fold.contiguous()
 
@@ -116,9 +120,17 @@ class RequestCond:
 
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
-                 hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None):
+                 hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None,
+                 residual_fp32: Optional[bool] = None):
         """dtype: 16-bit storage type of weights and activations (bf16, or fp16 = the reference's served default,
         eval_inference.py:294); with `hip` given, its dtype is used.
+        residual_fp32: keep the RESIDUAL STREAM in fp32 (ABI 11) — the outputs x + f(x) of every ResnetBlock and transformer
+        sub-block, the AlphaBlender outputs, the skip tensors and the stream between blocks are fp32 tensors (never rounded to
+        the 16-bit type), every MFMA operand stays 16-bit.  The reference keeps latents and the Euler update in fp32
+        (scheduling_euler_discrete.py:635,673) and autocasts nothing inside the UNet; with fp16 storage this is the
+        configuration that meets north_star's 1e-3 relative error on the served architecture (DESIGN.md 5:
+        oracle/precision_study.py `res32`, tests/test_hip_fp16.py).  Cost: the fused FeedForward / temporal-block kernels
+        (16-bit streams) are replaced by their unfused chains and the stream's bytes double.  Default: env WIW_RES32.
         fold_layernorm: fold norm1 / norm3 / norm_in into their consumer GEMMs at the widths the 256x160 tile serves
         (WIW_EPI_LNFOLD).  OFF by default: measured -0.7 % on the rollout (the in-kernel row statistics cost the K = 320
         GEMMs more than the four LayerNorm passes per block they replace); env WIW_LN_FOLD=1 turns it on."""
@@ -135,7 +147,12 @@ class UNetHIP:
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         # fused FeedForward kernel of the 320-channel level (ffn.hip); A/B knobs: WIW_FF_UNFUSED=1 -> two GEMMs again,
         # WIW_FFN_NO_LN=1 -> fused FeedForward behind a separate LayerNorm pass
-        self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED")
+        self.res32 = bool(os.environ.get("WIW_RES32")) if residual_fp32 is None else bool(residual_fp32)
+        self.sdt = torch.float32 if self.res32 else self.dtype      # dtype of residual-stream tensors
+        if self.res32:
+            self.ln_fold = False          # the folds read the raw stream as a 16-bit MFMA operand
+            self.temporal_unfused = True  # LayerNorm (fp32 in) + QKV GEMM + attention core
+        self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not self.res32
         self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
         self._prepare(state_dict)
 
@@ -338,9 +355,11 @@ class UNetHIP:
                 return sk
         return 1
 
-    def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, **kw):
+    def _linear(self, x, p, M, *, out_f32=False, silu=False, res1=None, stream=False, **kw):
+        """stream=True: the output is a residual-stream tensor (fp32 when `residual_fp32`)."""
         W = self.w[p + ".weight"]
         N, K = W.shape
+        out_f32 = out_f32 or (stream and self.res32)
         out = self._empty(M, N, dtype=torch.float32 if out_f32 else self.dtype)
         epi = (EPI_OUT_F32 if out_f32 else 0) | (EPI_SILU if silu else 0)
         return self.hip.gemm(x, W, out, M=M, N=N, K=K, C1=K, bias=self.w.get(p + ".bias"), epilogue=epi,
@@ -351,10 +370,11 @@ class UNetHIP:
         h = self._linear(x_bf16, p + ".linear_1", M, silu=True)
         return self._linear(h, p + ".linear_2", M, out_f32=True)
 
-    def _geglu_ff(self, a, p, M, Cn, ln_input=None, **epi_kw):
+    def _geglu_ff(self, a, p, M, Cn, ln_input=None, stream=True, **epi_kw):
         """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue.
         ln_input: the RAW input of the LayerNorm in front of this FeedForward — given instead of `a` (= None) where the
-        norm is folded into the projection (`_fold_ln`)."""
+        norm is folded into the projection (`_fold_ln`).  stream: the output is a residual-stream tensor (fp32 when
+        `residual_fp32`); False for the AlphaBlender output that only feeds proj_out as an MFMA operand."""
         if (p + ".ffn.w1") in self.w:     # C = 320: ONE kernel, the [M, 4C] hidden tensor never exists (ffn.hip)
             ln = ln_input is not None
             assert not ln or (p + ".ffn.w1ln") in self.w
@@ -375,8 +395,10 @@ class UNetHIP:
             self.hip.gemm(a, W1, g, M=M, N=W1.shape[0], K=Cn, C1=Cn, bias=self.w[p + ".net.0.proj.bias"],
                           epilogue=EPI_GEGLU, n_out=4 * Cn)
         W2 = self.w[p + ".net.2.weight"]
-        out = self._empty(M, Cn)
-        return self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"], **epi_kw)
+        f32 = stream and self.res32
+        out = self._empty(M, Cn, dtype=torch.float32 if f32 else self.dtype)
+        return self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"],
+                             epilogue=EPI_OUT_F32 if f32 else 0, **epi_kw)
 
     # ------------------------------------------------------------------------------------------
     # request-level (step-invariant) conditioning
@@ -423,18 +445,27 @@ class UNetHIP:
         S = H * W
         s, t = p + ".spatial_res_block", p + ".temporal_res_block"
         Cin = C1 + C2
-        xn = hip.groupnorm(x1, C1, x2, C2, M, S, w[s + ".norm1.weight"], w[s + ".norm1.bias"], eps, True)
+        sdt = self.sdt                       # residual-stream dtype: xs and the block output (fp32 when residual_fp32)
+        epi_s = EPI_OUT_F32 if self.res32 else 0
+        raw = None
+        if self.res32 and s + ".conv2sc.weight" in w:
+            # the fused 1x1 shortcut reads the block input as an MFMA operand: the GroupNorm pass (which holds it in
+            # registers anyway) also writes its rounded copy, already concatenated
+            raw = self._empty(M, Cin)
+        xn = hip.groupnorm(x1, C1, x2, C2, M, S, w[s + ".norm1.weight"], w[s + ".norm1.bias"], eps, True, raw16=raw)
         h = self._empty(M, Cout)
         hip.gemm(xn, w[s + ".conv1.weight"], h, M=M, N=Cout, K=9 * Cin, C1=Cin, mode=A_CONV3X3, H=H, Wd=W,
                  bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
                  rows_per_vec=S, splitk=self._splitk(T * S, Cout, 9 * Cin))
         hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
-        xs = self._empty(M, Cout)
+        xs = self._empty(M, Cout, dtype=sdt)
         if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
+            sc_ops = dict(A2=raw, C2=Cin) if raw is not None else dict(A2=x1, C2=C1, A3=x2, C3=C2)
             hip.gemm(hn, w[s + ".conv2sc.weight"], xs, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     A2=x1, C2=C1, A3=x2, C3=C2, bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin))
+                     bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin), epilogue=epi_s, **sc_ops)
         else:
             if s + ".conv_shortcut.weight" in w:   # unfused A/B path: separate 1x1 GEMM, then residual
+                assert not self.res32, "WIW_UNFUSED_SHORTCUT is a 16-bit-stream A/B knob"
                 sc = self._empty(M, Cout)
                 hip.gemm(x1, w[s + ".conv_shortcut.weight"], sc, M=M, N=Cout, K=Cin, C1=C1, A2=x2, C2=C2,
                          bias=w[s + ".conv_shortcut.bias"])
@@ -442,7 +473,8 @@ class UNetHIP:
                 assert x2 is None
                 sc = x1
             hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0, splitk=self._splitk(T * S, Cout, 9 * Cout))
+                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0, splitk=self._splitk(T * S, Cout, 9 * Cout),
+                     epilogue=epi_s)
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
         xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True, clip=True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
@@ -450,10 +482,10 @@ class UNetHIP:
                  rows_per_vec=S)
         hn = hip.groupnorm(h, Cout, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], eps, True, out=hn, clip=True)
         a = self.alpha[p]
-        out = self._empty(M, Cout)
+        out = self._empty(M, Cout, dtype=sdt)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2(h) + b) = xs + (1-a)*(acc + b)   (resnet.py:784-797)
         hip.gemm(hn, w[t + ".conv2.weight"], out, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
-                 bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0)
+                 bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s)
         return out
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
@@ -465,7 +497,7 @@ class UNetHIP:
         b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
         scale = 1.0 / math.sqrt(64.0)
         xn = hip.groupnorm(x, Cn, None, 0, M, S, w[p + ".norm.weight"], w[p + ".norm.bias"], 1e-6, False)
-        h = self._linear(xn, p + ".proj_in", M)
+        h = self._linear(xn, p + ".proj_in", M, stream=True)
         # ---- spatial block (attention.py:462-582)
         legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
         # LayerNorm folded into its consumer GEMM where that GEMM runs on the 256x160 tile (`_fold_ln`): the projection
@@ -473,6 +505,8 @@ class UNetHIP:
         fold_qkv = (b + ".attn1.to_qkv.lnfold.weight") in w and not self.swapped_vt
         fold_ff = ((b + ".ff.net.0.proj.lnfold.weight") in w or (b + ".ff.ffn.w1ln") in w) and not legacy
         a = xn
+        if self.res32:
+            assert not (fold_qkv or fold_ff or legacy or self.swapped_vt), "A/B knobs of the 16-bit stream"
         if not fold_qkv:
             a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
         vt = self._empty(Cn, M)
@@ -501,12 +535,15 @@ class UNetHIP:
             a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=h, out=a)
         else:
-            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S)
+            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S,
+                             stream=True)
             if not fold_ff:
                 a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
         am = self.alpha[p]
         # hs + emb is stored instead of hs; the blend below subtracts am * emb again
         fold_emb = abs(1.0 - am) > 1e-4 and not legacy
+        if self.res32 and not fold_emb:
+            raise NotImplementedError("residual_fp32 with sigmoid(mix_factor) == 1: the pre-add LayerNorm path is 16-bit only")
         lnin = h if fold_ff else None         # the FeedForwards below take the RAW stream where their norm is folded
         if fold_emb:
             hm = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0, rowvec=cond.pos_emb[p],
@@ -536,19 +573,21 @@ class UNetHIP:
             a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=hm, out=a)
         else:
-            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S)
+            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S,
+                              stream=True)
             if not fold_ff:
                 a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
         # AlphaBlender: am*hs + (1-am)*(hm + ff(a)); with hs' = hs + emb stored: am*hs = am*hs' - am*emb, and the
         # epilogue's vector enters as alpha * rowvec with alpha = 1 - am  ->  rowvec = -am / (1 - am) * emb
         lnin = hm if fold_ff else None
+        # (the blend only feeds proj_out as an MFMA operand: 16-bit in both stream modes)
         if fold_emb:
             hb = self._geglu_ff(a, t + ".ff", M, Cn, ln_input=lnin, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs,
-                                ldr2=Cn, beta2=am, rowvec=cond.pos_emb_blend[p], rowvec_ld=Cn, rows_per_vec=S)
+                                ldr2=Cn, beta2=am, rowvec=cond.pos_emb_blend[p], rowvec_ld=Cn, rows_per_vec=S, stream=False)
         else:
             hb = self._geglu_ff(a, t + ".ff", M, Cn, ln_input=lnin, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs,
-                                ldr2=Cn, beta2=am)
-        return self._linear(hb, p + ".proj_out", M, res1=x)
+                                ldr2=Cn, beta2=am, stream=False)
+        return self._linear(hb, p + ".proj_out", M, res1=x, stream=True)
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -576,9 +615,10 @@ class UNetHIP:
         temb_all = self._empty(frames, self.temb_total, dtype=torch.float32)
         hip.gemm(emb_silu, w["temb_all.weight"], temb_all, M=frames, N=self.temb_total, K=cfg.time_embed_dim,
                  C1=cfg.time_embed_dim, bias=w["temb_all.bias"], epilogue=EPI_OUT_F32)
-        x = self._empty(M, ch[0])
+        epi_s = EPI_OUT_F32 if self.res32 else 0     # residual-stream outputs (fp32 when residual_fp32)
+        x = self._empty(M, ch[0], dtype=self.sdt)
         hip.gemm(x_in, w["conv_in.weight"], x, M=M, N=ch[0], K=9 * CIN_PAD, C1=CIN_PAD, mode=A_CONV3X3, H=h, Wd=w_,
-                 bias=w["conv_in.bias"])
+                 bias=w["conv_in.bias"], epilogue=epi_s)
         skips = [(x, ch[0])]
         H, W, C = h, w_, ch[0]
         for i in range(n):
@@ -593,9 +633,11 @@ class UNetHIP:
                 skips.append((x, C))
             if i < n - 1:
                 H, W, M = H // 2, W // 2, M // 4
-                y = self._empty(M, C)
+                y = self._empty(M, C, dtype=self.sdt)
                 q = f"{p}.downsamplers.0.conv"
-                hip.gemm(x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_S2, H=H, Wd=W, bias=w[q + ".bias"])
+                # (an fp32 stream enters the convolution as its rounded copy: Downsample2D has no norm in front of it)
+                hip.gemm(hip.cast16(x) if self.res32 else x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_S2,
+                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s)
                 x = y
                 skips.append((x, C))
         x = self._res_block("mid_block.resnets.0", x, C, None, 0, C, M, H, W, temb_all, 1e-5)
@@ -613,9 +655,10 @@ class UNetHIP:
                     x = self._transformer(f"{p}.attentions.{j}", x, C, M, H, W, rheads[i], cond)
             if i < n - 1:
                 H, W, M = H * 2, W * 2, M * 4
-                y = self._empty(M, C)
+                y = self._empty(M, C, dtype=self.sdt)
                 q = f"{p}.upsamplers.0.conv"
-                hip.gemm(x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_UP, H=H, Wd=W, bias=w[q + ".bias"])
+                hip.gemm(hip.cast16(x) if self.res32 else x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_UP,
+                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s)
                 x = y
         xn = hip.groupnorm(x, C, None, 0, M, H * W, w["conv_norm_out.weight"], w["conv_norm_out.bias"], 1e-5, True)
         out = self._empty(M, cfg.out_channels, dtype=torch.float32)
