@@ -181,9 +181,7 @@ int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, in
  *   Wqkv : bf16 [heads*192][C], TILED as described for wiw_gemm_bf16 (WIW_W_TILED);  rows of head h = [to_q rows h*64.. | to_k rows | to_v rows], each row multiplied by the
  *          LayerNorm weight gamma (W' = W * gamma, rounded to bf16): the kernel runs its MFMAs on the raw rows of X
  *   fold : fp32 [heads][512]    per head: s[192] = sum_k W'[n][k] (of the bf16-rounded W'), t[192] = sum_k W[n][k]*beta[k],
- *          then 32 words holding 64 16-bit ONES (ABI 11: the operand row with which the kernel takes both row moments of
- *          the LayerNorm on the matrix pipe, one extra MFMA per site and k-step; `unet.pack_temporal_qkv` writes them), then
- *          96 zero words;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd
+ *          128 floats of padding;  q_n = rstd * (x . W'_n - mean * s_n) + t_n  (LayerNorm folded exactly; mean / rstd
  *          of each row are accumulated inside the kernel from the operand fragments, eps as given)
  *   O    : bf16 [batch*T*S][ldo], columns h*64 + d.   1 <= T <= 14; all pointers 16-byte aligned; ldo % 8 == 0.
  * ---------------------------------------------------------------------------------------------- */

@@ -25,6 +25,8 @@ Fixtures written (all fp32 unless noted):
   unet_full_16x32.npz      FULL-WIDTH UNet (320/640/1280/1280, 5/10/20/20 heads, T = 14 — the served architecture) forward
                            at latent 16x32, B=1 with CFG: fp32 reference output, the reference's own bf16 run, and the
                            reference run in fp32 with bf16-ROUNDED WEIGHTS (the error floor of any bf16-weight evaluation)
+  manip_actions.npz        task_type 'manipulation': get_action_ids on (b, 14, 8) continuous actions (absolute / relative),
+                           action_encode_positional, a tiny UNet forward with a 10-channel ActionEmbedder_
   pipeline_tiny.npz        StableVideoDiffusionPipeline.__call__ (output_type='latent', 3 steps) with
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
   pipeline_full_16x32.npz  the same __call__ for the FULL 25 steps with the served-width UNet at a 16x32 latent (T = 14):
@@ -109,6 +111,38 @@ def gen_action_ids(ns):
                      [4, 3, 3, 3, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1]], dtype=np.int64)
     ids = ns.get_action_ids(3, torch.from_numpy(acts), "micro_cond", torch.float32)
     save("action_ids.npz", actions=acts, action_ids=ids.numpy())
+
+
+def gen_manip(ns):
+    """task_type 'manipulation' (eval_inference.py:282-287, 324-331): `get_action_ids` on 3-D continuous actions — absolute
+    (get_norm_actions, the served default) and relative (get_relative_norm_actions) — `action_encode_positional`, and a tiny
+    UNet forward with a 10-channel ActionEmbedder_ (task_type='manipulation', action_input_channel=10)."""
+    su = sys.modules["utils.svd_utils"]          # imported by import_reference()
+    rs = np.random.RandomState(17)
+    B, T = 3, 14
+    acts = np.zeros((B, T, 8), dtype=np.float32)
+    lo, hi = np.array([-0.3, -0.5, 0.6]), np.array([0.7, 0.5, 1.6])
+    acts[..., :3] = lo + (hi - lo) * rs.uniform(-0.1, 1.1, size=(B, T, 3))       # a few positions outside the workspace: clipped
+    acts[..., 3:7] = rs.standard_normal((B, T, 4)) * rs.uniform(0.5, 2.0, size=(B, T, 1))   # un-normalised quaternions
+    acts[..., 7] = rs.choice([0.0, 1.0, 0.3, 1.4, -0.2], size=(B, T))
+    ta = torch.from_numpy(acts)
+    ids_abs = ns.get_action_ids(B, ta, "micro_cond", torch.float32)
+    ids_rel = ns.get_action_ids(B, ta, "micro_cond", torch.float32, use_absolute_pose=False)
+    pos = su.action_encode_positional(B, ids_abs)
+    cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), num_attention_heads=(1, 2, 2, 2), num_frames=4,
+                     action_input_channel=10, task_type="manipulation")
+    m = ns.UNet(block_out_channels=cfg.block_out_channels, num_attention_heads=cfg.num_attention_heads, num_frames=4,
+                action_strategy="micro_cond", task_type="manipulation", action_input_channel=10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in random_state_dict(cfg, 6).items()}, strict=True)
+    m.eval()
+    sample, ehs, tids, _ = unet_inputs(cfg, 1, 16, 32, seed=41)
+    aid = ids_abs[:1, :4]
+    with torch.no_grad():
+        out = m(torch.from_numpy(sample), torch.tensor(1.0640485), torch.from_numpy(ehs), torch.from_numpy(tids),
+                return_dict=False, added_action_ids=aid)[0]
+    save("manip_actions.npz", actions=acts, action_ids_abs=ids_abs.numpy(), action_ids_rel=ids_rel.numpy(),
+         action_ids_positional=pos.numpy(), unet_weight_seed=np.array(6), unet_timestep=np.array(1.0640485, dtype=np.float32),
+         unet_sample=sample, unet_ehs=ehs, unet_added_time_ids=tids, unet_action_ids=aid.numpy(), unet_out=out.numpy())
 
 
 def gen_noise_rotation(ns):
@@ -526,7 +560,7 @@ def main():
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
                 pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
-                pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0)
+                pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0, manip=gen_manip)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

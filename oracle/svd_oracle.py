@@ -338,6 +338,60 @@ def action_ids_idx_encode(actions: np.ndarray) -> np.ndarray:
     return out
 
 
+# ---- manipulation actions (utils/svd_utils.py:357-567), restated row by row as the reference loops over them
+_SCENE_BOUNDS = np.array([-0.3, -0.5, 0.6, 0.7, 0.5, 1.6])     # utils/svd_utils.py:15
+
+
+def quaternion_to_rotmatrix(q) -> np.ndarray:
+    """scipy Rotation.from_quat((x, y, z, w)).as_matrix() (utils/svd_utils.py:357-375): normalise, then the textbook matrix."""
+    x, y, z, w = (np.asarray(q, dtype=np.float64) / np.linalg.norm(np.asarray(q, dtype=np.float64)))
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def normalize_action(rel_xyz, rel_r6, gripper, low=-2 * np.pi, high=2 * np.pi):
+    """utils/svd_utils.py:499-539."""
+    span = _SCENE_BOUNDS[3:] - _SCENE_BOUNDS[:3]
+    xyz01 = (np.clip(np.asarray(rel_xyz) / np.maximum(span, 1e-8), -1.0, 1.0) + 1.0) * 0.5
+    r601 = (np.clip(rel_r6, -1.0, 1.0) + 1.0) * 0.5
+    g01 = np.clip(gripper, 0.0, 1.0)
+    return xyz01 * (high - low) + low, r601 * (high / 2 - low / 2) + low / 2, g01 * (high / 2 - low / 2) + low / 2
+
+
+def manip_action_ids(actions: np.ndarray, absolute: bool = True) -> np.ndarray:
+    """get_action_ids for 3-D actions (utils/svd_utils.py:544-567): get_norm_actions (:418-457) / get_relative_norm_actions
+    (:459-497) per batch item; (B, T, 8) -> (B, T, 10) float32."""
+    acts = np.asarray(actions, dtype=np.float32).astype(np.float64)
+    out = []
+    center = 0.5 * (_SCENE_BOUNDS[:3] + _SCENE_BOUNDS[3:])
+    for a in acts:
+        xyz, grip = a[:, :3], a[:, 7]
+        R = np.stack([quaternion_to_rotmatrix(q) for q in a[:, 3:7]])
+        rows = np.zeros((a.shape[0], 10))
+        for i in range(a.shape[0]):
+            if absolute:
+                nx, nr, ng = normalize_action(2.0 * (xyz[i] - center), R[i][:, :2].reshape(6), grip[i])
+            elif i == 0:
+                continue
+            else:
+                rel = R[i - 1].T @ (xyz[i] - xyz[i - 1])
+                nx, nr, ng = normalize_action(rel, (R[i - 1].T @ R[i])[:, :2].reshape(6), grip[i])
+            rows[i] = np.concatenate([nx, nr, [ng]])
+        out.append(rows)
+    return np.stack(out).astype(np.float32)
+
+
+def action_encode_positional(ids: np.ndarray) -> np.ndarray:
+    """utils/svd_utils.py:570-592: (B, T, L) -> (B, T, T + L - 1)."""
+    B, T, L = ids.shape
+    out = np.zeros((B, T, T + L - 1), dtype=np.float32)
+    for b in range(B):
+        for i in range(T):
+            out[b, i, i:i + L] = ids[b, i]
+    return out
+
+
 def decode_action_seq_frames(action_ids: np.ndarray) -> np.ndarray:
     """pipeline:826-844: the diagonal."""
     return np.diagonal(np.asarray(action_ids), axis1=-2, axis2=-1)
@@ -373,15 +427,24 @@ def denoise(sd: SD, cfg: Optional[dict], image_latents: torch.Tensor, image_embe
     image_latents (B,4,h,w): VAE mode() of the noisy cond image (cond half; uncond half is zeros,
     pipeline:244-250).  image_embeddings (B,1,Dctx): CLIP embeds (uncond half zeros, :221-227).
     noise (B,T,4,h,w): unit Gaussian draw BEFORE rotation and init_noise_sigma scaling.
-    actions (B,T) int.  Returns latents (B,T,4,h,w) fp32.
+    actions (B,T) int, or (B,T,8) float for manipulation.  Returns latents (B,T,4,h,w) fp32.
     """
     cfg = _cfg(cfg)
     T = cfg["num_frames"]
     B = noise.shape[0]
     sig = karras_sigmas(num_steps)
     ts = sigma_to_timestep(sig)
-    act_ids = torch.from_numpy(action_ids_idx_encode(actions))
-    lat = rotate_latent_noise(noise.float(), decode_action_seq_frames(act_ids.numpy())) * init_noise_sigma(sig)
+    if np.asarray(actions).ndim == 3:    # manipulation: continuous (B, T, 8) rows (eval_inference.py:324-331)
+        ids = manip_action_ids(actions)
+        if cfg.get("action_input_channel") == T + ids.shape[-1] - 1 and cfg.get("action_input_channel") != ids.shape[-1]:
+            ids = action_encode_positional(ids)
+        act_ids = torch.from_numpy(ids)
+    else:
+        act_ids = torch.from_numpy(action_ids_idx_encode(actions))
+    lat = noise.float()
+    if cfg.get("task_type", "navigation") == "navigation":     # pipeline:352-356: the rotation is navigation-only
+        lat = rotate_latent_noise(lat, decode_action_seq_frames(act_ids.numpy()))
+    lat = lat * init_noise_sigma(sig)
     g = torch.linspace(min_guidance, max_guidance, T).reshape(1, T, 1, 1, 1)  # pipeline:576-581
     tid = torch.tensor([[fps - 1, motion_bucket_id, noise_aug_strength]], dtype=torch.float32)  # pipeline:518, 254-280
     traj = []

@@ -81,7 +81,7 @@ def arg_parser():
 
 def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) -> SVDWorker:
     """cfg / vae_cfg / clip: overrides for tests (reduced-width checkpoints); the served geometry by default."""
-    cfg = cfg or UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel)
+    cfg = cfg or UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel, task_type=args.task_type)
     vae_cfg = vae_cfg or {}
     if args.random_weights:
         unet_sd, vae_sd = random_state_dict(cfg, 0), FE.vae_random_state_dict(1, **vae_cfg)
@@ -112,7 +112,7 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
 
     worker = SVDWorker(denoise, fe, width=args.width, height=args.height, out_width=args.out_width,
                        out_height=args.out_height, num_frames=args.num_frames,
-                       num_inference_steps=args.num_inference_steps)
+                       num_inference_steps=args.num_inference_steps, task_type=cfg.task_type)
     worker.bind_thread = unet.hip.bind_thread     # serve_tcp handler threads start on HIP device 0
     return worker
 
@@ -132,7 +132,7 @@ def main(argv=None) -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(args.device))
         from wiw_amd.server import plumbing as P
-        sharded = ShardedWorker(build_worker(args), validate=lambda r: P.validate_request(r, args.num_frames))
+        sharded = ShardedWorker(build_worker(args), validate=lambda r: P.validate_request(r, args.num_frames, args.task_type))
         if dist.get_rank() == 0:
             if args.port <= 0:
                 ap.error("multi-GPU serving needs --port (rank 0 runs the TCP server)")

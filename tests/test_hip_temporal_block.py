@@ -67,8 +67,7 @@ def test_pack_temporal_qkv_fold_algebra():
             got = folded[:, h * 192 + j * 64: h * 192 + (j + 1) * 64]
             # the only difference is the bf16 rounding of W * gamma (2^-9 relative per weight)
             assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
-    # 128 bytes of 16-bit ones (the statistics operand row of the kernel), then zeros
-    assert bool((fold.view(torch.int32)[:, 384:416] == 0x3F803F80).all()) and float(fold[:, 416:].abs().max()) == 0.0
+    assert float(fold[:, 384:].abs().max()) == 0.0
     # the fp16 build packs the same operands in its own 16-bit type (libwiwsvd_f16.so); the tiling is a pure
     # permutation of 16-bit words, so it is dtype-blind
     wg16, fold16 = pack_temporal_qkv(wq, wk, wv, gamma, beta, tiled=False, dtype=torch.float16)

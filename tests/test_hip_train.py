@@ -849,3 +849,64 @@ def test_trainer_with_sharded_adamw_over_rccl_single_rank(golden):
         assert diff == 0.0, diff
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fit_runs_validation_rollouts_like_the_reference_loop(golden, tmp_path):
+    """`Trainer.fit`: the outer loop of train_svd.py:844-1062 — validation at step 1 and every `validation_steps` (:995-1001)
+    through the INFERENCE loop on the EMA weights (:1004-1007; the live ones come back), checkpoints every `checkpointing_steps`,
+    one log record per optimiser step.  The validation numbers are the oracle's: the same rollout on the same (EMA) weights."""
+    import json
+
+    import svd_oracle as O
+    import wiw_amd  # noqa: F401
+    from wiw_amd import train as T
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.train_unet import Trainer, UNetTrain
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("train_step_tiny.npz")
+    cfg = UNetConfig.tiny(4)
+    hip = Hip(torch.device(DEV))
+    sd = random_state_dict(cfg, int(g["weight_seed"]))
+    st = T.prepare_step(torch.from_numpy(g["latents"]), torch.from_numpy(g["noise"]), float(g["sigmas"][0]),
+                        torch.from_numpy(g["conditional_latents"]), torch.from_numpy(g["encoder_hidden_states"]),
+                        float(g["noise_aug_strength"]), torch.from_numpy(g["action_ids"]))
+    rs = np.random.RandomState(3)
+    h, w = g["latents"].shape[-2:]
+    val = [dict(image_latents=torch.from_numpy(rs.standard_normal((1, 4, h, w)).astype(np.float32)),
+                image_embeddings=torch.from_numpy(rs.standard_normal((1, 1, cfg.cross_attention_dim)).astype(np.float32)),
+                noise=torch.from_numpy(rs.standard_normal((1, 4, 4, h, w)).astype(np.float32)),
+                actions=np.array([[4, 1, 2, 3]]),
+                target_latents=torch.from_numpy(rs.standard_normal((1, 4, 4, h, w)).astype(np.float32))) for _ in range(2)]
+    tr = Trainer(UNetTrain(cfg, sd, DEV, hip=hip), lr=1e-3, use_ema=True)
+    log_path = str(tmp_path / "log.jsonl")
+    log = tr.fit([st] * 10, max_train_steps=4, validation_steps=3, val_samples=val, checkpointing_steps=2,
+                 output_dir=str(tmp_path), log_path=log_path, val_kwargs=dict(num_steps=2))
+    steps = [r["step"] for r in log if "train_loss" in r]
+    vals = [r for r in log if "latent_mse" in r]
+    assert steps == [1, 2, 3, 4] and [v["global_step"] for v in vals] == [1, 3] and all(v["weights"] == "ema" for v in vals)
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint-2", "checkpoint-4", "log.jsonl"]
+    with open(log_path) as f:
+        assert [json.loads(x) for x in f] == log
+    # the live weights came back after validation: one more step equals an un-validated run's fifth step
+    ref = Trainer(UNetTrain(cfg, sd, DEV, hip=hip), lr=1e-3, use_ema=True)
+    for _ in range(5):
+        ref.step(st)
+    tr.step(st)
+    assert all(torch.equal(tr.net.master[k], ref.net.master[k]) for k in sd)
+    # the numbers: the oracle's rollout on the EMA weights of step 3 is what validate() measured (bf16-class tolerance)
+    chk = Trainer(UNetTrain(cfg, sd, DEV, hip=hip), lr=1e-3, use_ema=True)
+    for _ in range(3):
+        chk.step(st)
+    ema_sd = {k: v.cpu() for k, v in chk.ema.shadow.items()}
+    se = n = 0.0
+    with torch.no_grad():
+        for s in val:
+            lat = O.denoise(ema_sd, cfg.as_dict(), s["image_latents"], s["image_embeddings"], s["noise"], s["actions"], num_steps=2)
+            d = (lat - s["target_latents"]).double()
+            se += float(d.pow(2).sum()); n += d.numel()
+    got, want = vals[1]["latent_mse"], se / n
+    print(f"[f2] validation rollout latent_mse: HIP {got:.6e} vs oracle on the same EMA weights {want:.6e}")
+    assert abs(got - want) <= 2e-2 * want

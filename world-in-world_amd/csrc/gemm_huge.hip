@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 const int n = m / HW, rem = m - n * HW;
                 a_y[i] = rem / p.Wd;
                 a_x[i] = rem - a_y[i] * p.Wd;
-                a_fb[i] = (MODE == WIW_A_CONV3X3) ? n * HW
+                a_fb[i] = (MODE == WIW_A_CONV3X3) ? 0      // unused: the tap row is a_m + dy * Wd + dx
                           : ((MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) ? n * HW * 4 : n * (HW >> 2));
             } else if (MODE == WIW_A_CONV_T3) {
                 a_y[i] = (m / HW) % p.T;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             if (MODE == WIW_A_CONV3X3) {
                 const int iy = a_y[i] + dy, ix = a_x[i] + dx;
                 ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                row = a_fb[i] + iy * p.Wd + ix;
+                row = a_m[i] + dy * p.Wd + dx;     // = frame base + iy * Wd + ix: no per-row frame base to keep live
             } else if (MODE == WIW_A_CONV3X3_S2 || MODE == WIW_A_CONV3X3_S2P) {
                 constexpr int o = (MODE == WIW_A_CONV3X3_S2P) ? 1 : 0;
                 const int iy = 2 * a_y[i] + dy + o, ix = 2 * a_x[i] + dx + o;

@@ -41,14 +41,22 @@
 #ifndef WIW_T_MFMA_STATS
 #define WIW_T_MFMA_STATS 1   // 1: LayerNorm row statistics on the MATRIX pipe (round 4); 0: 16 v_dot2c per k-step (round 3, A/B)
 #endif
-// Row statistics on the matrix pipe.  Frame slot 15 of every site is padding (T <= 14), so the lanes that hold fragment row 15
-// fetch 16-bit ONES instead of a frame (128 bytes of ones sit in the pad of the head's fold vector, `fold[h][384..415]`, put
-// there by the host).  ONE extra MFMA per site and k-step, G = A . A^T, then accumulates both moments of every real row m:
-//     G[m][m]  = sum_k x[m][k]^2          (lane frow = m, fq = m >> 2, register m & 3)
-//     G[15][m] = sum_k 1 * x[m][k]        (lane frow = m, fq = 3,      register 3)
+// Row statistics on the matrix pipe: two extra MFMAs per site and k-step on operands the wave holds anyway,
+//     S = ONES . A^T  ->  every register of lane (frow = m, *) accumulates  sum_k x[m][k]          (ONES: a constant fragment)
+//     G = A . A^T     ->  lane (frow = m, fq = m >> 2), register m & 3 accumulates  sum_k x[m][k]^2  (the diagonal)
 // exact fp32 sums of exact products, as v_dot2c gave — and no VALU instruction in the main loop: round 3's ablation priced
 // the 16 v_dot2c per k-step at 45 of the resident form's 283 us (a VALU stream next to a streaming MFMA partner gets one
-// issue per MFMA; the matrix pipe takes the two extra MFMAs per k-step for +8 % of its own time).
+// issue per MFMA; the matrix pipe takes the four extra MFMAs per k-step for +17 % of its own time).
+// (A first form took both moments from ONE MFMA per site by making fragment row 15 — a padding frame slot — a row of ones,
+// with the loads of those lanes masked out through EXEC so that their registers kept the ones: hipcc re-shuffles such
+// loop-carried "+v" registers with v_mov WHILE the asm loads are in flight — stale copies and loads landing in re-assigned
+// registers, a memory fault on the GPU.  tools/experiments/temporal_ones_row.txt.)
+#ifndef WIW_T_RES_S1_MFMA
+#define WIW_T_RES_S1_MFMA 0   // resident form (256-register limit): 1 = also the plain row sums S on the matrix pipe (the ones
+                              // fragment + its accumulators cost 12 registers: 32 bytes of scratch per lane, reloaded every K
+                              // tile); 0 = S stays on v_dot2c — 8 VALU instructions per k-step instead of 16 — and only G, the
+                              // sums of squares, moves to the matrix pipe
+#endif
 #ifndef WIW_T_EPI
 #define WIW_T_EPI 1       // 1: LayerNorm fold / output scaling of the epilogue on packed fp32 pairs (0: scalar FMAs, round 2)
 #endif
@@ -261,7 +269,7 @@ WIW_DEV void attention_epilogue(f32x4 (&acc)[2][NF], const float (&sum1)[2], con
 
 // Row moments out of the Gram accumulators (WIW_T_MFMA_STATS): per-lane PARTIALS in the form attention_epilogue reduces (it
 // sums over the four fq lanes of a row) — the lane that holds the moment contributes it, the others zero.
-WIW_DEV void stats_from_gram(const f32x4 (&g)[2], float (&sum1)[2], float (&sum2)[2], int lane) {
+WIW_DEV void stats_from_gram(const f32x4 (&s1)[2], const f32x4 (&g)[2], float (&sum1)[2], float (&sum2)[2], int lane) {
     asm volatile("" : "+v"(lane));
     const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -269,8 +277,23 @@ WIW_DEV void stats_from_gram(const f32x4 (&g)[2], float (&sum1)[2], float (&sum2
         const int r = frow & 3;
         const float d = r == 0 ? g[mi][0] : (r == 1 ? g[mi][1] : (r == 2 ? g[mi][2] : g[mi][3]));
         sum2[mi] = fq == (frow >> 2) ? d : 0.f;
-        sum1[mi] = fq == 3 ? g[mi][3] : 0.f;
+        sum1[mi] = fq == 0 ? s1[mi][0] : 0.f;
     }
+}
+WIW_DEV void sq_from_gram(const f32x4 (&g)[2], float (&sum2)[2], int lane) {
+    asm volatile("" : "+v"(lane));
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = frow & 3;
+        const float d = r == 0 ? g[mi][0] : (r == 1 ? g[mi][1] : (r == 2 ? g[mi][2] : g[mi][3]));
+        sum2[mi] = fq == (frow >> 2) ? d : 0.f;
+    }
+}
+WIW_DEV bf16x8 ones_fragment() {
+    union { uint32_t u[4]; bf16x8 v; } one;
+    one.u[0] = one.u[1] = one.u[2] = one.u[3] = WIW_ONE16 * 0x10001u;
+    return one.v;
 }
 
 // ---- RING form (any C; used for C > 320): A and W tiles through a 3-stage LDS ring, two wave groups one slot apart.
@@ -395,13 +418,8 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         a_off[mi] = rho * 128 + ((fq ^ (rho & 7)) << 4);        // k-step 0; k-step 1 flips bit 2 of the chunk: ^ 64
     }
 #if WIW_T_MFMA_STATS
-    // fragment row 15 = the ones row: 128 bytes in the pad of fold buffer 0 (absolute LDS address; the DMA that refills that
-    // buffer for every other item rewrites the same bytes).
-    const int ones_off = (int)(scratch - smem) + 2 * W_ROWS * 4 + (fq << 4);
-    const int st_mul = frow == 15 ? 0 : STAGE_BYTES;      // the ones row does not move with the ring stage
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) a_off[mi] = frow == 15 ? ones_off : a_off[mi];
-    f32x4 acc_s[2];
+    f32x4 acc_s1[2], acc_s2[2];
+    const bf16x8 ones = ones_fragment();
 #endif
     const int w_off = frow * 128 + ((fq ^ (frow & 7)) << 4);
 
@@ -411,14 +429,8 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
     auto read_frags = [&](int stage, int kk) {
         const char* sA = smem + stage * STAGE_BYTES;
         const char* sW = sA + A_BYTES;
-#if WIW_T_MFMA_STATS
-        const int so = stage * st_mul;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) fa[mi] = *(const bf16x8*)(smem + ((a_off[mi] + so) ^ (kk << 6)));
-#else
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) fa[mi] = *(const bf16x8*)(sA + (a_off[mi] ^ (kk << 6)));
-#endif
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) fb[ni] = *(const bf16x8*)(sW + ni * 2048 + (w_off ^ (kk << 6)));
     };
@@ -436,7 +448,10 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
                 acc[mi][ni] = WIW_MFMA(fa[mi], fb[ni], acc[mi][ni]);
 #if WIW_T_MFMA_STATS
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) acc_s[mi] = WIW_MFMA(fa[mi], fa[mi], acc_s[mi]);   // both row moments (see the top of the file)
+        for (int mi = 0; mi < 2; ++mi) {          // the two row moments (see the top of the file)
+            acc_s1[mi] = WIW_MFMA(ones, fa[mi], acc_s1[mi]);
+            acc_s2[mi] = WIW_MFMA(fa[mi], fa[mi], acc_s2[mi]);
+        }
         __builtin_amdgcn_s_setprio(0);
         return;
 #endif
@@ -494,7 +509,8 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         for (int mi = 0; mi < 2; ++mi) {
             sum1[mi] = 0.f; sum2[mi] = 0.f;
 #if WIW_T_MFMA_STATS
-            acc_s[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_s1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_s2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_kernel(const Tempor
         st_e = st_e >= STAGES ? st_e - STAGES : st_e;
 
 #if WIW_T_MFMA_STATS
-        stats_from_gram(acc_s, sum1, sum2, lane);
+        stats_from_gram(acc_s1, acc_s2, sum1, sum2, lane);
 #endif
         // ---- epilogue (per wave, no block barrier); O staging in the ring stage nobody reads or fills now
         attention_epilogue<TP>(acc, sum1, sum2, (const float*)(scratch + parity * SCR_BYTES),
@@ -642,34 +658,21 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const uint32_t vo = o[mi] + (uint32_t)(kt * (BK * 2));
-#if WIW_T_MFMA_STATS
-            // the lanes of fragment row 15 (lanes 15, 31, 47, 63) are masked out of the loads: their registers keep the 16-bit
-            // ONES they were initialised with ("+v": the old contents are an input)
-            uint64_t keep;
-            asm volatile("s_mov_b64 %2, exec\n\ts_andn2_b64 exec, exec, %5\n\tglobal_load_dwordx4 %0, %3, %4\n\t"
-                         "global_load_dwordx4 %1, %3, %4 offset:64\n\ts_mov_b64 exec, %2"
-                         : "+v"(dst[0][mi]), "+v"(dst[1][mi]), "=&s"(keep) : "v"(vo), "s"(xb), "s"(0x8000800080008000ull) : "memory");
-#else
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[0][mi]) : "v"(vo), "s"(xb) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(dst[1][mi]) : "v"(vo), "s"(xb) : "memory");
-#endif
         }
     };
 #if WIW_T_MFMA_STATS
-    f32x4 acc_s[2];
+    f32x4 acc_s2[2];
+#if WIW_T_RES_S1_MFMA
+    f32x4 acc_s1[2];
+    const bf16x8 ones = ones_fragment();
+#endif
 #endif
 
     const int w_off = frow * 128 + ((fq ^ (frow & 7)) << 4);
     f32x4 acc[2][NF];
     bf16x8 fa[2][2][2];   // [buffer][k-step][site]
-#if WIW_T_MFMA_STATS
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        union { uint32_t u[4]; bf16x8 v; } one;
-        one.u[0] = one.u[1] = one.u[2] = one.u[3] = WIW_ONE16 * 0x10001u;
-        fa[i >> 2][(i >> 1) & 1][i & 1] = one.v;
-    }
-#endif
     bf16x8 fb[NF];
     float sum1[2], sum2[2];
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -701,7 +704,23 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
             }
         }
 #if WIW_T_MFMA_STATS && !(WIW_T_ABLATE & 8)
-        acc_s[hf] = WIW_MFMA(a[hf], a[hf], acc_s[hf]);   // both row moments of site hf (see the top of the file)
+        acc_s2[hf] = WIW_MFMA(a[hf], a[hf], acc_s2[hf]);   // row sums of squares of site hf: the diagonal of A . A^T
+#if WIW_T_RES_S1_MFMA
+        acc_s1[hf] = WIW_MFMA(ones, a[hf], acc_s1[hf]);
+#else
+        {
+            union { bf16x8 v; uint32_t u[4]; } x;
+            x.v = a[hf];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum1[hf] = dot2_acc(x.u[j], WIW_ONE16 * 0x10001u, sum1[hf]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // 1 VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        }
+#endif
 #elif !(WIW_T_ABLATE & 8)
         union { bf16x8 v; uint32_t u[4]; } x;
         x.v = a[hf];
@@ -740,7 +759,10 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
         for (int mi = 0; mi < 2; ++mi) {
             sum1[mi] = 0.f; sum2[mi] = 0.f;
 #if WIW_T_MFMA_STATS
-            acc_s[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if WIW_T_RES_S1_MFMA
+            acc_s1[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+            acc_s2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
 #pragma unroll
             for (int ni = 0; ni < NF; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -787,7 +809,11 @@ __global__ __launch_bounds__(NW * 64, 2) void temporal_block_resident_kernel(con
 #else
         const int b_cur = mt / p.tiles_per_batch, s0_cur = (mt - b_cur * p.tiles_per_batch) * 16;
 #if WIW_T_MFMA_STATS
-        stats_from_gram(acc_s, sum1, sum2, lane);
+#if WIW_T_RES_S1_MFMA
+        stats_from_gram(acc_s1, acc_s2, sum1, sum2, lane);
+#else
+        sq_from_gram(acc_s2, sum2, lane);           // sum1 already holds the lanes' v_dot2c partials
+#endif
 #endif
         attention_epilogue<TP>(acc, sum1, sum2, fs, ostage + wave * STG_WAVE, p, b_cur, s0_cur, h, wave, lane);
 #endif

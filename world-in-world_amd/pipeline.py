@@ -53,6 +53,67 @@ def action_ids_idx_encode(actions: np.ndarray) -> np.ndarray:
     return a[:, None, :] * tri[None]
 
 
+# ---- manipulation actions (task_type 'manipulation', the reference's second served task: FTsvd/eval_inference.py:282-287,
+# 313-349; the manipulation planner speaks the same protocol, world-in-world-manip/wiw_manip/planner/igenex_planner.py:154-191)
+SCENE_BOUNDS = np.array([-0.3, -0.5, 0.6, 0.7, 0.5, 1.6])      # utils/svd_utils.py:15  (xmin, ymin, zmin, xmax, ymax, zmax)
+
+
+def quaternion_to_rotmatrix(quat: np.ndarray) -> np.ndarray:
+    """`scipy.spatial.transform.Rotation.from_quat(q).as_matrix()` for q = (x, y, z, w), any norm (utils/svd_utils.py:357-375):
+    (..., 4) -> (..., 3, 3), float64."""
+    q = np.asarray(quat, dtype=np.float64)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3), dtype=np.float64)
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z); R[..., 0, 1] = 2 * (x * y - z * w); R[..., 0, 2] = 2 * (x * z + y * w)
+    R[..., 1, 0] = 2 * (x * y + z * w); R[..., 1, 1] = 1 - 2 * (x * x + z * z); R[..., 1, 2] = 2 * (y * z - x * w)
+    R[..., 2, 0] = 2 * (x * z - y * w); R[..., 2, 1] = 2 * (y * z + x * w); R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def _normalize_action(rel_xyz, r6, grip, low=-2 * np.pi, high=2 * np.pi):
+    """`normalize_action` (utils/svd_utils.py:499-539): xyz / span -> [low, high]; r6 and gripper -> [low / 2, high / 2]."""
+    span = SCENE_BOUNDS[3:] - SCENE_BOUNDS[:3]
+    xyz01 = (np.clip(rel_xyz / np.maximum(span, 1e-8), -1.0, 1.0) + 1.0) * 0.5
+    r601 = (np.clip(r6, -1.0, 1.0) + 1.0) * 0.5
+    g01 = np.clip(grip, 0.0, 1.0)
+    return xyz01 * (high - low) + low, r601 * (high / 2 - low / 2) + low / 2, g01 * (high / 2 - low / 2) + low / 2
+
+
+def manip_action_ids(actions: np.ndarray, absolute: bool = True) -> np.ndarray:
+    """`get_action_ids(..., 'micro_cond')` for 3-D continuous actions (utils/svd_utils.py:544-567 with get_norm_actions
+    :418-457, or get_relative_norm_actions :459-497 when `absolute` is False): (B, T, 8) rows
+    [x, y, z, qx, qy, qz, qw, gripper] -> (B, T, 10) float32 rows [norm_xyz (3) | r6 = first two COLUMNS of the rotation
+    matrix, row-major (6) | norm_grip]."""
+    a = np.asarray(actions, dtype=np.float32).astype(np.float64)      # torch.tensor(b_action, dtype=float32), then numpy float
+    assert a.ndim == 3 and a.shape[-1] == 8, f"manipulation b_action must be (b, T, 8), got {a.shape}"
+    xyz, R, grip = a[..., :3], quaternion_to_rotmatrix(a[..., 3:7]), a[..., 7]
+    out = np.zeros(a.shape[:2] + (10,), dtype=np.float64)
+    if absolute:
+        center = 0.5 * (SCENE_BOUNDS[:3] + SCENE_BOUNDS[3:])
+        nx, nr, ng = _normalize_action(2.0 * (xyz - center), R[..., :, :2].reshape(a.shape[:2] + (6,)), grip)
+        out[..., :3], out[..., 3:9], out[..., 9] = nx, nr, ng
+    else:                                        # row 0 stays zero: no previous frame
+        Rt = np.swapaxes(R[:, :-1], -1, -2)
+        rel_xyz = np.einsum("bnij,bnj->bni", Rt, xyz[:, 1:] - xyz[:, :-1])
+        rel_R = np.einsum("bnij,bnjk->bnik", Rt, R[:, 1:])
+        nx, nr, ng = _normalize_action(rel_xyz, rel_R[..., :, :2].reshape(a.shape[0], a.shape[1] - 1, 6), grip[:, 1:])
+        out[:, 1:, :3], out[:, 1:, 3:9], out[:, 1:, 9] = nx, nr, ng
+    return out.astype(np.float32)
+
+
+def action_encode_positional(ids: np.ndarray) -> np.ndarray:
+    """`action_encode_positional` (utils/svd_utils.py:570-592): (B, T, L) -> (B, T, T + L - 1), frame i's L values at
+    columns i .. i + L - 1 — the 23-channel form of a 10-channel manipulation action at T = 14 (the reference's
+    `--action_input_channel` help, eval_inference.py:286-287; its call is commented out at :562, so a checkpoint decides)."""
+    ids = np.asarray(ids, dtype=np.float32)
+    B, T, L = ids.shape
+    out = np.zeros((B, T, T + L - 1), dtype=np.float32)
+    for i in range(T):
+        out[:, i, i:i + L] = ids[:, i]
+    return out
+
+
 def rotate_latent_noise(noise: torch.Tensor, actions: np.ndarray) -> torch.Tensor:
     """`sample_latent_noise` after its randn draw (pipeline:750-786): a turn at frame i makes frame i a
     +-W/16 cyclic shift of frame i-1 (22.5 degrees of the panorama)."""
@@ -138,17 +199,29 @@ class SVDDenoiser:
                 callback=None) -> torch.Tensor:
         """image_latents (B,4,h,w): VAE mode() of the noise-augmented conditioning image;
         image_embeddings (B,1,D): CLIP image embeds; noise (B,T,4,h,w): unit Gaussian draw (before the
-        action rotation and init_noise_sigma); actions (B,T) ints.  Returns latents (B,T,4,h,w) fp32.
+        action rotation and init_noise_sigma); actions: (B,T) navigation ids, or — as in the reference, decided by the
+        rank of the array (eval_inference.py:324-331) — (B,T,8) continuous manipulation actions
+        [x,y,z,qx,qy,qz,qw,gripper].  Returns latents (B,T,4,h,w) fp32.
         fps / motion_bucket_id are accepted for API parity: `aug_emb` is dead for micro_cond (unet:482)."""
         cfg = self.unet.cfg
         B, T, _, h, w = noise.shape
         assert T == cfg.num_frames and image_latents.shape == (B, 4, h, w)
         sig = karras_sigmas(num_steps, self.sched)
         ts = sigma_to_timestep(sig)
-        act_ids = action_ids_idx_encode(actions)
-        decoded = np.diagonal(act_ids, axis1=-2, axis2=-1)  # decode_action_seq_frames (pipeline:826-844)
-        lat = rotate_latent_noise(noise.to(self.device, torch.float32), decoded) * init_noise_sigma(sig)
-        lat = lat.contiguous()
+        lat = noise.to(self.device, torch.float32)
+        if np.asarray(actions).ndim == 3:      # manipulation: 10 channels, or their 23-channel positional form
+            act_ids = manip_action_ids(actions)
+            if cfg.action_input_channel == T + act_ids.shape[-1] - 1 and cfg.action_input_channel != act_ids.shape[-1]:
+                act_ids = action_encode_positional(act_ids)
+        else:
+            act_ids = action_ids_idx_encode(actions)
+        if act_ids.shape[-1] != cfg.action_input_channel:
+            raise ValueError(f"action ids have {act_ids.shape[-1]} channels, the UNet embeds {cfg.action_input_channel} "
+                             f"(--action_input_channel: 14 navigation, 10 / 23 manipulation)")
+        if cfg.task_type == "navigation":      # the panorama rotation of the initial noise is navigation-only (pipeline:352-356)
+            decoded = np.diagonal(act_ids, axis1=-2, axis2=-1)  # decode_action_seq_frames (pipeline:826-844)
+            lat = rotate_latent_noise(lat, decoded)
+        lat = (lat * init_noise_sigma(sig)).contiguous()
         img = image_latents.to(self.device, torch.float32).contiguous()
         cond = self.unet.prepare_request(image_embeddings, act_ids, noise_aug_strength)
         hw = h * w

@@ -40,15 +40,26 @@ def check_inputdict(d: dict) -> None:
             assert isinstance(v, list) and all(isinstance(s, bool) for s in v), "return_objects should be list[bool]"
 
 
-def validate_request(d: dict, num_frames: int) -> None:
+def check_b_action(b_action, num_frames: int, task_type: str = "navigation") -> np.ndarray:
+    """Shape facts of `b_action` the reference worker assumes (eval_inference.py:313-331): (b, T) action ids for
+    navigation, (b, T, 8) continuous [x, y, z, qx, qy, qz, qw, gripper] rows for manipulation (utils/svd_utils.py:377-409)."""
+    b_action = np.asarray(b_action)
+    if task_type == "manipulation":
+        assert b_action.ndim == 3 and b_action.shape[1:] == (num_frames, 8), \
+            f"manipulation b_action must be (b, {num_frames}, 8), got {b_action.shape}"
+    else:
+        assert b_action.ndim == 2 and b_action.shape[1] == num_frames, \
+            f"navigation b_action must be (b, {num_frames}), got {b_action.shape}"
+    return b_action
+
+
+def validate_request(d: dict, num_frames: int, task_type: str = "navigation") -> None:
     """Everything the worker would trip over, checked BEFORE compute is committed (a multi-GPU server must not hand a
     malformed request to its ranks): the reference's `check_inputdict` plus the shape facts its worker assumes
-    (b_action (b, num_frames) for navigation, eval_inference.py:313-349; one save_dir / image per candidate;
-    b_image uint8 (b, C>=3, H, W); `<save_dir>/cond_rgb.png` present when no b_image travels)."""
+    (`check_b_action`; one save_dir / image per candidate; b_image uint8 (b, C>=3, H, W); `<save_dir>/cond_rgb.png` present
+    when no b_image travels)."""
     check_inputdict(d)
-    b_action = np.asarray(d["b_action"])
-    assert b_action.ndim == 2 and b_action.shape[1] == num_frames, \
-        f"navigation b_action must be (b, {num_frames}), got {b_action.shape}"
+    b_action = check_b_action(d["b_action"], num_frames, task_type)
     b = b_action.shape[0]
     assert b > 0 and len(d["save_dirs"]) == b, "one save_dir per candidate"
     if "return_objects" in d:

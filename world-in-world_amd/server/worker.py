@@ -49,12 +49,13 @@ class Frontend(Protocol):
 class SVDWorker:
     def __init__(self, denoise_fn: Callable[..., "np.ndarray"], frontend: Frontend, *, width=1024, height=576,
                  out_width=480, out_height=480, num_frames=14, num_inference_steps=30, seed=1,
-                 world_model_name=P.WORLD_MODEL_NAME, noise_fn: Optional[Callable] = None):
+                 world_model_name=P.WORLD_MODEL_NAME, noise_fn: Optional[Callable] = None, task_type: str = "navigation"):
         self.denoise_fn = denoise_fn
         self.frontend = frontend
         self.width, self.height = width, height
         self.out_size = (out_width, out_height)
         self.num_frames = num_frames
+        self.task_type = task_type      # 'navigation': (b, T) action ids; 'manipulation': (b, T, 8) continuous actions
         self.num_inference_steps = num_inference_steps
         self.world_model_name = world_model_name
         # persistent generator: the draws of request k depend on requests 0..k-1, as in the reference
@@ -67,9 +68,7 @@ class SVDWorker:
         if self.bind_thread is not None:
             self.bind_thread()
         b_action, save_dirs, return_objects, images = P.parse_request(request, self.world_model_name)
-        b_action = np.asarray(b_action)
-        if b_action.ndim != 2 or b_action.shape[1] != self.num_frames:
-            raise AssertionError(f"navigation b_action must be (b, {self.num_frames}), got {b_action.shape}")
+        b_action = P.check_b_action(b_action, self.num_frames, self.task_type)
         B = len(images)
         x = np.stack([P.preprocess_image(im, self.width, self.height) for im in images])
         # CLIP sees the image at its ORIGINAL size (pipeline:192-199); only the VAE branch is resized (pipeline:521)
@@ -314,7 +313,9 @@ def build_arg_parser() -> argparse.ArgumentParser:
     ap.add_argument("--exp_id", type=str, default="wiw_amd")
     ap.add_argument("--num_frames", type=int, default=14)
     ap.add_argument("--num_past_obs", type=int, default=1)
-    ap.add_argument("--task_type", type=str, default="navigation", choices=["navigation"])
+    ap.add_argument("--task_type", type=str, default="navigation", choices=["navigation", "manipulation"],
+                    help="manipulation: b_action rows are [x, y, z, qx, qy, qz, qw, gripper] (b, 14, 8); pass "
+                         "--action_input_channel 10 (or 23, the positional form) as the checkpoint was trained")
     ap.add_argument("--action_strategy", type=str, default="micro_cond", choices=["micro_cond"])
     ap.add_argument("--action_input_channel", type=int, default=14)
     ap.add_argument("--device", type=str, default="cuda:0")

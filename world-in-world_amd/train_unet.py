@@ -584,7 +584,7 @@ class EMAShadow:
 
     def __init__(self, params: Dict[str, torch.Tensor], trainable=None, hip=None, decay: float = 0.9999, min_decay: float = 0.0,
                  update_after_step: int = 0, use_ema_warmup: bool = False, inv_gamma: float = 1.0, power: float = 2 / 3):
-        self.shadow = {k: v.detach().clone().to(torch.float32) for k, v in params.items()}
+        self.shadow = {k: v.detach().to(torch.float32).contiguous().clone() for k, v in params.items()}   # flat views below
         self.trainable = trainable or (lambda n: True)
         self.hip = hip
         self.decay, self.min_decay, self.update_after_step = float(decay), float(min_decay), int(update_after_step)
@@ -628,8 +628,11 @@ class EMAShadow:
         assert set(shadow) == set(self.shadow), "unet_ema parameters do not match this architecture"
         for k, v in shadow.items():
             self.shadow[k].copy_(v)
-        for k, v in state.items():
-            setattr(self, k, v)
+        from .checkpoint import EMA_STATE_KEYS
+
+        for k in EMA_STATE_KEYS:        # the EMA state only: nothing else in a config.json may overwrite an attribute
+            if k in state:
+                setattr(self, k, state[k])
 
     # validation under the averaged weights (train_svd.py:1004-1007, 1189-1191): store -> copy_to -> ... -> restore
     @torch.no_grad()
@@ -694,6 +697,11 @@ class Trainer:
         # step skipped — when a gradient comes back non-finite, doubled after `scale_growth_interval` consecutive good
         # optimiser steps (GradScaler's growth_interval = 2000), capped at 2^16; 1 for bf16 (no scaling)
         self.loss_scale = (2.0 ** 14 if net.dt == torch.float16 else 1.0) if loss_scale is None else loss_scale
+        # scaling is a property of the RUN (fp16 storage, or an explicit scale), not of the scale's current value: an fp16 run
+        # that has backed off to 1.0 keeps checking for overflow and grows again.  (GradScaler starts at 2^16 and has no cap;
+        # here 2^14 and a cap of 2^16: the gradients of this network overflow fp16 above that, so the first steps are not
+        # spent backing off.)
+        self.scaling = net.dt == torch.float16 or self.loss_scale != 1.0
         self.scale_growth_interval, self._good_steps = int(scale_growth_interval), 0
         self.opt = optimizer
         self.steps = 0
@@ -735,8 +743,14 @@ class Trainer:
         master, optim, meta = C.load_checkpoint(path, rank=self.opt.rank if sharded else 0, sharded=sharded)
         assert meta["world"] == (self.opt.world if sharded else 1), "the optimizer state was saved for another world size"
         if sharded:   # the per-rank slices only mean something under the SAME flat layout (bucket size, parameter order and set)
-            assert meta.get("opt_layout") == self.opt.layout_fingerprint(), \
-                "the sharded optimizer state was saved under another flat layout (bucket size / parameter set or order)"
+            if "opt_layout" not in meta:   # written before the fingerprint existed: the slice lengths are all that can be checked
+                import warnings
+
+                warnings.warn("checkpoint carries no optimizer layout fingerprint (older writer): checking slice lengths only")
+                assert optim["master"].numel() == self.opt.master.numel(), "optimizer slice length differs from this layout"
+            else:
+                assert meta["opt_layout"] == self.opt.layout_fingerprint(), \
+                    "the sharded optimizer state was saved under another flat layout (bucket size / parameter set or order)"
         assert set(master) == set(self.net.master), "checkpoint parameters do not match this architecture"
         for k, v in master.items():
             self.net.master[k].copy_(v)
@@ -757,6 +771,91 @@ class Trainer:
             self.ema.load(*C.load_ema(path))
         self.net.refresh()
 
+    def fit(self, batches, max_train_steps: int, validation_steps: int = 0, val_samples=None, checkpointing_steps: int = 0,
+            output_dir: Optional[str] = None, checkpoints_total_limit: Optional[int] = None, lr_schedule=None, log_path=None,
+            val_kwargs: Optional[dict] = None):
+        """The outer loop of train_svd.py:844-1062 around `step`: micro-batches from `batches` until `max_train_steps` optimiser
+        steps; after every optimiser step (`accelerator.sync_gradients`, :971) the reference's order — checkpoint every
+        `checkpointing_steps` (:986-993), validation every `validation_steps` AND at step 1 (:995-1030).  lr_schedule:
+        global_step -> lr (`train.lr_at`).  Returns the list of {"step", "loss" | validation dict} records (also appended to
+        `log_path` as JSON lines: what `accelerator.log` receives)."""
+        import json
+
+        log = []
+
+        def emit(rec):
+            log.append(rec)
+            if log_path:
+                with open(log_path, "a") as f:
+                    f.write(json.dumps(rec) + "\n")
+
+        for st in batches:
+            if self.steps >= max_train_steps:
+                break
+            if lr_schedule is not None:
+                self.lr = float(lr_schedule(self.steps))
+            before = self.steps
+            loss = self.step(st)
+            if self.steps == before:          # accumulating micro-batch, or a skipped (overflowed) window: no optimiser step
+                continue
+            emit({"step": self.steps, "train_loss": loss, "lr": self.lr})
+            if checkpointing_steps and output_dir and self.steps % checkpointing_steps == 0:
+                self.save(output_dir, checkpoints_total_limit)
+            if validation_steps and val_samples and (self.steps % validation_steps == 0 or self.steps == 1):
+                emit(self.validate(val_samples, **(val_kwargs or {})))
+        return log
+
+    @torch.no_grad()
+    def validate(self, samples, num_steps: int = 25, use_ema: Optional[bool] = None, frontend=None, log_path: Optional[str] = None,
+                 residual_fp32: bool = False) -> dict:
+        """The validation pass of the training loop (train_svd.py:996-1030 -> eval_inference :1140-1193): the INFERENCE loop on
+        the current weights — the EMA weights under `--use_ema` (:1004-1007; the live ones come back afterwards, :1189-1191) —
+        over `samples`, with the reference's knobs (fps 7, motion bucket 127, noise_aug 0.02), and its per-clip PSNR
+        (evaluation/FVD/calculate_psnr.py:6-15, `only_final`: mean over clips and frames).  FVD / LPIPS need the I3D / AlexNet
+        checkpoints the tree does not hold: not computed.
+        samples: dicts with image_latents (1,4,h,w), image_embeddings (1,1,D), noise (1,T,4,h,w), actions (1,T) and the
+        ground truth `target_latents` (1,T,4,h,w) [+ `target_frames` (1,T,3,H,W) in [0,1] when a `frontend` decodes].
+        Returns {"global_step", "latent_mse", "latent_psnr", ["psnr"], "clips"}; appended as one JSON line to `log_path`
+        (`accelerator.log(log_dict, step=global_step)`)."""
+        import json
+        import math
+
+        from .pipeline import SVDDenoiser
+        from .unet import UNetHIP
+
+        use_ema = (self.ema is not None) if use_ema is None else use_ema
+        assert not use_ema or self.ema is not None, "validate(use_ema=True) needs Trainer(use_ema=True)"
+        weights = self.ema.shadow if use_ema else self.net.master
+        unet = UNetHIP(self.net.cfg, weights, self.net.device, hip=self.net.hip, residual_fp32=residual_fp32)
+        den = SVDDenoiser(unet, use_graph=False)
+        se, n, psnrs, lat_psnrs = 0.0, 0, [], []
+        for s in samples:
+            lat = den.denoise(s["image_latents"], s["image_embeddings"], s["noise"], s["actions"], num_steps=num_steps, fps=7,
+                              motion_bucket_id=127, noise_aug_strength=0.02)
+            tgt = torch.as_tensor(s["target_latents"]).to(lat.device, torch.float32)
+            d = (lat - tgt).double()
+            se += float(d.pow(2).sum()); n += d.numel()
+            rng = float(tgt.max() - tgt.min()) or 1.0
+            mse = float(d.pow(2).mean())
+            lat_psnrs.append(100.0 if mse < 1e-10 else 20 * math.log10(rng / math.sqrt(mse)))
+            if frontend is not None and "target_frames" in s:
+                fr = torch.as_tensor(frontend.decode(lat.cpu().numpy() if not hasattr(frontend, "decode_frames") else lat))
+                fr = (fr.float().cpu() / 2 + 0.5).clamp(0, 1)                    # postprocess_video (video_processor.py:90-113)
+                gt = torch.as_tensor(s["target_frames"]).float().cpu()
+                for a, b in zip(fr.reshape(-1, *fr.shape[-3:]), gt.reshape(-1, *gt.shape[-3:])):
+                    m = float((a - b).pow(2).mean())
+                    psnrs.append(100.0 if m < 1e-10 else 20 * math.log10(1.0 / math.sqrt(m)))
+        out = {"global_step": self.steps, "clips": len(lat_psnrs), "weights": "ema" if use_ema else "live",
+               "latent_mse": se / max(n, 1), "latent_psnr": float(sum(lat_psnrs) / max(len(lat_psnrs), 1))}
+        if psnrs:
+            out["psnr"] = float(sum(psnrs) / len(psnrs))
+        if log_path:
+            with open(log_path, "a") as f:
+                f.write(json.dumps(out) + "\n")
+        del den, unet
+        torch.cuda.empty_cache()
+        return out
+
     def _mean_grad(self, name: str, g: torch.Tensor) -> torch.Tensor:
         """This micro-batch's share of the mean gradient plus what the earlier micro-batches of the window left."""
         if self.grad_accum == 1:
@@ -772,7 +871,7 @@ class Trainer:
         net, hip = self.net, self.net.hip
         pred = net.forward(st.unet_input, st.timestep, st.ehs, st.added_time_ids, st.action_ids)
         loss, dpred = TrainStep(hip).loss_and_grad(pred, st)
-        if self.opt is not None and self.loss_scale == 1.0 and self._seen is not None:
+        if self.opt is not None and not self.scaling and self._seen is not None:
             # hand every finished gradient to the sharded optimiser DURING the backward: its buckets are reduce-scattered
             # (asynchronously, over all xGMI links) while the remaining operators still run.  Which parameters get a
             # gradient is learnt from the first step (dead / frozen ones never do and must not be waited for).
@@ -790,7 +889,7 @@ class Trainer:
         grads = net.backward(dpred.reshape(pred.shape), self.loss_scale)
         net.tape.after_op = None
         self._seen = {n for n in grads if self.trainable(n)}
-        if self.loss_scale != 1.0:
+        if self.scaling:
             bad = ~torch.stack([torch.isfinite(g).all() for g in grads.values()]).all()
             if self.opt is not None and self.opt.world > 1:                # EVERY rank skips, or none: the collectives of
                 import torch.distributed as dist                           # `opt.step()` must be entered by all of them
@@ -821,7 +920,7 @@ class Trainer:
             grads = {name: self._mean_grad(name, g) for name, g in grads.items() if self.trainable(name)}
         self._acc = {}
         self.steps += 1
-        if self.loss_scale != 1.0:                                         # GradScaler growth: x2 after N good steps in a row
+        if self.scaling:                                                   # GradScaler growth: x2 after N good steps in a row
             self._good_steps += 1
             if self._good_steps >= self.scale_growth_interval:
                 self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 2.0 ** 16), 0

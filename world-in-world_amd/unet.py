@@ -77,9 +77,7 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
     weight folded in (W' = bf16(W * gamma)), and per head the fold vectors s = sum_k W'[n][k] (of the ROUNDED weights,
     so the fold is exact for what the MFMAs multiply), t = sum_k W[n][k] * beta[k]:
-        LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n.
-    fold[h] = [s (192) | t (192) | 32 words of 16-bit ONES | zeros] fp32 words: the 128 bytes of ones are the "frame slot 15"
-    operand row with which the kernel takes the LayerNorm row moments on the matrix pipe (temporal.hip, WIW_T_MFMA_STATS)."""
+        LayerNorm(x) . W_n = rstd * (x . W'_n - mean * s_n) + t_n."""
     C = wq.shape[1]
     heads = C // 64
     wp = torch.stack([m.float().reshape(heads, 64, C) for m in (wq, wk, wv)], dim=1).reshape(heads * 192, C)
@@ -87,8 +85,6 @@ def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamm
     fold = torch.zeros(heads, 512, dtype=torch.float32, device=wp.device)
     fold[:, :192] = wg.float().sum(dim=1).reshape(heads, 192)
     fold[:, 192:384] = (wp @ beta.float()).reshape(heads, 192)
-    one16 = 0x3C00 if dtype == torch.float16 else 0x3F80
-    fold.view(torch.int32)[:, 384:416] = one16 * 0x10001
     # the kernel streams the weight in the tiled layout of hip.TiledW (1-KiB blocks, one contiguous KiB per DMA instruction)
     return (tile_weight(wg) if tiled else wg), fold.contiguous()
 
