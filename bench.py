@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` legs the default single-GPU line appends after its timed region (B = 8 rollout = "
                          "BASELINE config 2's per-GPU work, fp16 and fp16 + fp32-residual rollouts, a 2-step --train leg)")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="skip the box calibration launches (rocprofv3 runs: ~100 ms of calibration kernels would lead the "
+                         "kernel statistics); `box` and `roofline.frac_of_box_peak` are then absent")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -203,7 +206,7 @@ def main():
     unet = UNetHIP(cfg, sd, device, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16,
                    residual_fp32=True if args.residual_fp32 else None)
     # what THIS box gives a pure-MFMA loop and a device copy (outside the timed region): the pool's boxes differ by +-5 %
-    box = unet.hip.calibrate_box() if rank == 0 else None
+    box = unet.hip.calibrate_box() if rank == 0 and not args.no_calibrate else None
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
@@ -293,9 +296,10 @@ def main():
         }
         # host time spent enqueueing one UNet forward (~1 100 launches through ctypes, or one hipGraphLaunch): measured around the
         # calls of the timed region, no synchronisation inside; the event-carrying steps are the eager sample
-        res["box"] = {"mfma_peak_measured": box["mfma_tflops"], "mfma_peak_unit": "TFLOP/s", "hbm_copy_GBps": box["copy_GBps"],
-                      "cus": box["cus"], "what": "a ~50 ms launch of back-to-back MFMAs on register operands (8 waves per CU) and a "
-                      "1 GiB device copy (read + write bytes), measured on this box before the timed region"}
+        if box is not None:
+            res["box"] = {"mfma_peak_measured": box["mfma_tflops"], "mfma_peak_unit": "TFLOP/s", "hbm_copy_GBps": box["copy_GBps"],
+                          "cus": box["cus"], "what": "a ~50 ms launch of back-to-back MFMAs on register operands (8 waves per CU) and "
+                          "a 1 GiB device copy (read + write bytes), measured on this box before the timed region"}
         hl = den.host_launch
         res["host_launch"] = {
             "hip_graph": (not args.no_graph) and den.graph_error is None,
@@ -340,7 +344,7 @@ def main():
             res["roofline"] = {"kernel": MODE_NAMES[dom], "templates": MODE_TEMPLATES.get(dom, []), "bound": "mfma",
                                "achieved": round(ach, 1),
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                               "frac_of_box_peak": round(ach / box["mfma_tflops"], 4),
+                               **({"frac_of_box_peak": round(ach / box["mfma_tflops"], 4)} if box is not None else {}),
                                "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                                "launches": cnt, "avg_launch_us": round(1e6 * tsec / cnt, 1),
                                "share_of_timed_region": round(tsec / (dt * ev_frac), 3)}
