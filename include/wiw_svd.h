@@ -115,7 +115,15 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
         * `out`; MFMA operands stay 16-bit.  Launches with any of these three bits run the 256x160 / 128x160 tiles with
         * a fragment-layout epilogue: fp32 accumulator + bias + vector + residuals, ONE rounding (none for fp32 out),
         * 16-byte accesses (N, ldo, ldr1, ldr2 % 4 == 0; no GEGLU / SiLU / GELU). */
-       WIW_EPI_RES1_F32 = 128, WIW_EPI_RES2_F32 = 256 };
+       WIW_EPI_RES1_F32 = 128, WIW_EPI_RES2_F32 = 256,
+       /* Convolution modes, ABI 11: the K index of W (and of the kernel's tap walk) is CHANNEL-BLOCK major,
+        *     k = ((c / 64) * taps + tap) * 64 + c % 64        instead of        k = tap * C1 + c,
+        * so the `taps` K tiles that read (shifted windows of) the SAME 64 channels of the activation are consecutive: the
+        * window stays in the XCD's L2 between them.  In tap-major order every tap streams the whole activation panel
+        * through the 4-MiB L2 before the next tap touches it again, and the PMC FETCH_SIZE of the 3x3 convolutions was 9x
+        * their algorithmic reads (1.39 GB per launch at 2.4 TB/s).  The fused shortcut segment (C2 + C3) stays behind the
+        * taps.  Pure permutation of K: the host re-orders W (`unet.py`), results differ only by fp32 summation order. */
+       WIW_K_CMAJOR = 512 };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -205,6 +213,11 @@ int wiw_temporal_attn_block_bf16(void* stream, const void* X, const void* Wqkv, 
  *   b1   : fp32 [2560] packed the same way;   W2: bf16 [320][1280] TILED;   b2: fp32 [320] or NULL
  *   rowvec / rows_per_vec / res1 / res2 / alpha / beta1 / beta2 : as for wiw_gemm_bf16 (fp32 vector rows; bf16 residuals)
  *   C_in, hidden : must be 320, 1280 (anything else returns WIW_EINVAL: the wider levels run on wiw_gemm_bf16)
+ * Rounding contract: as in the staged epilogue of wiw_gemm_bf16, alpha * (h . W2^T) is rounded to the 16-bit type when it is
+ * staged for the row-major store phase, b2 / rowvec / residuals are then added in fp32 and the sum is rounded again on store —
+ * one more 16-bit rounding of the FeedForward branch than a single fp32 epilogue would give (2^-9 resp. 2^-12 relative to the
+ * BRANCH, not to the sum).  The parity gates of this kernel are against the fp32 oracle (tests/test_hip_ffn.py), and the
+ * fp32-residual-stream mode does not use it (its FeedForward adds run in the one-rounding epilogue of wiw_gemm_bf16, ABI 11).
  * All pointers 16-byte aligned; ldx, ldo, ldr1, ldr2 multiples of 8; rowvec_ld a multiple of 4.
  * ---------------------------------------------------------------------------------------------- */
 int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,

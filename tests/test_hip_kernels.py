@@ -752,3 +752,74 @@ def test_transpose_is_exact(rows, C, c0, ldx, pad, dtype):
     hip.transpose(X, ldx, c0, rows, C, Y, ldy)
     assert torch.equal(Y[:, :rows], X[:, c0:c0 + C].t())
     assert bool((Y[:, rows:] == 7.0).all())                                    # nothing written past the rows
+
+
+# ----------------------------------------------------------------------------------------------
+# WIW_K_CMAJOR (round 4): the K index of the convolution modes in channel-block-major order
+# ----------------------------------------------------------------------------------------------
+def test_conv_modes_with_channel_block_major_k(hip):
+    """k = ((c / 64) * taps + tap) * 64 + c % 64 (include/wiw_svd.h): a permutation of K on both operands — every conv mode,
+    the fused shortcut segment behind the taps, split-K ranges that start inside a channel block / inside the segment, on
+    the 256x320 tile (the large shapes) and the 128x160 tile (the small ones).  Against fp32 torch, and against the tap-major launch
+    of the same problem (the two differ by the fp32 summation order only)."""
+    from wiw_amd import hip as H
+    from wiw_amd.unet import conv_k_cmajor
+
+    # 3x3, 3x3 + shortcut, stride 2, upsample — small and 256x320-sized
+    for (n, c, c2, c3, cout, h, w, sk) in [(3, 128, 0, 0, 64, 8, 16, 1), (3, 128, 64, 128, 320, 12, 16, 1),
+                                           (4, 256, 128, 64, 640, 40, 56, 1), (3, 64, 384, 320, 320, 12, 16, 2),
+                                           (3, 256, 0, 0, 320, 12, 16, 4), (4, 256, 128, 64, 640, 40, 56, 3)]:
+        x = bf(rnd(n, c, h, w, seed=1))
+        wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+        b = rnd(cout, seed=6)
+        M = n * h * w
+        w_tap = wt.permute(0, 2, 3, 1).reshape(cout, -1)
+        kw = dict(M=M, N=cout, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b), splitk=sk)
+        ref = F.conv2d(x, wt, b, padding=1)
+        w_cm, w_tm = conv_k_cmajor(w_tap, 9), w_tap
+        if c2:
+            s1, s2 = bf(rnd(n, c2, h, w, seed=2)), bf(rnd(n, c3, h, w, seed=3))
+            wsc = bf(rnd(cout, c2 + c3, 1, 1, seed=5) / math.sqrt(c2 + c3))[:, :, 0, 0]
+            w_cm, w_tm = torch.cat([w_cm, wsc], 1), torch.cat([w_tm, wsc], 1)
+            kw.update(A2=dev_bf(nhwc(s1)), C2=c2, A3=dev_bf(nhwc(s2)), C3=c3)
+            ref = ref + F.conv2d(torch.cat([s1, s2], dim=1), wsc[:, :, None, None])
+        K = w_cm.shape[1]
+        o_cm = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+        o_tm = torch.empty_like(o_cm)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_cm)), o_cm, K=K, epilogue=H.K_CMAJOR, **kw)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_tm)), o_tm, K=K, **kw)
+        check(from_nhwc(o_cm, n, h, w), ref, what=f"K-cmajor conv3x3 {c}|{c2}+{c3}->{cout} splitk={sk}")
+        d = (o_cm.float() - o_tm.float()).cpu()
+        rms = float(d.pow(2).mean().sqrt() / o_tm.float().pow(2).mean().sqrt().cpu())
+        assert rms <= 2e-3, "channel-block-major and tap-major launches differ by more than the summation order"
+    n, c, h, w = 3, 128, 8, 16
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(c, c, 3, 3, seed=2) / math.sqrt(9 * c))
+    b = rnd(c, seed=3)
+    wk = H.TiledW(dev_bf(conv_k_cmajor(wt.permute(0, 2, 3, 1).reshape(c, -1), 9)))
+    Mo = n * (h // 2) * (w // 2)
+    out = torch.empty(Mo, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=Mo, N=c, K=9 * c, C1=c, mode=H.A_CONV3X3_S2, H=h // 2, Wd=w // 2, bias=dev_f(b),
+             epilogue=H.K_CMAJOR)
+    check(from_nhwc(out, n, h // 2, w // 2), F.conv2d(x, wt, b, stride=2, padding=1), what="K-cmajor conv3x3 stride 2")
+    Mo = n * 4 * h * w
+    out = torch.empty(Mo, c, dtype=torch.bfloat16, device=DEV)
+    hip.gemm(dev_bf(nhwc(x)), wk, out, M=Mo, N=c, K=9 * c, C1=c, mode=H.A_CONV3X3_UP, H=2 * h, Wd=2 * w, bias=dev_f(b),
+             epilogue=H.K_CMAJOR)
+    check(from_nhwc(out, n, 2 * h, 2 * w), F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1),
+          what="K-cmajor nearest-up + conv3x3")
+    # temporal (3 taps), plain and split-K
+    B, T, c, h, w = 2, 6, 128, 4, 8
+    x5 = bf(rnd(B, c, T, h, w, seed=1))
+    wt3 = bf(rnd(c, c, 3, 1, 1, seed=2) / math.sqrt(3 * c))
+    tok = x5.permute(0, 2, 3, 4, 1).reshape(-1, c)
+    M = tok.shape[0]
+    ref = F.conv3d(x5, wt3, b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, c)
+    wk3 = H.TiledW(dev_bf(conv_k_cmajor(wt3[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, -1), 3)))
+    for sk in (1, 2, 3):
+        out = torch.empty(M, c, dtype=torch.bfloat16, device=DEV)
+        hip.gemm(dev_bf(tok), wk3, out, M=M, N=c, K=3 * c, C1=c, mode=H.A_CONV_T3, H=h, Wd=w, T=T, bias=dev_f(b), splitk=sk,
+                 epilogue=H.K_CMAJOR)
+        check(out, ref, what=f"K-cmajor temporal conv splitk={sk}")
+    with pytest.raises(RuntimeError, match="convolution-mode"):
+        hip.gemm(dev_bf(tok), wk3, out, M=M, N=c, K=3 * c, C1=3 * c, epilogue=H.K_CMAJOR)

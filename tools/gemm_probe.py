@@ -3,7 +3,7 @@
 the kernel and to attach rocprofv3 PMC counters to ONE shape.
 
     python tools/gemm_probe.py M,N,K[,mode[,epi]] ...      e.g.  258048,2560,320,0,1   (GEGLU)
-env: ITERS, TILED=1 (hip.TiledW weights), RES=1 (residual operand), SPLITK=n (WiwGemmArgs.splitk)
+env: ITERS, TILED=1 (hip.TiledW weights), RES=1 (residual operand), SPLITK=n (WiwGemmArgs.splitk), KCMAJOR=1 (WIW_K_CMAJOR on conv modes)
 mode: 0 dense 1 conv3x3 2 s2 3 up 4 temporal (conv shapes use H=72,W=128-like factorisation of M)
 """
 import math
@@ -35,6 +35,8 @@ def main():
         if os.environ.get("TILED"):
             W = H.TiledW(W)
         bias = torch.randn(N, device=dev)
+        if mode and os.environ.get("KCMAJOR"):      # channel-block-major K walk (random weights: no re-ordering needed for timing)
+            epi |= H.K_CMAJOR
         kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi, splitk=int(os.environ.get("SPLITK", "1")))
         if mode:
             frames = 28 if M % 28 == 0 else 1

@@ -158,6 +158,26 @@ WIW_DEV void wiw_epilogue_f32(const WiwGemmArgs& p, const f32x4 (&acc)[2][10], i
 // sums / sums of squares of its rows from the A fragments it feeds to the MFMAs anyway, and the fold is applied to the
 // fp32 accumulators in the fragment layout BEFORE the first 16-bit rounding.  The LayerNorm pass (one read + one write
 // of the activation) and the normalised tensor disappear.
+// One K tile forward in the implicit-GEMM K walk (see the cursor declaration in the kernel): tap-major, or channel-block
+// major under WIW_K_CMAJOR; the fused shortcut segment (tap 9, conv3x3 only) is walked last in both.
+struct WiwKCur { int tap, cc; };
+template <int MODE, int KT>
+WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   // by value: by-reference cursors end up in scratch
+    int ld_tap = c.tap, ld_cc = c.cc;
+    constexpr int NT = MODE == WIW_A_CONV_T3 ? 3 : 9;
+    if (MODE != WIW_A_DENSE && cmajor && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) {
+        if (++ld_tap == NT) {
+            ld_tap = 0;
+            ld_cc += KT;
+            if (MODE == WIW_A_CONV3X3 && ld_cc == Ctot) { ld_tap = 9; ld_cc = 0; }   // (only reached with a shortcut segment)
+        }
+    } else {
+        ld_cc += KT;
+        if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
+    }
+    return WiwKCur{ld_tap, ld_cc};
+}
+
 // F32E: the instantiation that serves the fp32 residual stream (ABI 11: WIW_EPI_OUT_F32 / _RES1_F32 / _RES2_F32 on aligned
 // shapes) — ONLY the vectorised fragment-layout epilogue is compiled into it, and it is compiled into no other instantiation
 // (in the common one its 120 residual registers cost every launch 240-300 bytes of scratch per lane).
@@ -261,6 +281,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
     const bool w_tiled = (p.epilogue & WIW_W_TILED) != 0;
     const int64_t w_kstep = w_tiled ? 1024 : BK * 2;
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
+    // K walk of the implicit GEMM.  Tap-major (k = tap * Ctot + c) or, with WIW_K_CMAJOR, channel-block-major
+    // (k = ((c / 64) * taps + tap) * 64 + c % 64): the taps of one 64-channel block are consecutive K tiles and re-read the
+    // same activation window while it is still in the XCD's L2 (include/wiw_svd.h).  The shortcut segment (tap 9) is last.
+    constexpr int NTAPS = MODE == WIW_A_CONV_T3 ? 3 : 9;
+    const bool cmajor = MODE != WIW_A_DENSE && (p.epilogue & WIW_K_CMAJOR) != 0;
 
     auto setup_loader = [&](int tile) {
         const int m0 = ((tile / Nt) % Mt1) * BM, n0 = (tile % Nt) * BN;
@@ -312,6 +337,12 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
         const int k0 = ld_kt * BK;
         if (MODE == WIW_A_DENSE) { ld_tap = 0; ld_cc = k0; }
         else {
+            if (cmajor) {
+                const int kt0 = k0 / BK, nblk = Ctot / BK;
+                if (kt0 < NTAPS * nblk) { ld_tap = kt0 % NTAPS; ld_cc = (kt0 / NTAPS) * BK; }
+                else { ld_tap = 9; ld_cc = (kt0 - NTAPS * nblk) * BK; }
+                return;
+            }
             int tp = k0 / Ctot;
             if (MODE == WIW_A_CONV3X3 && tp > 9) tp = 9;     // inside the fused-shortcut segment (longer than one tap)
             ld_tap = tp; ld_cc = k0 - tp * Ctot;
@@ -369,8 +400,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
             if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * w_kstep, sH);
         }
         ++ld_kt;
-        ld_cc += BK;
-        if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
+        { const WiwKCur kc = wiw_advance_k<MODE, BK>(WiwKCur{ld_tap, ld_cc}, Ctot, cmajor); ld_tap = kc.tap; ld_cc = kc.cc; }
     };
 
     // BIG: the 7 DMA instructions of a K tile are spread 2|2|2|1 over the four slots of the previous tile's
@@ -392,8 +422,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const WiwGemmArgs p, c
                 if (lane < 32) glds16(w_row[B_FULL] + (int64_t)ld_kt * w_kstep, sH);
             }
             ++ld_kt;
-            ld_cc += BK;
-            if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
+            { const WiwKCur kc = wiw_advance_k<MODE, BK>(WiwKCur{ld_tap, ld_cc}, Ctot, cmajor); ld_tap = kc.tap; ld_cc = kc.cc; }
         }
     };
 
@@ -1044,7 +1073,7 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
         WiwGemmArgs g = a;
         g.out = a.workspace; g.ldo = a.N;
         g.bias = nullptr; g.rowvec = nullptr; g.res1 = nullptr; g.res2 = nullptr;
-        g.alpha = 1.0f; g.epilogue = WIW_EPI_OUT_F32 | (a.epilogue & WIW_W_TILED);   // (the fp32-residual bits belong to pass 2)
+        g.alpha = 1.0f; g.epilogue = WIW_EPI_OUT_F32 | (a.epilogue & (WIW_W_TILED | WIW_K_CMAJOR));   // (the fp32-residual bits belong to pass 2)
         // tile: 256 x 320 when N fills it, every K range keeps >= 10 K tiles and the ranges give (nearly) every CU an
         // item; else 256 x 160.   WIW_GEMM_TILE=huge|big overrides (A/B).
         static const char* force_sk = getenv("WIW_GEMM_TILE");
@@ -1140,6 +1169,8 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
                     "gemm: LayerNorm fold needs the aligned (staged) output layout");
         WIW_REQUIRE(a.ln_eps > 0.0f, "gemm: LayerNorm fold needs ln_eps > 0");
     }
+    if (a.epilogue & WIW_K_CMAJOR)
+        WIW_REQUIRE(a.mode != WIW_A_DENSE, "gemm: WIW_K_CMAJOR is a convolution-mode K order");
     if (a.splitk > 1) {
         WIW_REQUIRE(a.workspace != nullptr, "gemm: split-K needs a workspace of splitk * M * N floats");
         WIW_REQUIRE((a.K / 64) % a.splitk == 0, "gemm: split-K needs K / 64 divisible by splitk");

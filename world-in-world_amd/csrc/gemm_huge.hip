@@ -68,6 +68,26 @@ template <int V> using IC = std::integral_constant<int, V>;
 // SK: split-K instantiation (raw fp32 slabs, no staged epilogue).  A separate template parameter because this kernel
 // lives at the 256-VGPR limit: with the split path compiled into the common instantiation its spills doubled
 // (80 -> 163 VGPRs) and every K >= 640 launch lost ~15 %.
+// One K tile forward in the implicit-GEMM K walk (see the cursor declaration in the kernel): tap-major, or channel-block
+// major under WIW_K_CMAJOR; the fused shortcut segment (tap 9, conv3x3 only) is walked last in both.
+struct WiwKCur { int tap, cc; };
+template <int MODE, int KT>
+WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   // by value: by-reference cursors end up in scratch
+    int ld_tap = c.tap, ld_cc = c.cc;
+    constexpr int NT = MODE == WIW_A_CONV_T3 ? 3 : 9;
+    if (MODE != WIW_A_DENSE && cmajor && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) {
+        if (++ld_tap == NT) {
+            ld_tap = 0;
+            ld_cc += KT;
+            if (MODE == WIW_A_CONV3X3 && ld_cc == Ctot) { ld_tap = 9; ld_cc = 0; }   // (only reached with a shortcut segment)
+        }
+    } else {
+        ld_cc += KT;
+        if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
+    }
+    return WiwKCur{ld_tap, ld_cc};
+}
+
 template <int MODE, bool GE, bool SK>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,6 +127,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             if (best < 0 || slots <= best) { best = slots; sn = c; }
         }
     }
+    {   // tuning knob WIW_GEMM_SN=1|2|4|8 (bits 8..11 of `stagger`): force the width of the per-XCD super-tile
+        const int sn_force = (stagger >> 8) & 15;
+        if (sn_force > 0 && sn_force <= bpx && sn_force <= Nt) sn = sn_force;
+    }
     const int sm = super ? bpx / sn : 1;
     const int SNt = (Nt + sn - 1) / sn, SMt = (Mt + sm - 1) / sm;
     const int n_super = SNt * SMt;
@@ -128,9 +152,9 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
     int t = next_tile(q);
     if (t < 0) return;
-    if (stagger > 0) {   // de-phase the blocks (tuning knob WIW_GEMM_STAGGER): see gemm.hip
+    if ((stagger & 255) > 0) {   // de-phase the blocks (tuning knob WIW_GEMM_STAGGER): see gemm.hip
         const int phase = (blockIdx.x >> 3) & 7;
-        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 cycles per iteration
+        for (int i = 0; i < phase * (stagger & 255); ++i) __builtin_amdgcn_s_sleep(16);   // 1024 cycles per iteration
     }
 
     // ---- loader state
@@ -153,6 +177,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     const bool w_tiled = (p.epilogue & WIW_W_TILED) != 0;
     const int64_t w_kstep = w_tiled ? 1024 : HK * 2;
     int ld_tap = 0, ld_cc = 0, ld_kt = 0;
+    // K walk of the implicit GEMM.  Tap-major (k = tap * Ctot + c) or, with WIW_K_CMAJOR, channel-block-major
+    // (k = ((c / 64) * taps + tap) * 64 + c % 64): the taps of one 64-channel block are consecutive K tiles and re-read the
+    // same activation window while it is still in the XCD's L2 (include/wiw_svd.h).  The shortcut segment (tap 9) is last.
+    constexpr int NTAPS = MODE == WIW_A_CONV_T3 ? 3 : 9;
+    const bool cmajor = MODE != WIW_A_DENSE && (p.epilogue & WIW_K_CMAJOR) != 0;
 
     auto setup_loader = [&](int tile) {
         const int m0 = (SK ? (tile / Nt) % Mt1 : tile / Nt) * HM, n0 = (tile % Nt) * HN;
@@ -239,8 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         } else {
             glds16(w_row[4] + (int64_t)ld_kt * w_kstep, sB + 4 * 1024);
             ++ld_kt;
-            ld_cc += HK;
-            if (ld_cc == Ctot && !(MODE == WIW_A_CONV3X3 && ld_tap == 9)) { ld_cc = 0; ++ld_tap; }
+            { const WiwKCur kc = wiw_advance_k<MODE, HK>(WiwKCur{ld_tap, ld_cc}, Ctot, cmajor); ld_tap = kc.tap; ld_cc = kc.cc; }
         }
     };
     auto issue_all = [&](int stage) {
@@ -292,6 +320,12 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         const int k0 = ld_kt * HK;
         if (MODE == WIW_A_DENSE) { ld_tap = 0; ld_cc = k0; }
         else {
+            if (cmajor) {
+                const int kt0 = k0 / HK, nblk = Ctot / HK;
+                if (kt0 < NTAPS * nblk) { ld_tap = kt0 % NTAPS; ld_cc = (kt0 / NTAPS) * HK; }
+                else { ld_tap = 9; ld_cc = (kt0 - NTAPS * nblk) * HK; }
+                return;
+            }
             int tp = k0 / Ctot;
             if (MODE == WIW_A_CONV3X3 && tp > 9) tp = 9;
             ld_tap = tp; ld_cc = k0 - tp * Ctot;
@@ -644,7 +678,8 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     int64_t grid = num_cu;
     if (tiles < grid) grid = tiles;   // one tile per block (a grid that is not a multiple of 8 uses contiguous ranges)
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
-    const int stagger = stg_env ? atoi(stg_env) : 0;
+    static const char* sn_env = getenv("WIW_GEMM_SN");
+    const int stagger = ((stg_env ? atoi(stg_env) : 0) & 255) | ((sn_env ? atoi(sn_env) & 15 : 0) << 8);
     hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }

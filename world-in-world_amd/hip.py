@@ -21,6 +21,7 @@ EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
 EPI_LNFOLD = 64  # epilogue bit: A is the raw LayerNorm input, W = W * gamma, lnfold = [s | t] (include/wiw_svd.h)
 EPI_RES1_F32, EPI_RES2_F32 = 128, 256   # epilogue bits: res1 / res2 are fp32 (the fp32 residual stream, ABI 11)
+K_CMAJOR = 512   # conv modes: K of W is channel-block major, k = ((c / 64) * taps + tap) * 64 + c % 64 (include/wiw_svd.h)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
 FFN_C, FFN_HIDDEN = 320, 1280   # the one shape wiw_ffn_geglu_bf16 is built for
@@ -292,8 +293,9 @@ class Hip:
         # algorithmic work: Q.K^T and P.V, 2*S*S*64 each per (frame, head); bytes: Q, K, V read + O written (bf16)
         if lse is not None:
             assert lse.dtype == torch.float32 and lse.numel() == frames * heads * S
-            self._ck(self.lib.wiw_attn_spatial_lse_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo, frames, S,
-                                                        heads, scale, self.zeros.data_ptr(), _p(lse)), "wiw_attn_spatial_lse_bf16")
+            self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
+                self.lib.wiw_attn_spatial_lse_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo, frames, S,
+                                                   heads, scale, self.zeros.data_ptr(), _p(lse)), "wiw_attn_spatial_lse_bf16"))
             return O
         self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
             self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,

@@ -28,7 +28,7 @@ import torch
 
 from .config import UNetConfig
 from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI_GEGLU, EPI_OUT_F32, EPI_SILU,
-                  FFN_C, FFN_CHUNK, FFN_HIDDEN, GEGLU_TILE, Hip, TiledW, tile_weight)
+                  FFN_C, FFN_CHUNK, FFN_HIDDEN, GEGLU_TILE, K_CMAJOR, Hip, TiledW, tile_weight)
 from .weights import validate_state_dict
 
 CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
@@ -50,6 +50,15 @@ def action_features(action_ids: np.ndarray) -> np.ndarray:
         feats += [np.cos(np.float32(k) * x), np.sin(np.float32(k) * x)]
     f = np.stack(feats, axis=-1)
     return f.reshape(x.shape[0] * x.shape[1], x.shape[2] * 12)
+
+
+def conv_k_cmajor(w: torch.Tensor, taps: int) -> torch.Tensor:
+    """[N, taps * C] (k = tap * C + c) -> the same weights with K in CHANNEL-BLOCK-major order, k = ((c / 64) * taps + tap) * 64
+    + c % 64 (WIW_K_CMAJOR, include/wiw_svd.h): the taps of one 64-channel block become consecutive K tiles of the implicit GEMM."""
+    N, K = w.shape
+    C = K // taps
+    assert K == taps * C and C % 64 == 0
+    return w.reshape(N, taps, C // 64, 64).permute(0, 2, 1, 3).reshape(N, K).contiguous()
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, tile: int = GEGLU_TILE):
@@ -148,6 +157,9 @@ class UNetHIP:
         if self.res32:
             self.ln_fold = False          # the folds read the raw stream as a 16-bit MFMA operand
             self.temporal_unfused = True  # LayerNorm (fp32 in) + QKV GEMM + attention core
+        # convolution weights with K in channel-block-major order (round 4: the taps of a 64-channel block re-read the same
+        # activation window while it is still in L2; A/B knob WIW_K_TAPMAJOR=1 keeps the tap-major order)
+        self.kc = 0 if os.environ.get("WIW_K_TAPMAJOR") else K_CMAJOR
         self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not self.res32
         self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
         self._prepare(state_dict)
@@ -181,12 +193,14 @@ class UNetHIP:
             x = self._t(sd, p + ".weight").permute(0, 2, 3, 1)  # OIHW -> OHWI
             if cin_pad and x.shape[-1] < cin_pad:
                 x = torch.cat([x, x.new_zeros(*x.shape[:-1], cin_pad - x.shape[-1])], dim=-1)
-            w[p + ".weight"] = x.reshape(x.shape[0], -1).to(bf).contiguous()
+            x = x.reshape(x.shape[0], -1)
+            w[p + ".weight"] = (conv_k_cmajor(x, 9) if self.kc else x).to(bf).contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
 
         def convt(p):
             x = self._t(sd, p + ".weight")[:, :, :, 0, 0].permute(0, 2, 1)  # (O,I,3) -> (O,3,I)
-            w[p + ".weight"] = x.reshape(x.shape[0], -1).to(bf).contiguous()
+            x = x.reshape(x.shape[0], -1)
+            w[p + ".weight"] = (conv_k_cmajor(x, 3) if self.kc else x).to(bf).contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
 
         def res(p):
@@ -202,6 +216,8 @@ class UNetHIP:
                 # GEMM: W = [conv2 (9*Cout) | shortcut (Cin)], bias = b2 + b_sc — the shortcut tensor is never written
                 x = self._t(sd, s + ".conv_shortcut.weight")[:, :, 0, 0]
                 w2 = self._t(sd, s + ".conv2.weight").permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+                if self.kc:
+                    w2 = conv_k_cmajor(w2, 9)          # the shortcut segment stays behind the taps
                 w[s + ".conv2sc.weight"] = torch.cat([w2, x], dim=1).to(bf).contiguous()
                 w[s + ".conv2sc.bias"] = (self._t(sd, s + ".conv2.bias") + self._t(sd, s + ".conv_shortcut.bias")).contiguous()
                 del w[s + ".conv2.weight"], w[s + ".conv2.bias"]
@@ -452,13 +468,13 @@ class UNetHIP:
         h = self._empty(M, Cout)
         hip.gemm(xn, w[s + ".conv1.weight"], h, M=M, N=Cout, K=9 * Cin, C1=Cin, mode=A_CONV3X3, H=H, Wd=W,
                  bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
-                 rows_per_vec=S, splitk=self._splitk(T * S, Cout, 9 * Cin))
+                 rows_per_vec=S, splitk=self._splitk(T * S, Cout, 9 * Cin), epilogue=self.kc)
         hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
         xs = self._empty(M, Cout, dtype=sdt)
         if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
             sc_ops = dict(A2=raw, C2=Cin) if raw is not None else dict(A2=x1, C2=C1, A3=x2, C3=C2)
             hip.gemm(hn, w[s + ".conv2sc.weight"], xs, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin), epilogue=epi_s, **sc_ops)
+                     bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin), epilogue=epi_s | self.kc, **sc_ops)
         else:
             if s + ".conv_shortcut.weight" in w:   # unfused A/B path: separate 1x1 GEMM, then residual
                 assert not self.res32, "WIW_UNFUSED_SHORTCUT is a 16-bit-stream A/B knob"
@@ -470,18 +486,18 @@ class UNetHIP:
                 sc = x1
             hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
                      bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0, splitk=self._splitk(T * S, Cout, 9 * Cout),
-                     epilogue=epi_s)
+                     epilogue=epi_s | self.kc)
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
         xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True, clip=True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
                  bias=w[t + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[t]:], rowvec_ld=self.temb_total,
-                 rows_per_vec=S)
+                 rows_per_vec=S, epilogue=self.kc)
         hn = hip.groupnorm(h, Cout, None, 0, M, T * S, w[t + ".norm2.weight"], w[t + ".norm2.bias"], eps, True, out=hn, clip=True)
         a = self.alpha[p]
         out = self._empty(M, Cout, dtype=sdt)
         # AlphaBlender: a*xs + (1-a)*(xs + conv2(h) + b) = xs + (1-a)*(acc + b)   (resnet.py:784-797)
         hip.gemm(hn, w[t + ".conv2.weight"], out, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
-                 bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s)
+                 bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s | self.kc)
         return out
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
@@ -614,7 +630,7 @@ class UNetHIP:
         epi_s = EPI_OUT_F32 if self.res32 else 0     # residual-stream outputs (fp32 when residual_fp32)
         x = self._empty(M, ch[0], dtype=self.sdt)
         hip.gemm(x_in, w["conv_in.weight"], x, M=M, N=ch[0], K=9 * CIN_PAD, C1=CIN_PAD, mode=A_CONV3X3, H=h, Wd=w_,
-                 bias=w["conv_in.bias"], epilogue=epi_s)
+                 bias=w["conv_in.bias"], epilogue=epi_s | self.kc)
         skips = [(x, ch[0])]
         H, W, C = h, w_, ch[0]
         for i in range(n):
@@ -633,7 +649,7 @@ class UNetHIP:
                 q = f"{p}.downsamplers.0.conv"
                 # (an fp32 stream enters the convolution as its rounded copy: Downsample2D has no norm in front of it)
                 hip.gemm(hip.cast16(x) if self.res32 else x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_S2,
-                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s)
+                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s | self.kc)
                 x = y
                 skips.append((x, C))
         x = self._res_block("mid_block.resnets.0", x, C, None, 0, C, M, H, W, temb_all, 1e-5)
@@ -654,12 +670,12 @@ class UNetHIP:
                 y = self._empty(M, C, dtype=self.sdt)
                 q = f"{p}.upsamplers.0.conv"
                 hip.gemm(hip.cast16(x) if self.res32 else x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_UP,
-                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s)
+                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s | self.kc)
                 x = y
         xn = hip.groupnorm(x, C, None, 0, M, H * W, w["conv_norm_out.weight"], w["conv_norm_out.bias"], 1e-5, True)
         out = self._empty(M, cfg.out_channels, dtype=torch.float32)
         hip.gemm(xn, w["conv_out.weight"], out, M=M, N=cfg.out_channels, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W,
-                 bias=w["conv_out.bias"], epilogue=EPI_OUT_F32)
+                 bias=w["conv_out.bias"], epilogue=EPI_OUT_F32 | self.kc)
         return out
 
     # ------------------------------------------------------------------------------------------
