@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 11  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 12  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -44,7 +44,9 @@ extern "C" {
                                  log-sum-exp to the backward);
                              11: the fp32 residual stream: WIW_EPI_RES1_F32 / WIW_EPI_RES2_F32, WIW_EPI_OUT_F32 on vectorised
                                  stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
-                                 wiw_cast_f32_to_16, wiw_calib_mfma */
+                                 wiw_cast_f32_to_16, wiw_calib_mfma;
+                             12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
+                                 statistics launch (wiw_groupnorm_counters) */
 
 int wiw_abi_version(void);
 
@@ -235,14 +237,21 @@ int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, con
  *           sums per thread, then Chan merges of (count, mean, M2) — no E[x^2] - mean^2 cancellation (ABI v3;
  *           v2 stored raw (sum, sum of squares));
  *   scratch : fp32, >= wiw_groupnorm_scratch_floats(rows, rows_per_unit, rows_per_block) elements (per-block
- *             (mean, M2) pairs).  The reduction is deterministic: fixed merge order, no atomics (two launches:
- *             partials, then a block-order merge).  rows_per_block (0 = default by unit size) fixes the summation order of a unit
+ *             (mean, M2) pairs, then per-part (count, mean, M2) triples).  The reduction is deterministic: every merge
+ *             order is fixed and no DATA goes through atomics.  ONE launch since ABI 12: a block publishes its pair behind
+ *             an agent-scope release fence and bumps a counter; the block that finds its part of 32 blocks complete merges
+ *             the part, the block that finds the unit's parts complete merges those — which block that is depends on
+ *             timing, what it computes does not (before: a second launch, 8.7 us x 105 GroupNorms per UNet forward).
+ *             rows_per_block (0 = default by unit size) fixes the summation order of a unit
  *             independently of how many units the call covers — a candidate's bits do not depend on its batch;
+ *   counters : >= wiw_groupnorm_counters(rows, rows_per_unit, rows_per_block) unsigned, ZERO before the first call; every
+ *              call leaves them zero.  Calls that may run concurrently (different streams) need different counters;
  *   ab    : fp32 [units][2][C]  per-channel scale a = rstd*gamma and shift b = beta - mean*a.
  * ---------------------------------------------------------------------------------------------- */
 int64_t wiw_groupnorm_scratch_floats(int64_t rows, int rows_per_unit, int rows_per_block);
+int64_t wiw_groupnorm_counters(int64_t rows, int rows_per_unit, int rows_per_block);
 int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
-                        int rows_per_unit, int rows_per_block, float* stats, float* scratch);
+                        int rows_per_unit, int rows_per_block, float* stats, float* scratch, unsigned* counters);
 int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta, int units,
                            int C, int rows_per_unit, float eps, float* ab);
 int wiw_groupnorm_apply(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
@@ -256,7 +265,7 @@ int wiw_groupnorm_apply_stats(void* stream, const void* X1, int C1, const void* 
  * (concatenated): the MFMA operand of ResnetBlock2D's 1x1 conv_shortcut (resnet.py:311-318), which reads the block input
  * itself — one extra write in a pass that holds the value in registers anyway, instead of a cast pass. */
 int wiw_groupnorm_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
-                              int rows_per_unit, int rows_per_block, float* stats, float* scratch);
+                              int rows_per_unit, int rows_per_block, float* stats, float* scratch, unsigned* counters);
 int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
                                     int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
                                     int silu, void* out, void* raw16);

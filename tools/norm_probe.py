@@ -42,16 +42,30 @@ def main():
         us = timeit(lambda: hip.layernorm(x, M, C, g, b, addvec=av, addvec_ld=C, rows_per_vec=S, sum_out=sm, out=out))
         print(f"layernorm+sum    M={M} C={C}: {us:8.1f} us  {3 * byts / us / 1e6:6.2f} TB/s")
         stats = torch.zeros(frames * 64, device=dev)
-        scratch = torch.empty(max(int(hip.lib.wiw_groupnorm_scratch_floats(M, S, hip.gn_rows_per_block(S, False))), int(hip.lib.wiw_groupnorm_scratch_floats(M, 14 * S, hip.gn_rows_per_block(14 * S, True)))),
-                              device=dev)
         ab = torch.randn(frames * 2 * C, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, S, hip.gn_rows_per_block(S, False), stats.data_ptr(), scratch.data_ptr()))
-        print(f"gn_stats         M={M} C={C}: {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s")
+        cnt = hip._gn_cnt
+        ref = x.float().view(frames, S, 32, C // 32).transpose(1, 2).reshape(frames, 32, -1)
+        ref_m, ref_v = ref.mean(-1), ref.var(-1, unbiased=False)
+        for clip, rpu, label in ((False, S, "gn_stats        "), (True, 14 * S, "gn_stats (T*S)  ")):
+            rpbs = [hip.gn_rows_per_block(rpu, clip)] + [int(v) for v in os.environ.get("RPB", "").split(",") if v]
+            for rpb in rpbs:
+                scratch = torch.empty(int(hip.lib.wiw_groupnorm_scratch_floats(M, rpu, rpb)), device=dev)
+                assert int(hip.lib.wiw_groupnorm_counters(M, rpu, rpb)) <= cnt.numel()
+                fn = lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, rpu, rpb, stats.data_ptr(), scratch.data_ptr(), cnt.data_ptr())
+                us = timeit(fn)
+                st = stats[: (M // rpu) * 64].view(-1, 32, 2)
+                if not clip:
+                    err = max(float((st[..., 0] - ref_m).abs().max()), float((st[..., 1] - ref_v).abs().max()))
+                else:
+                    rc = x.float().view(M // rpu, rpu, 32, C // 32).transpose(1, 2).reshape(M // rpu, 32, -1)
+                    err = max(float((st[..., 0] - rc.mean(-1)).abs().max()), float((st[..., 1] - rc.var(-1, unbiased=False)).abs().max()))
+                a0 = st.clone(); fn(); torch.cuda.synchronize()
+                print(f"{label} M={M} C={C} rpb={rpb:4d}: {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s   max|err| {err:.2e}  rerun identical {bool((a0 == st).all())}  counters zero {int(cnt.abs().sum()) == 0}")
         us = timeit(lambda: hip.lib.wiw_groupnorm_apply(s, x.data_ptr(), C, None, 0, M, S, ab.data_ptr(), 1, out.data_ptr()))
         print(f"gn_apply(silu)   M={M} C={C}: {us:8.1f} us  {2 * byts / us / 1e6:6.2f} TB/s")
-        us = timeit(lambda: hip.lib.wiw_groupnorm_stats(s, x.data_ptr(), C, None, 0, M, 14 * S, hip.gn_rows_per_block(14 * S, True), stats.data_ptr(), scratch.data_ptr()))
-        print(f"gn_stats (T*S)   M={M} C={C}: {us:8.1f} us  {byts / us / 1e6:6.2f} TB/s")
+        us = timeit(lambda: hip.groupnorm(x, C, None, 0, M, S, g, b, 1e-5, True, out=out))
+        print(f"groupnorm (both) M={M} C={C}: {us:8.1f} us  {3 * byts / us / 1e6:6.2f} TB/s")
 
 
 if __name__ == "__main__":

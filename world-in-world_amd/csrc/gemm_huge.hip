@@ -699,9 +699,11 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     if (a.res1 && a.ldr1 % 8) return false;
     if (a.res2 && a.ldr2 % 8) return false;
     if ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) || a.rowvec_ld % 4) return false;
-    // short K (< 10 K tiles): the output tile's epilogue dominates and the smaller tile's finer granularity wins
-    // (measured: K = 320 GEGLU -6 %, plain +-2 %; K >= 640 +4...+28 %)
-    if (a.K < 640 && !getenv("WIW_GEMM_HUGE_ANYK")) return false;
+    // short K (< 10 K tiles) with GEGLU: the output tile's epilogue dominates and the smaller tile's finer granularity wins
+    // (K = 320 GEGLU -6 %).  Plain epilogues at K = 320 were +-2 % while this kernel spilled; spill-free (round 4) the
+    // 320-wide tile reads the A panel once instead of twice: M = 258 048, N = 320 138.7 -> 125.6 us with a residual,
+    // 102.3 -> 88.5 without, N = 960 284 -> 250 (profiles/r10a_tile_probe.txt, r10b_tile_probe.txt)
+    if (a.K < 640 && ge && !getenv("WIW_GEMM_HUGE_ANYK")) return false;
     const int64_t tiles = (int64_t)((a.M + HM - 1) / HM) * ((a.N + HN - 1) / HN);
     if (tiles < 200) return false;
     // persistent grid of one block per CU: a tile count just above a multiple of the CU count leaves the last round mostly

@@ -18,11 +18,18 @@ constexpr int GROUPS = 32;
 // order.  The single-pass E[x^2] - mean^2 of round 1 lost the variance for |mean| >> std (torch uses Welford; trained
 // SVD activations have outlier channels).
 // DETERMINISTIC: no atomics anywhere — every merge order is fixed; every block writes its 32 (mean, M2) pairs to
-// `partials[unit][block][32][2]`, and gn_reduce_kernel merges the blocks in block order.  (With fp32 atomics the same
+// `partials[unit][block][32][2]`, and the second stage (below) merges the blocks in block order.  (With fp32 atomics the same
 // request differed by 1.6e-2 relative rms between two runs after two Euler steps at full size: a random-init network
 // amplifies last-bit differences; the reference's GroupNorm is deterministic.)
 // ---------------------------------------------------------------------------------------------
 constexpr int GN_MAXC = 4096;
+#ifndef WIW_GN_U
+#define WIW_GN_U 4
+#endif
+#ifndef WIW_GN_WAVES
+#define WIW_GN_WAVES 5                  // waves per SIMD the register allocation is held to (96 VGPRs, no scratch)
+#endif
+constexpr int GN_U = WIW_GN_U;          // loads in flight per thread of the statistics pass (A/B: tools/build_variant.py)
 
 // 8 consecutive channels starting at element offset `off` of a 16-bit (F32IN = false: one 16-byte load, returned packed)
 // or fp32 (two 16-byte loads) tensor.  The fp32 form serves the fp32 residual stream (ABI 11).
@@ -58,14 +65,70 @@ WIW_DEV void chan_merge(float& na, float& ma, float& Ma, float nb, float mb, flo
     na = n;
 }
 
+// SECOND STAGE IN THE SAME LAUNCH (round 4, ABI 12; the stand-alone gn_reduce_kernel cost 8.7 us x 105 launches per
+// forward): blocks are grouped in PARTS of GN_PART consecutive blocks.  Every block publishes its partial and bumps its
+// part's counter; the block that finds the part complete merges the part's blocks (thread = (group, 4 consecutive blocks),
+// then the 8 sub-results in order) into `parts[unit][part]`, then bumps the unit's counter the same way; the block that
+// finds the unit complete merges the parts in part order and writes stats[unit].  WHICH block does a merge depends on
+// timing, WHAT it computes does not: every merge order is fixed.
+// Publication WITHOUT agent-scope fences: `__threadfence()` is buffer_wbl2 + buffer_inv of the XCD's whole L2, and 2 000
+// blocks doing that serialise chip-wide (measured, profiles/r10a_norm_probe.txt: 0.12 us per block, the pass at 0.7 TB/s).
+// Instead the exchanged words themselves are agent-scope accesses — stores written through (sc1), completed
+// (s_waitcnt vmcnt(0)) before the counter's atomic is issued; loads that bypass the non-coherent levels (sc0 sc1), issued
+// after the atomic returned — so no cached copy of them exists anywhere.  The streamed tensor never needs coherence.
+// counters: [units][nparts + 1] unsigned, zero before the launch, left at zero.
+constexpr int GN_PART = 32;
+
+WIW_DEV void gn_publish2(float* p, float x, float y) {       // 8-byte agent-scope store
+    __hip_atomic_store((unsigned long long*)p, ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// N independent 8-byte (16-byte) loads that bypass L1 / L2 non-coherent copies, all in flight together, waited for inside
+// the statement (the compiler sees plain register outputs)
+WIW_DEV void gn_fetch4x2(const float2* p0, const float2* p1, const float2* p2, const float2* p3, float2* v) {
+    unsigned long long a, b, c, d;
+    asm volatile(
+        "global_load_dwordx2 %0, %4, off sc0 sc1\n\t"
+        "global_load_dwordx2 %1, %5, off sc0 sc1\n\t"
+        "global_load_dwordx2 %2, %6, off sc0 sc1\n\t"
+        "global_load_dwordx2 %3, %7, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+    const unsigned long long r[4] = {a, b, c, d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = float2{__uint_as_float((unsigned)(r[i] & 0xffffffffull)), __uint_as_float((unsigned)(r[i] >> 32))};
+}
+WIW_DEV void gn_fetch4x4(const float4* p0, const float4* p1, const float4* p2, const float4* p3, float4* v) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u a, b, c, d;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+    const v4u r[4] = {a, b, c, d};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = float4{__uint_as_float(r[i].x), __uint_as_float(r[i].y), __uint_as_float(r[i].z), __uint_as_float(r[i].w)};
+}
+
 template <bool F32IN>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ X1, int C1,
+__global__ __launch_bounds__(256, WIW_GN_WAVES) void gn_stats_kernel(const void* __restrict__ X1, int C1,
                                                         const void* __restrict__ X2, int C2, int rows_per_unit,
-                                                        int rows_per_block, float* __restrict__ partials) {
+                                                        int rows_per_block, float* partials, unsigned* counters,
+                                                        float* __restrict__ stats) {
     __shared__ float red[256][17];          // per-thread (mean[8], M2[8]); 17: skewed banks
-    __shared__ float chan[2][GN_MAXC];      // per-channel block (mean, M2)
+    extern __shared__ float chan_dyn[];     // per-channel block (mean, M2): [2][C]
     const int tid = threadIdx.x;
     const int C = C1 + C2;
+    float* const chan0 = chan_dyn;
+    float* const chan1 = chan_dyn + C;
     const int cg = C / GROUPS;
     const int chunks = C >> 3;
     const int cpb = chunks < 256 ? chunks : 256;   // chunk columns handled per pass
@@ -110,13 +173,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ 
             if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
             int r = r0 + rl;
             pairs(load_raw8<F32IN>(src, (base_row + r) * ld + coff), p2);   // pivot = first row (re-read below: L1 hit)
-            for (; r + 3 * rp < r1; r += 4 * rp) {   // four independent (pairs of) 16-byte loads in flight per thread
-                Raw8<F32IN> raw[4];
+            for (; r + (GN_U - 1) * rp < r1; r += GN_U * rp) {   // GN_U independent (pairs of) 16-byte loads in flight per thread
+                Raw8<F32IN> raw[GN_U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) raw[u] = load_raw8<F32IN>(src, (base_row + r + u * rp) * ld + coff);
+                for (int u = 0; u < GN_U; ++u) raw[u] = load_raw8<F32IN>(src, (base_row + r + u * rp) * ld + coff);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) accum(raw[u]);
-                cnt += 4;
+                for (int u = 0; u < GN_U; ++u) accum(raw[u]);
+                cnt += GN_U;
             }
             for (; r < r1; r += rp) {
                 accum(load_raw8<F32IN>(src, (base_row + r) * ld + coff));
@@ -157,8 +220,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ 
                     const float dm = red[j * cpb + cc][e] - mean;
                     M2 += red[j * cpb + cc][8 + e] + nj * dm * dm;
                 }
-                chan[0][(cbase + cc) * 8 + e] = mean;
-                chan[1][(cbase + cc) * 8 + e] = M2;
+                chan0[(cbase + cc) * 8 + e] = mean;
+                chan1[(cbase + cc) * 8 + e] = M2;
             }
         }
         __syncthreads();
@@ -167,63 +230,87 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const void* __restrict__ 
         const int g = tid;
         const float nr = (float)(r1 - r0);
         float ms = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) ms += chan[0][c];
+        for (int c = g * cg; c < (g + 1) * cg; ++c) ms += chan0[c];
         const float mean = ms / (float)cg;
         float M2 = 0.f;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) { const float dm = chan[0][c] - mean; M2 += chan[1][c] + nr * dm * dm; }
-        float* dst = partials + ((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + 2 * g;
-        dst[0] = mean;
-        dst[1] = M2;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { const float dm = chan0[c] - mean; M2 += chan1[c] + nr * dm * dm; }
+        gn_publish2(partials + ((int64_t)unit * gridDim.x + blockIdx.x) * (GROUPS * 2) + 2 * g, mean, M2);
     }
-}
-
-// stats[unit][g] = (mean, biased variance) of the whole unit: the blocks' (count, mean, M2) triples are merged in a
-// FIXED order: 16 waves each merge a contiguous 1/16 of the blocks in block order (lane = group), wave 0 merges the 16
-// results in wave order.  Block b of a unit holds min(rows_per_block, rows_per_unit - b*rows_per_block) * cg elements.
-constexpr int GN_RED_PARTS = 16;
-
-__global__ __launch_bounds__(64 * GN_RED_PARTS) void gn_reduce_kernel(const float* __restrict__ partials, int splits,
-                                                                       int rows_per_unit, int rows_per_block, int cg,
-                                                                       float* __restrict__ stats) {
-    __shared__ float part[GN_RED_PARTS][GROUPS][3];
-    const int unit = blockIdx.x, t = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = (splits + GN_RED_PARTS - 1) / GN_RED_PARTS;
-    const int b0 = w * per, b1 = b0 + per < splits ? b0 + per : splits;
-    if (t < GROUPS) {   // two-pass merge of this wave's blocks (block order): weighted mean, then M2 about it.
-        // The partials are loaded ONCE (all loads independent, then held in registers for the second pass).
-        constexpr int CACHE = 32;
-        const float2* p = (const float2*)(partials + (int64_t)unit * splits * (GROUPS * 2)) + t;
-        float2 v[CACHE];
-#pragma unroll
-        for (int i = 0; i < CACHE; ++i)
-            if (b0 + i < b1) v[i] = p[(int64_t)(b0 + i) * GROUPS];
-        auto rows_of = [&](int b) {
-            return rows_per_unit - b * rows_per_block < rows_per_block ? rows_per_unit - b * rows_per_block : rows_per_block;
-        };
-        float n = 0.f, ms = 0.f;
-#pragma unroll
-        for (int i = 0; i < CACHE; ++i)
-            if (b0 + i < b1) { const float nb_ = (float)rows_of(b0 + i) * (float)cg; n += nb_; ms += nb_ * v[i].x; }
-        for (int b = b0 + CACHE; b < b1; ++b) { const float nb_ = (float)rows_of(b) * (float)cg; n += nb_; ms += nb_ * p[(int64_t)b * GROUPS].x; }
-        const float m = n > 0.f ? ms / n : 0.f;
-        float M2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < CACHE; ++i)
-            if (b0 + i < b1) { const float dm = v[i].x - m; M2 += v[i].y + (float)rows_of(b0 + i) * (float)cg * dm * dm; }
-        for (int b = b0 + CACHE; b < b1; ++b) {
-            const float2 u = p[(int64_t)b * GROUPS];
-            const float dm = u.x - m;
-            M2 += u.y + (float)rows_of(b) * (float)cg * dm * dm;
-        }
-        part[w][t][0] = n; part[w][t][1] = m; part[w][t][2] = M2;
+    // ---- second stage (see the header of this section)
+    __shared__ int s_flag;
+    __shared__ float red2[8][GROUPS][3];
+    const int splits = (int)gridDim.x;
+    const int nparts = (splits + GN_PART - 1) / GN_PART;
+    const int w = (int)blockIdx.x / GN_PART;
+    const int b0 = w * GN_PART, b1 = b0 + GN_PART < splits ? b0 + GN_PART : splits;
+    unsigned* cnt = counters + (int64_t)unit * (nparts + 1);
+    float* parts = partials + (int64_t)gridDim.y * splits * (GROUPS * 2);      // [units][nparts][32][4]: (n, mean, M2, -)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's published words have landed (write-through acknowledged)
+    __syncthreads();
+    if (tid == 0) {
+        s_flag = atomicAdd(&cnt[1 + w], 1u) == (unsigned)(b1 - b0 - 1) ? 1 : 0;
+        // every block of the part has passed: nobody touches the counter again in this launch
+        if (s_flag) __hip_atomic_store(&cnt[1 + w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (w == 0 && t < GROUPS) {
+    if (!s_flag) return;
+    auto elems_of = [&](int b) {
+        const int left = rows_per_unit - b * rows_per_block;
+        return (float)(left < rows_per_block ? left : rows_per_block) * (float)cg;
+    };
+    {
+        const int g = tid & 31, j = tid >> 5;
+        const float2* p = (const float2*)(partials + (int64_t)unit * splits * (GROUPS * 2)) + g;
+        const int bl = b1 - 1;                                   // out-of-part slots re-read the last block (ignored)
+        const int bb = b0 + 4 * j;
+        float2 v[4];
+        gn_fetch4x2(p + (int64_t)(bb < bl ? bb : bl) * GROUPS, p + (int64_t)(bb + 1 < bl ? bb + 1 : bl) * GROUPS,
+                    p + (int64_t)(bb + 2 < bl ? bb + 2 : bl) * GROUPS, p + (int64_t)(bb + 3 < bl ? bb + 3 : bl) * GROUPS, v);
         float n = 0.f, m = 0.f, M2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < GN_RED_PARTS; ++k) chan_merge(n, m, M2, part[k][t][0], part[k][t][1], part[k][t][2]);
-        stats[(int64_t)unit * (GROUPS * 2) + 2 * t] = m;
-        stats[(int64_t)unit * (GROUPS * 2) + 2 * t + 1] = n > 0.f ? M2 / n : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int b = bb + i;
+            if (b < b1) chan_merge(n, m, M2, elems_of(b), v[i].x, v[i].y);
+        }
+        red2[j][g][0] = n; red2[j][g][1] = m; red2[j][g][2] = M2;
+    }
+    __syncthreads();
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    if (tid < GROUPS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) chan_merge(n, m, M2, red2[j][tid][0], red2[j][tid][1], red2[j][tid][2]);
+        if (nparts > 1) {
+            float* pr = parts + (((int64_t)unit * nparts + w) * GROUPS + tid) * 4;
+            gn_publish2(pr, n, m);
+            gn_publish2(pr + 2, M2, 0.f);
+        }
+    }
+    if (nparts > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            s_flag = atomicAdd(&cnt[0], 1u) == (unsigned)(nparts - 1) ? 1 : 0;
+            if (s_flag) __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_flag) return;
+        if (tid < GROUPS) {
+            const float4* pp = (const float4*)(parts + ((int64_t)unit * nparts * GROUPS + tid) * 4);
+            n = 0.f; m = 0.f; M2 = 0.f;
+            const int wl = nparts - 1;
+            for (int w0 = 0; w0 < nparts; w0 += 4) {       // part order; 4 loads in flight
+                float4 u[4];
+                gn_fetch4x4(pp + (int64_t)(w0 < wl ? w0 : wl) * GROUPS, pp + (int64_t)(w0 + 1 < wl ? w0 + 1 : wl) * GROUPS,
+                            pp + (int64_t)(w0 + 2 < wl ? w0 + 2 : wl) * GROUPS, pp + (int64_t)(w0 + 3 < wl ? w0 + 3 : wl) * GROUPS, u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (w0 + i < nparts) chan_merge(n, m, M2, u[i].x, u[i].y, u[i].z);
+            }
+        }
+    }
+    if (tid < GROUPS) {
+        stats[(int64_t)unit * (GROUPS * 2) + 2 * tid] = m;
+        stats[(int64_t)unit * (GROUPS * 2) + 2 * tid + 1] = n > 0.f ? M2 / n : 0.f;
     }
 }
 
@@ -472,12 +559,22 @@ extern "C" int64_t wiw_groupnorm_scratch_floats(int64_t rows, int rows_per_unit,
     if (rows <= 0 || rows_per_unit <= 0 || rows % rows_per_unit != 0 || rows_per_block < 0) return 0;
     int units, splits, rpb;
     gn_stats_geometry(rows, rows_per_unit, rows_per_block, &units, &splits, &rpb);
-    return (int64_t)units * splits * (GROUPS * 2);
+    const int nparts = (splits + GN_PART - 1) / GN_PART;
+    return (int64_t)units * splits * (GROUPS * 2) + (int64_t)units * nparts * (GROUPS * 4);
 }
 
-extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
-                                   int rows_per_unit, int rows_per_block_in, float* stats, float* scratch) {
-    WIW_REQUIRE(X1 && stats && scratch, "groupnorm_stats: null pointer");
+extern "C" int64_t wiw_groupnorm_counters(int64_t rows, int rows_per_unit, int rows_per_block) {
+    if (rows <= 0 || rows_per_unit <= 0 || rows % rows_per_unit != 0 || rows_per_block < 0) return 0;
+    int units, splits, rpb;
+    gn_stats_geometry(rows, rows_per_unit, rows_per_block, &units, &splits, &rpb);
+    return (int64_t)units * ((splits + GN_PART - 1) / GN_PART + 1);
+}
+
+namespace {
+template <bool F32IN>
+int gn_stats_launch(const char* what, void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                    int rows_per_unit, int rows_per_block_in, float* stats, float* scratch, unsigned* counters) {
+    WIW_REQUIRE(X1 && stats && scratch && counters, "groupnorm_stats: null pointer");
     WIW_REQUIRE(rows_per_block_in >= 0, "groupnorm_stats: rows_per_block must be >= 0 (0 = default)");
     WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_stats: X2 iff C2 > 0");
     const int C = C1 + C2;
@@ -486,29 +583,23 @@ extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const v
     WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats: bad rows");
     int units, splits, rows_per_block;
     gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
-    hipLaunchKernelGGL(gn_stats_kernel<false>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, X1, C1, X2, C2,
-                       rows_per_unit, rows_per_block, scratch);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits,
-                       rows_per_unit, rows_per_block, C / GROUPS, stats);
-    return wiw_check_launch("wiw_groupnorm_stats");
+    hipLaunchKernelGGL(gn_stats_kernel<F32IN>, dim3(splits, units), dim3(256), (size_t)C * 2 * sizeof(float),
+                       (hipStream_t)stream, X1, C1, X2, C2, rows_per_unit, rows_per_block, scratch, counters, stats);
+    return wiw_check_launch(what);
+}
+}  // namespace
+
+extern "C" int wiw_groupnorm_stats(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows,
+                                   int rows_per_unit, int rows_per_block_in, float* stats, float* scratch, unsigned* counters) {
+    return gn_stats_launch<false>("wiw_groupnorm_stats", stream, X1, C1, X2, C2, rows, rows_per_unit, rows_per_block_in, stats,
+                                  scratch, counters);
 }
 
 extern "C" int wiw_groupnorm_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
-                                         int rows_per_unit, int rows_per_block_in, float* stats, float* scratch) {
-    WIW_REQUIRE(X1 && stats && scratch, "groupnorm_stats_f32in: null pointer");
-    WIW_REQUIRE(rows_per_block_in >= 0, "groupnorm_stats_f32in: rows_per_block must be >= 0 (0 = default)");
-    WIW_REQUIRE((C2 == 0) == (X2 == nullptr), "groupnorm_stats_f32in: X2 iff C2 > 0");
-    const int C = C1 + C2;
-    WIW_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 % 8 == 0 && C % GROUPS == 0 && C <= GN_MAXC,
-                "groupnorm_stats_f32in: channels must be %8, C %32 and C <= 4096");
-    WIW_REQUIRE(rows > 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, "groupnorm_stats_f32in: bad rows");
-    int units, splits, rows_per_block;
-    gn_stats_geometry(rows, rows_per_unit, rows_per_block_in, &units, &splits, &rows_per_block);
-    hipLaunchKernelGGL(gn_stats_kernel<true>, dim3(splits, units), dim3(256), 0, (hipStream_t)stream, (const void*)X1, C1,
-                       (const void*)X2, C2, rows_per_unit, rows_per_block, scratch);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(units), dim3(64 * GN_RED_PARTS), 0, (hipStream_t)stream, scratch, splits,
-                       rows_per_unit, rows_per_block, C / GROUPS, stats);
-    return wiw_check_launch("wiw_groupnorm_stats_f32in");
+                                         int rows_per_unit, int rows_per_block_in, float* stats, float* scratch,
+                                         unsigned* counters) {
+    return gn_stats_launch<true>("wiw_groupnorm_stats_f32in", stream, X1, C1, X2, C2, rows, rows_per_unit, rows_per_block_in,
+                                 stats, scratch, counters);
 }
 
 extern "C" int wiw_groupnorm_finalize(void* stream, const float* stats, const float* gamma, const float* beta,

@@ -111,7 +111,7 @@ EXPORTS = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "wiw_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "wiw_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
-                                      C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "wiw_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_float, C.c_void_p]),
     "wiw_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
@@ -121,7 +121,8 @@ EXPORTS = {
     "wiw_layernorm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wiw_groupnorm_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
-                                            C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wiw_groupnorm_counters": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "wiw_groupnorm_apply_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "wiw_layernorm_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -199,7 +200,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 11:
+        if self.lib.wiw_abi_version() != 12:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -219,6 +220,7 @@ class Hip:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
         self._splitk_ws = None
+        self._gn_cnt = torch.zeros(65536, dtype=torch.int32, device=self.device)    # see _gn_buffers
         # ... and this one for the non-GEMM kernels: (start_event, end_event, family, algorithmic_flops, algorithmic_bytes)
         self.kernel_profile = None
 
@@ -361,11 +363,16 @@ class Hip:
         return rpb
 
     def _gn_buffers(self, rows, rows_per_unit, rpb):
-        """(stats [units*64], scratch) — both fully written by wiw_groupnorm_stats (deterministic two-stage reduction)."""
+        """(stats [units*64], scratch, counters) of wiw_groupnorm_stats.  stats / scratch are fully written by the call
+        (deterministic two-level reduction inside the statistics launch).  counters: zero before the first call, left at
+        zero by every call — ONE buffer per Hip, made at construction (never inside a graph capture): the GroupNorm
+        launches of a Hip are stream-ordered (one request at a time per GPU; the capture's warm-up stream is joined
+        before the capture starts)."""
         units = rows // rows_per_unit
         n = int(self.lib.wiw_groupnorm_scratch_floats(rows, rows_per_unit, rpb))
+        assert int(self.lib.wiw_groupnorm_counters(rows, rows_per_unit, rpb)) <= self._gn_cnt.numel(), "groupnorm: more parts than counters"
         buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
-        return buf[: units * 64], buf[units * 64:]
+        return buf[: units * 64], buf[units * 64:], self._gn_cnt
 
     def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False, raw16=None):
         """statistics (deterministic, no atomics) -> fused finalize + apply; returns the normalised (and SiLU'd) bf16
@@ -379,21 +386,20 @@ class Hip:
             return self.groupnorm_unfused(X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out, clip)
         Ct = C1 + C2
         rpb = self.gn_rows_per_block(rows_per_unit, clip)
-        stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
+        stats, scratch, cnt = self._gn_buffers(rows, rows_per_unit, rpb)
         if out is None:
             out = torch.empty((rows, Ct), dtype=self.dtype, device=self.device)
         s = self._stream()
 
         def launch():
+            fn = self.lib.wiw_groupnorm_stats_f32in if f32in else self.lib.wiw_groupnorm_stats
+            self._ck(fn(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(), scratch.data_ptr(), cnt.data_ptr()),
+                     "wiw_groupnorm_stats")
             if f32in:
-                self._ck(self.lib.wiw_groupnorm_stats_f32in(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
-                                                            scratch.data_ptr()), "wiw_groupnorm_stats_f32in")
                 self._ck(self.lib.wiw_groupnorm_apply_stats_f32in(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
                                                                   _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr(),
                                                                   _p(raw16)), "wiw_groupnorm_apply_stats_f32in")
                 return
-            self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
-                                                  scratch.data_ptr()), "wiw_groupnorm_stats")
             self._ck(self.lib.wiw_groupnorm_apply_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, stats.data_ptr(),
                                                         _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr()),
                      "wiw_groupnorm_apply_stats")
@@ -407,13 +413,13 @@ class Hip:
         Ct = C1 + C2
         units = rows // rows_per_unit
         rpb = self.gn_rows_per_block(rows_per_unit, clip)
-        stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
+        stats, scratch, cnt = self._gn_buffers(rows, rows_per_unit, rpb)
         ab = torch.empty(units * 2 * Ct, dtype=torch.float32, device=self.device)
         if out is None:
             out = torch.empty((rows, Ct), dtype=self.dtype, device=self.device)
         s = self._stream()
         self._ck(self.lib.wiw_groupnorm_stats(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, rpb, stats.data_ptr(),
-                                              scratch.data_ptr()), "wiw_groupnorm_stats")
+                                              scratch.data_ptr(), cnt.data_ptr()), "wiw_groupnorm_stats")
         self._ck(self.lib.wiw_groupnorm_finalize(s, stats.data_ptr(), _p(gamma), _p(beta), units, Ct, rows_per_unit,
                                                  eps, ab.data_ptr()), "wiw_groupnorm_finalize")
         self._ck(self.lib.wiw_groupnorm_apply(s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, ab.data_ptr(),
@@ -543,9 +549,9 @@ class Hip:
         units = rows // rows_per_unit
         if stats is None:
             rpb = self.gn_rows_per_block(rows_per_unit, False)
-            stats, scratch = self._gn_buffers(rows, rows_per_unit, rpb)
+            stats, scratch, cnt = self._gn_buffers(rows, rows_per_unit, rpb)
             self._ck(self.lib.wiw_groupnorm_stats(self._stream(), _p(X), Cn, None, 0, rows, rows_per_unit, rpb, stats.data_ptr(),
-                                                  scratch.data_ptr()), "wiw_groupnorm_stats")
+                                                  scratch.data_ptr(), cnt.data_ptr()), "wiw_groupnorm_stats")
         # rows per block: enough (row split, unit) blocks for ~4 per CU, at least 64 rows each (the per-chunk constants are
         # loaded once per thread; the finish pass sums the splits)
         rpb_b = max(64, min(256, (rows_per_unit * units) // 1024))
