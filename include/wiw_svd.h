@@ -46,7 +46,7 @@ extern "C" {
                                  stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
                                  wiw_cast_f32_to_16, wiw_calib_mfma;
                              12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
-                                 statistics launch (wiw_groupnorm_counters) */
+                                 statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok */
 
 int wiw_abi_version(void);
 
@@ -125,7 +125,16 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
         * through the 4-MiB L2 before the next tap touches it again, and the PMC FETCH_SIZE of the 3x3 convolutions was 9x
         * their algorithmic reads (1.39 GB per launch at 2.4 TB/s).  The fused shortcut segment (C2 + C3) stays behind the
         * taps.  Pure permutation of K: the host re-orders W (`unet.py`), results differ only by fp32 summation order. */
-       WIW_K_CMAJOR = 512 };
+       WIW_K_CMAJOR = 512,
+       /* WIW_A_CONV3X3 only, ABI 12: HALO-STAGED A operand.  K index of W (and of the kernel's walk) in 32-channel blocks,
+        *     k = ((c / 32) * 9 + tap) * 32 + c % 32,
+        * and the kernel (256x320 tile) stages, per 32-channel block, the (R + 2) x (Wd + 2) pixel neighbourhood of its
+        * R = 256 / Wd image rows in LDS ONCE; the nine taps are nine shifted reads of that image instead of nine LDS-DMA
+        * fetches of a [256][64]-element tile (1/9 of the A bytes through the DMA + the halo).  Geometry the kernel takes
+        * (wiw_conv_halo_ok; anything else is refused — W's K order belongs to this kernel, the caller keeps a second copy
+        * of W in one of the other orders for other geometries): Wd = 64 or 128, (H * Wd) % 256 == 0, M % 256 == 0,
+        * C2 == C3 == 0, K = 9 * C1, W tiled (WIW_W_TILED), 16-bit output through the staged epilogue, no split-K. */
+       WIW_K_HALO32 = 1024 };
 
 typedef struct WiwGemmArgs {
     const void* A;       /* bf16 [rows_in][C1] */
@@ -156,6 +165,8 @@ typedef struct WiwGemmArgs {
 } WiwGemmArgs;
 
 int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args);
+/* 1 when `args` (with WIW_K_HALO32 set) is a launch the halo-staged convolution kernel takes, else 0 (no launch). */
+int wiw_conv_halo_ok(const WiwGemmArgs* args);
 
 /* ------------------------------------------------------------------------------------------------
  * Spatial self-attention, head_dim 64, flash-style (online softmax, fp32 statistics):

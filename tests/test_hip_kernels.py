@@ -823,3 +823,51 @@ def test_conv_modes_with_channel_block_major_k(hip):
         check(out, ref, what=f"K-cmajor temporal conv splitk={sk}")
     with pytest.raises(RuntimeError, match="convolution-mode"):
         hip.gemm(dev_bf(tok), wk3, out, M=M, N=c, K=3 * c, C1=3 * c, epilogue=H.K_CMAJOR)
+
+
+@pytest.mark.gpu
+def test_conv3x3_halo_staged_kernel(hip):
+    """WIW_K_HALO32 (include/wiw_svd.h): the 3x3 convolution whose A operand is a halo image per 32-channel block, read at nine
+    pixel offsets.  Against fp32 torch and against the per-tap launch of the same problem (summation order only), at both
+    widths the kernel takes, one and several tiles per frame, frames that start inside a grid round, one and two N tiles,
+    1 / 3 / 10 channel-block pairs, with bias, the per-frame vector, a residual and alpha; the image border (zero padding)
+    is every tile's first / last row and column.  Geometry outside the kernel's is refused, not re-routed."""
+    from wiw_amd import hip as H
+    from wiw_amd.unet import conv_k_cmajor, conv_k_halo32
+
+    for (n, c, cout, h, w, extras) in [(2, 64, 320, 4, 64, False), (3, 192, 320, 2, 128, True), (2, 128, 640, 8, 64, True),
+                                       (5, 64, 320, 12, 64, False), (28, 320, 320, 36, 64, True), (3, 640, 640, 4, 128, True)]:
+        x = bf(rnd(n, c, h, w, seed=1))
+        wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+        b = rnd(cout, seed=6)
+        M = n * h * w
+        assert H.Hip.conv_halo_ok(M, cout, c, h, w)
+        w_tap = wt.permute(0, 2, 3, 1).reshape(cout, -1)
+        kw = dict(M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+        ref = F.conv2d(x, wt, b, padding=1)
+        if extras:
+            vec = rnd(n, cout, seed=7)
+            res = bf(rnd(n, cout, h, w, seed=8))
+            kw.update(rowvec=dev_f(vec), rowvec_ld=cout, rows_per_vec=h * w, res1=dev_bf(nhwc(res)), ldr1=cout, beta1=1.0, alpha=0.75)
+            ref = 0.75 * (ref + vec[:, :, None, None]) + res
+        o_h = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+        o_t = torch.empty_like(o_h)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(w_tap))), o_h, epilogue=H.K_HALO32, **kw)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_cmajor(w_tap, 9))), o_t, epilogue=H.K_CMAJOR, **kw)
+        check(from_nhwc(o_h, n, h, w), ref, what=f"halo conv3x3 {c}->{cout} {n}x{h}x{w}")
+        d = (o_h.float() - o_t.float()).cpu()
+        rms = float(d.pow(2).mean().sqrt() / o_t.float().pow(2).mean().sqrt().cpu())
+        print(f"[halo] conv3x3 {c}->{cout} {n}x{h}x{w}: rms vs the per-tap kernel {rms:.2e}")
+        assert rms <= 2e-3, "halo-staged and per-tap launches differ by more than the summation order"
+        o2 = torch.empty_like(o_h)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(w_tap))), o2, epilogue=H.K_HALO32, **kw)
+        assert torch.equal(o2, o_h), "halo-staged launch is not deterministic"
+    # outside the geometry: refused (W's K order belongs to this kernel)
+    n, c, cout, h, w = 2, 64, 320, 8, 32
+    x = bf(rnd(n, c, h, w, seed=1))
+    wt = bf(rnd(cout, c, 3, 3, seed=4))
+    out = torch.empty(n * h * w, cout, dtype=torch.bfloat16, device=DEV)
+    assert not H.Hip.conv_halo_ok(n * h * w, cout, c, h, w)
+    with pytest.raises(RuntimeError, match="HALO32"):
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(wt.permute(0, 2, 3, 1).reshape(cout, -1)))), out, M=n * h * w,
+                 N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, epilogue=H.K_HALO32)

@@ -37,6 +37,8 @@ def main():
         bias = torch.randn(N, device=dev)
         if mode and os.environ.get("KCMAJOR"):      # channel-block-major K walk (random weights: no re-ordering needed for timing)
             epi |= H.K_CMAJOR
+        if mode == 1 and os.environ.get("HALO"):    # halo-staged 3x3 kernel (needs TILED=1 and the served geometry below)
+            epi |= H.K_HALO32
         kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi, splitk=int(os.environ.get("SPLITK", "1")))
         if mode:
             frames = 28 if M % 28 == 0 else 1
@@ -44,6 +46,8 @@ def main():
             h = int(math.sqrt(hw / 2)) if mode != 4 else 1
             while hw % h:
                 h -= 1
+            if os.environ.get("SERVED") and mode != 4:     # the served latent geometry: 72 x 128 / 36 x 64 / 18 x 32 / 9 x 16
+                h = {9216: 72, 2304: 36, 576: 18, 144: 9}.get(hw, h)
             kw.update(H=h, Wd=hw // h, T=14 if frames % 14 == 0 else 1)
         if epi & H.EPI_GEGLU:
             out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)

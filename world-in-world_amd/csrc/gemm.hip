@@ -1171,6 +1171,8 @@ extern "C" int wiw_gemm_bf16(void* stream, const WiwGemmArgs* args) {
     }
     if (a.epilogue & WIW_K_CMAJOR)
         WIW_REQUIRE(a.mode != WIW_A_DENSE, "gemm: WIW_K_CMAJOR is a convolution-mode K order");
+    if (a.epilogue & WIW_K_HALO32)      // W's K order belongs to one kernel: checked and launched there, no other tile takes it
+        return wiw_gemm_huge_launch((hipStream_t)stream, a);
     if (a.splitk > 1) {
         WIW_REQUIRE(a.workspace != nullptr, "gemm: split-K needs a workspace of splitk * M * N floats");
         WIW_REQUIRE((a.K / 64) % a.splitk == 0, "gemm: split-K needs K / 64 divisible by splitk");

@@ -46,6 +46,17 @@ constexpr int HSTG_ROWB_G = 176;                 // GEGLU: 80 output cols + 16 B
 constexpr int HSTG_WAVE = 32 * HSTG_ROWB_G;      // 5632 B per wave (plain: 16 rows x 336 B = 5376)
 static_assert(16 * HSTG_ROWB <= HSTG_WAVE, "");
 static_assert(8 * HSTG_WAVE <= HSTAGE, "epilogue staging must fit in one ring stage");
+// HALO instantiation (3x3 convolution, round 4): the A operand is NOT fetched per tap.  A 256-row tile is R = 256 / Wd whole
+// image rows; per 32-channel block the (R + 2) x (Wd + 2) pixel neighbourhood is staged ONCE ([halo pixel][32 ch = 64 B],
+// pitch = Wd + 2 rounded up to 16 pixels, 16-byte chunks XOR-swizzled by (pixel >> 1) & 3: conflict-free for the 16-lane
+// groups of ds_read_b128 at any tap offset) and the nine taps read it at pixel offsets dy * pitch + dx.  1/9 of the A
+// bytes through the LDS-DMA (+ the halo): the ablation that fetched the A tile for the centre tap only ran the long-K
+// convolutions 19-29 % faster (profiles/r10c_conv_a_dma_ablation.txt) — the fill rate of 128-byte row segments
+// (25 B/clk/CU) is a first-order cost of this loop.  K walk: k = ((c / 32) * 9 + tap) * 32 + c % 32 (WIW_K_HALO32; a K tile
+// is two taps of one 32-channel block).  LDS: 2 W stages of 40 KiB + 2 halo buffers of 36 KiB = 152 KiB.
+constexpr int HALO_BUF = 36864;                  // 4 x 144 pixels (Wd = 128) / 6 x 80 pixels (Wd = 64) x 64 B
+constexpr int HALO_SMEM = 2 * HB_BYTES + 2 * HALO_BUF;
+static_assert(4 * HSTG_WAVE <= HB_BYTES && 4 * HSTG_WAVE <= HALO_BUF, "HALO epilogue staging: 4 waves per free region");
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -88,8 +99,11 @@ WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   
     return WiwKCur{ld_tap, ld_cc};
 }
 
-template <int MODE, bool GE, bool SK>
+template <int MODE, bool GE, bool SK, bool HALO = false>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
+    static_assert(!HALO || (MODE == WIW_A_CONV3X3 && !GE && !SK), "the halo-staged A operand is a plain 3x3 convolution");
+    constexpr int WSTAGE = HALO ? HB_BYTES : HSTAGE;          // bytes per ring stage
+    constexpr int WOFF = HALO ? 0 : HA_BYTES;                 // offset of the W tile inside a stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     int lane = tid & 63;
@@ -257,10 +271,18 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     auto issue_part = [&](int stage, auto part_tag) {
         constexpr int part = decltype(part_tag)::value;
         char* sA = smem + stage * HSTAGE + wave * 4 * 1024;
-        char* sB = smem + stage * HSTAGE + HA_BYTES + wave * 5 * 1024;
-        if constexpr (part < 2) {
+        char* sB = smem + stage * WSTAGE + WOFF + wave * 5 * 1024;
+        if constexpr (HALO && part < 2) {
+            // (the halo instantiation has no per-tap A tile: issue_halo below)
+        } else if constexpr (part < 2) {
+#if WIW_ABLATE == 30   // timing experiment only (wrong results): the A tile of a 3x3 convolution is fetched for the centre tap
+                       // alone = the LDS-DMA instruction count of a halo-staged A operand (1 of 9 A tiles per channel block)
+            if (MODE != WIW_A_CONV3X3 || ld_tap == 4 || ld_tap == 9)
+#endif
+            {
             glds16(a_src(2 * part, ld_tap, ld_cc), sA + (2 * part) * 1024);
             glds16(a_src(2 * part + 1, ld_tap, ld_cc), sA + (2 * part + 1) * 1024);
+            }
         } else if constexpr (part < 4) {
             constexpr int i = 2 * (part - 2);
             glds16(w_row[i] + (int64_t)ld_kt * w_kstep, sB + i * 1024);
@@ -276,9 +298,66 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         issue_part(stage, IC<3>{}); issue_part(stage, IC<4>{});
     };
 
+    // ---- HALO: geometry (uniform), the DMA instruction -> halo position map of this wave, the tap cursor
+    char* const halo0 = smem + 2 * HB_BYTES;
+    const int h_ipr = HALO ? (p.Wd + 2 + 15) >> 4 : 1;          // DMA instructions (16 pixels x 64 B) per halo row
+    const int h_P = h_ipr * 16;                                  // halo pitch in pixels
+    const int h_ninstr = HALO ? (256 / p.Wd + 2) * h_ipr : 0;    // <= 36
+    const int h_nblk = p.C1 >> 5;                                // 32-channel blocks
+    const int h_rowbase = HALO ? ((wm * 64) / p.Wd + 1) * h_P + (wm * 64) % p.Wd + 1 : 0;   // halo pixel of this wave's row 0, tap (0, 0)
+    int h_hy[5], h_jx[5];                                        // instruction j = wave + 8 i of a block: halo row, 16-pixel column
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const int j = wave + 8 * i; h_hy[i] = j / h_ipr; h_jx[i] = j - h_hy[i] * h_ipr; }
+    int h_tap = 0, h_blk = 0, h_next = 1, h_tile = 0;
+    // instruction i of this wave for 32-channel block b of the tile whose first row is m0t (first image row y0t)
+    auto issue_halo = [&](int m0t, int y0t, int b, auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        const int j = wave + 8 * i;
+        if (j >= h_ninstr) return;
+        const int iy = y0t - 1 + h_hy[i];
+        const int ix = h_jx[i] * 16 + (lane >> 2) - 1;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+        const int csrc = (lane & 3) ^ ((lane >> 3) & 3);        // LDS chunk (lane & 3) of pixel hp holds source chunk ^ ((hp >> 1) & 3)
+        const char* src = ok ? Ab + (((int64_t)m0t + (h_hy[i] - 1) * p.Wd + ix) * p.C1 + b * 32 + csrc * 8) * 2 : zeros;
+        glds16(src, halo0 + (b & 1) * HALO_BUF + j * 1024);
+    };
+    auto tile_y0 = [&](int m0t) { return (m0t % HW) / p.Wd; };
+    auto issue_halo_all = [&](int m0t, int y0t, int b) {
+        issue_halo(m0t, y0t, b, IC<0>{}); issue_halo(m0t, y0t, b, IC<1>{}); issue_halo(m0t, y0t, b, IC<2>{});
+        issue_halo(m0t, y0t, b, IC<3>{}); issue_halo(m0t, y0t, b, IC<4>{});
+    };
+    // DMA of slot `sl` (0..4) of a K tile: the five parts of the next K tile; HALO: its 5 W instructions in slots 0..2 and,
+    // in the tile where block h_next may be fetched (hdo), that block's <= 5 halo instructions in slots 2..4
+    auto issue_slot = [&](int si, auto slot_tag, bool more, bool hdo, int m0t, int y0t) {
+        constexpr int sl = decltype(slot_tag)::value;
+        if constexpr (!HALO) {
+            if (more) issue_part(si, IC<sl>{});
+        } else {
+            if (more) {
+                if constexpr (sl == 0) issue_part(si, IC<2>{});
+                else if constexpr (sl == 1) issue_part(si, IC<3>{});
+                else if constexpr (sl == 2) issue_part(si, IC<4>{});
+            }
+            if (hdo) {
+                if constexpr (sl == 2) issue_halo(m0t, y0t, h_next, IC<0>{});
+                else if constexpr (sl == 3) { issue_halo(m0t, y0t, h_next, IC<1>{}); issue_halo(m0t, y0t, h_next, IC<2>{}); }
+                else if constexpr (sl == 4) { issue_halo(m0t, y0t, h_next, IC<3>{}); issue_halo(m0t, y0t, h_next, IC<4>{}); }
+            }
+        }
+    };
+
     f32x4 acc[4][10];
     bf16x8 fa[4], fb[5];
+    auto read_a_halo = [&]() {   // the A fragments of the next 32-deep k-step: tap h_tap of block h_blk
+        const int dy = h_tap / 3 - 1, dx = h_tap - (h_tap / 3) * 3 - 1;
+        const int hp = h_rowbase + dy * h_P + dx + frow;
+        const char* sA = halo0 + (h_blk & 1) * HALO_BUF + hp * 64 + ((fq ^ ((hp >> 1) & 3)) << 4);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 1024);
+        if (++h_tap == 9) { h_tap = 0; ++h_blk; }
+    };
     auto read_a = [&](int stage, int kk) {
+        if constexpr (HALO) { read_a_halo(); return; }
         const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
         const char* sA = smem + stage * HSTAGE + (wm * 64 + frow) * 128 + sw;
 #pragma unroll
@@ -287,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     auto read_b = [&](int stage, int kk, auto h_tag) {
         constexpr int h = decltype(h_tag)::value;
         const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
-        const char* sB = smem + stage * HSTAGE + HA_BYTES + (wn * 160 + h * 80 + frow) * 128 + sw;
+        const char* sB = smem + stage * WSTAGE + WOFF + (wn * 160 + h * 80 + frow) * 128 + sw;
 #pragma unroll
         for (int j = 0; j < 5; ++j) fb[j] = *(const bf16x8*)(sB + j * 2048);
     };
@@ -338,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     int st_c = 0;
     int pending_stores = 0;   // 0 / 10 (GEGLU) / 24
     issue_all(0);
+    if constexpr (HALO) { const int m0f = (t / Nt) * HM; issue_halo_all(m0f, tile_y0(m0f), 0); }
 
     while (t >= 0) {
         const int tile_n = t % Nt;
@@ -345,6 +425,8 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         const int64_t out_slab = SK ? (int64_t)((t / Nt) / Mt1) * p.M * p.ldo : 0;
         rederive();
         setup_loader(t);
+        const int y0 = HALO ? tile_y0(m0) : 0;
+        h_tap = 0; h_blk = 0; h_next = 1; h_tile = 0;       // (HALO) block 0 was fetched with K tile 0; block 1 may go at once
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -365,33 +447,38 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
             const int si = st_c ^ 1;
+            // HALO: block h_next goes into the buffer of block h_next - 2, whose last k-step (9 h_next - 10) was read in K
+            // tile (9 h_next - 10) / 2 — every wave is past that read once it has passed this tile's first barrier (same
+            // argument as for the ring stage below) — and is confirmed with this tile's vmcnt(0), long before its first use
+            const bool hdo = HALO && h_next < h_nblk && kt == h_tile;
             slot_barrier();                                    // 8kt
 #if WIW_DMA_BURST
             // a slot that issues ANY LDS-DMA pays ~180 cycles once, further instructions ~25 each (tools/trace_probe.py)
             if (more) issue_all(si);
+            if (HALO && hdo) issue_halo_all(m0, y0, h_next);
 #else
-            if (more) issue_part(si, IC<0>{});
+            issue_slot(si, IC<0>{}, more, hdo, m0, y0);
 #endif
             read_a(st_c, 0);
             read_b(st_c, 0, IC<0>{});
             slot_barrier();                                    // +1
 #if !WIW_DMA_BURST
-            if (more) issue_part(si, IC<1>{});
+            issue_slot(si, IC<1>{}, more, hdo, m0, y0);
 #endif
             mma(IC<0>{});
             slot_barrier();                                    // +2
 #if !WIW_DMA_BURST
-            if (more) issue_part(si, IC<2>{});
+            issue_slot(si, IC<2>{}, more, hdo, m0, y0);
 #endif
             read_b(st_c, 0, IC<1>{});
             slot_barrier();                                    // +3
 #if !WIW_DMA_BURST
-            if (more) issue_part(si, IC<3>{});
+            issue_slot(si, IC<3>{}, more, hdo, m0, y0);
 #endif
             mma(IC<1>{});
             slot_barrier();                                    // +4
 #if !WIW_DMA_BURST
-            if (more) issue_part(si, IC<4>{});
+            issue_slot(si, IC<4>{}, more, hdo, m0, y0);
 #endif
             read_a(st_c, 1);
             read_b(st_c, 1, IC<0>{});
@@ -406,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             slot_barrier();                                    // +7
             mma(IC<1>{});
             st_c ^= 1;
+            if (HALO && hdo) { ++h_next; h_tile = (9 * h_next - 10) / 2 + 1; }
         }
         if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
 
@@ -458,7 +546,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         // per-wave staging area: in the ring stage that held the LAST K tile (every wave has finished reading it: the
         // lagging group passed its last read before the leading group's closing barrier); the next tile's first K tile
         // goes to the other stage
-        char* const stg = smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE;
+        // (HALO: the free W stage holds the staging areas of waves 0..3, halo buffer 1 — the last block's, never the target of
+        // the next tile's first fetch — those of waves 4..7)
+        char* const stg = !HALO ? smem + (st_c ^ 1) * HSTAGE + wave * HSTG_WAVE
+                                : (wave < 4 ? smem + (st_c ^ 1) * HB_BYTES + wave * HSTG_WAVE
+                                            : halo0 + HALO_BUF + (wave - 4) * HSTG_WAVE);
         // plain path, step (a) of a 16-row pass: fragment layout -> 16-bit rows in LDS (lane owns row frow, columns
         // 16*ni + 4*fq .. +3).  Pass 0 is staged BEFORE the epilogue's global loads are issued: its 40 accumulator
         // registers are free by the time the 40 registers of bias / per-frame vector / residual rows arrive (with the loads
@@ -499,6 +591,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             setup_loader(t_next);
             reset_loader(t_next);
             issue_all(st_c);            // stage st_c is free (it held K tile nk-2); staging uses the other one
+            if constexpr (HALO) { const int m0n = (t_next / Nt) * HM; issue_halo_all(m0n, tile_y0(m0n), 0); }
         }
         pending_stores = 0;
 
@@ -657,14 +750,15 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 }
 
-template <int MODE, bool GE, bool SK>
+template <int MODE, bool GE, bool SK, bool HALO = false>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
+    constexpr int SMEM = HALO ? HALO_SMEM : H_SMEM;
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
     static std::once_flag once;
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -680,7 +774,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     static const char* sn_env = getenv("WIW_GEMM_SN");
     const int stagger = ((stg_env ? atoi(stg_env) : 0) & 255) | ((sn_env ? atoi(sn_env) & 15 : 0) << 8);
-    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK>), dim3((unsigned)grid), dim3(512), H_SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK, HALO>), dim3((unsigned)grid), dim3(512), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }
 
@@ -716,8 +810,33 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     return true;
 }
 
+// WIW_K_HALO32 launches (include/wiw_svd.h): geometry and epilogue the HALO instantiation takes
+bool wiw_conv_halo_shape_ok(const WiwGemmArgs& a) {
+    if (a.mode != WIW_A_CONV3X3 || !(a.epilogue & WIW_K_HALO32) || !(a.epilogue & WIW_W_TILED)) return false;
+    if (a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 |
+                      WIW_EPI_RES2_F32 | WIW_EPI_LNFOLD | WIW_K_CMAJOR)) return false;
+    if (a.splitk > 1 || a.C2 != 0 || a.C3 != 0 || a.A2 != nullptr || a.A3 != nullptr) return false;
+    if (a.C1 % 64 != 0 || a.K != 9 * a.C1) return false;
+    if ((a.Wd != 64 && a.Wd != 128) || a.H <= 0 || ((int64_t)a.H * a.Wd) % HM != 0 || a.M % HM != 0) return false;
+    if (a.N % 8 || a.ldo % 8) return false;
+    if (a.res1 && a.ldr1 % 8) return false;
+    if (a.res2 && a.ldr2 % 8) return false;
+    if ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) || a.rowvec_ld % 4) return false;
+    if (a.N % HN != 0) return false;
+    return true;
+}
+
+extern "C" int wiw_conv_halo_ok(const WiwGemmArgs* args) { return args != nullptr && wiw_conv_halo_shape_ok(*args) ? 1 : 0; }
+
 int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
+    if (a.epilogue & WIW_K_HALO32) {
+        if (!wiw_conv_halo_shape_ok(a)) {
+            wiw_set_error("gemm: WIW_K_HALO32 launch outside the halo kernel's geometry (wiw_conv_halo_ok)");
+            return WIW_EINVAL;
+        }
+        return launch_huge<WIW_A_CONV3X3, false, false, true>(s, a);
+    }
     if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)
         switch (a.mode) {
             case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, true>(s, a);

@@ -21,6 +21,7 @@ EPI_GEGLU, EPI_SILU, EPI_OUT_F32, EPI_GELU, EPI_QUICK_GELU = 1, 2, 4, 8, 16
 W_TILED = 32     # epilogue bit: W is pre-tiled for the LDS-DMA stream (include/wiw_svd.h)
 EPI_LNFOLD = 64  # epilogue bit: A is the raw LayerNorm input, W = W * gamma, lnfold = [s | t] (include/wiw_svd.h)
 EPI_RES1_F32, EPI_RES2_F32 = 128, 256   # epilogue bits: res1 / res2 are fp32 (the fp32 residual stream, ABI 11)
+K_HALO32 = 1024  # conv3x3: halo-staged A operand, k = ((c / 32) * 9 + tap) * 32 + c % 32 (include/wiw_svd.h, conv_halo_ok below)
 K_CMAJOR = 512   # conv modes: K of W is channel-block major, k = ((c / 64) * taps + tap) * 64 + c % 64 (include/wiw_svd.h)
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
@@ -123,6 +124,7 @@ EXPORTS = {
     "wiw_groupnorm_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "wiw_groupnorm_counters": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "wiw_conv_halo_ok": (C.c_int, [C.c_void_p]),
     "wiw_groupnorm_apply_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "wiw_layernorm_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -249,6 +251,12 @@ class Hip:
             raise RuntimeError(f"{what} failed ({rc}): {self.lib.wiw_last_error().decode()}")
 
     # ---- operators
+    @staticmethod
+    def conv_halo_ok(M: int, N: int, C1: int, H: int, Wd: int) -> bool:
+        """Geometry the halo-staged 3x3 convolution kernel takes (WIW_K_HALO32; the C side re-checks: wiw_conv_halo_ok):
+        a 256-row tile is whole image rows of one frame."""
+        return Wd in (64, 128) and (H * Wd) % 256 == 0 and M % 256 == 0 and C1 % 64 == 0 and N % 320 == 0
+
     def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, A3=None, C3=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
              rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,
              ldo=None, epilogue=0, n_out=0, splitk=1, lnfold=None, ln_eps=1e-5):

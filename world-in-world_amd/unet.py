@@ -28,7 +28,7 @@ import torch
 
 from .config import UNetConfig
 from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI_GEGLU, EPI_OUT_F32, EPI_SILU,
-                  FFN_C, FFN_CHUNK, FFN_HIDDEN, GEGLU_TILE, K_CMAJOR, Hip, TiledW, tile_weight)
+                  FFN_C, FFN_CHUNK, FFN_HIDDEN, GEGLU_TILE, K_CMAJOR, K_HALO32, Hip, TiledW, tile_weight)
 from .weights import validate_state_dict
 
 CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
@@ -59,6 +59,15 @@ def conv_k_cmajor(w: torch.Tensor, taps: int) -> torch.Tensor:
     C = K // taps
     assert K == taps * C and C % 64 == 0
     return w.reshape(N, taps, C // 64, 64).permute(0, 2, 1, 3).reshape(N, K).contiguous()
+
+
+def conv_k_halo32(w: torch.Tensor) -> torch.Tensor:
+    """[N, 9 * C] (k = tap * C + c) -> K in 32-channel blocks, k = ((c / 32) * 9 + tap) * 32 + c % 32 (WIW_K_HALO32): the K
+    order of the halo-staged 3x3 convolution kernel, whose K tile is two taps of one 32-channel block."""
+    N, K = w.shape
+    C = K // 9
+    assert K == 9 * C and C % 64 == 0
+    return w.reshape(N, 9, C // 32, 32).permute(0, 2, 1, 3).reshape(N, K).contiguous()
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, tile: int = GEGLU_TILE):
@@ -160,6 +169,7 @@ class UNetHIP:
         # convolution weights with K in channel-block-major order (round 4: the taps of a 64-channel block re-read the same
         # activation window while it is still in L2; A/B knob WIW_K_TAPMAJOR=1 keeps the tap-major order)
         self.kc = 0 if os.environ.get("WIW_K_TAPMAJOR") else K_CMAJOR
+        self.halo = not os.environ.get("WIW_CONV_NO_HALO")      # A/B knob: 3x3 convolutions without the halo-staged kernel
         self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not self.res32
         self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
         self._prepare(state_dict)
@@ -196,6 +206,10 @@ class UNetHIP:
             x = x.reshape(x.shape[0], -1)
             w[p + ".weight"] = (conv_k_cmajor(x, 9) if self.kc else x).to(bf).contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
+            # a second copy in the K order of the halo-staged kernel for the layers of the two outer levels (N = 320 / 640
+            # at the served widths): `_conv3` picks it when the request's geometry fits (hip.conv_halo_ok), else the copy above
+            if self.halo and x.shape[0] in (320, 640) and x.shape[1] % (9 * 64) == 0:
+                w[p + ".weight_h"] = conv_k_halo32(x).to(bf).contiguous()
 
         def convt(p):
             x = self._t(sd, p + ".weight")[:, :, :, 0, 0].permute(0, 2, 1)  # (O,I,3) -> (O,3,I)
@@ -221,6 +235,7 @@ class UNetHIP:
                 w[s + ".conv2sc.weight"] = torch.cat([w2, x], dim=1).to(bf).contiguous()
                 w[s + ".conv2sc.bias"] = (self._t(sd, s + ".conv2.bias") + self._t(sd, s + ".conv_shortcut.bias")).contiguous()
                 del w[s + ".conv2.weight"], w[s + ".conv2.bias"]
+                w.pop(s + ".conv2.weight_h", None)
             norm(t + ".norm1"); convt(t + ".conv1"); norm(t + ".norm2"); convt(t + ".conv2")
             for q in (s, t):  # all time_emb_proj layers are evaluated by ONE batched GEMM per step
                 tw = self._t(sd, q + ".time_emb_proj.weight")
@@ -324,7 +339,7 @@ class UNetHIP:
         if not os.environ.get("WIW_W_UNTILED"):    # A/B knob
             for k in list(w):
                 t_ = w[k]
-                if (k.endswith(".weight") and torch.is_tensor(t_) and t_.dim() == 2 and t_.dtype == bf
+                if ((k.endswith(".weight") or k.endswith(".weight_h")) and torch.is_tensor(t_) and t_.dim() == 2 and t_.dtype == bf
                         and t_.shape[1] % 64 == 0 and not k.endswith(".attn1.to_v.weight") and ".fused." not in k):
                     w[k] = TiledW(t_)
         for k in list(w):   # the fused FeedForward kernel streams W2 tiled whatever the A/B knob above says
@@ -466,9 +481,8 @@ class UNetHIP:
             raw = self._empty(M, Cin)
         xn = hip.groupnorm(x1, C1, x2, C2, M, S, w[s + ".norm1.weight"], w[s + ".norm1.bias"], eps, True, raw16=raw)
         h = self._empty(M, Cout)
-        hip.gemm(xn, w[s + ".conv1.weight"], h, M=M, N=Cout, K=9 * Cin, C1=Cin, mode=A_CONV3X3, H=H, Wd=W,
-                 bias=w[s + ".conv1.bias"], rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total,
-                 rows_per_vec=S, splitk=self._splitk(T * S, Cout, 9 * Cin), epilogue=self.kc)
+        self._conv3(xn, s + ".conv1", h, M=M, N=Cout, C=Cin, H=H, W=W, splitk=self._splitk(T * S, Cout, 9 * Cin),
+                    rowvec=temb_all[:, self.temb_off[s]:], rowvec_ld=self.temb_total, rows_per_vec=S)
         hn = hip.groupnorm(h, Cout, None, 0, M, S, w[s + ".norm2.weight"], w[s + ".norm2.bias"], eps, True)
         xs = self._empty(M, Cout, dtype=sdt)
         if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
@@ -484,9 +498,8 @@ class UNetHIP:
             else:
                 assert x2 is None
                 sc = x1
-            hip.gemm(hn, w[s + ".conv2.weight"], xs, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     bias=w[s + ".conv2.bias"], res1=sc, ldr1=Cout, beta1=1.0, splitk=self._splitk(T * S, Cout, 9 * Cout),
-                     epilogue=epi_s | self.kc)
+            self._conv3(hn, s + ".conv2", xs, M=M, N=Cout, C=Cout, H=H, W=W, splitk=self._splitk(T * S, Cout, 9 * Cout),
+                        res1=sc, ldr1=Cout, beta1=1.0, epilogue=epi_s)
         # temporal resnet: GroupNorm statistics run over (T, H, W) of each batch item (5-D input, resnet.py:611)
         xn = hip.groupnorm(xs, Cout, None, 0, M, T * S, w[t + ".norm1.weight"], w[t + ".norm1.bias"], eps, True, clip=True)
         hip.gemm(xn, w[t + ".conv1.weight"], h, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
@@ -499,6 +512,18 @@ class UNetHIP:
         hip.gemm(hn, w[t + ".conv2.weight"], out, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
                  bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s | self.kc)
         return out
+
+    def _conv3(self, x, key, out, *, M, N, C, H, W, splitk=1, epilogue=0, **kw):
+        """One 3x3 convolution (stride 1, pad 1) as an implicit GEMM: the halo-staged kernel (weight copy `key.weight_h`,
+        WIW_K_HALO32) when the geometry and the epilogue fit it, else the per-tap kernels on `key.weight`."""
+        w = self.w
+        wh = w.get(key + ".weight_h")
+        if wh is not None and splitk <= 1 and not epilogue and isinstance(wh, TiledW) and self.hip.conv_halo_ok(M, N, C, H, W):
+            self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
+                          epilogue=K_HALO32, **kw)
+        else:
+            self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
+                          splitk=splitk, epilogue=epilogue | self.kc, **kw)
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
         """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer."""
