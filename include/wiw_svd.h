@@ -132,8 +132,10 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
         * R = 256 / Wd image rows in LDS ONCE; the nine taps are nine shifted reads of that image instead of nine LDS-DMA
         * fetches of a [256][64]-element tile (1/9 of the A bytes through the DMA + the halo).  Geometry the kernel takes
         * (wiw_conv_halo_ok; anything else is refused — W's K order belongs to this kernel, the caller keeps a second copy
-        * of W in one of the other orders for other geometries): Wd = 64 or 128, (H * Wd) % 256 == 0, M % 256 == 0,
-        * C2 == C3 == 0, K = 9 * C1, W tiled (WIW_W_TILED), 16-bit output through the staged epilogue, no split-K. */
+        * of W in one of the other orders for other geometries): Wd = 32, 64 or 128, H >= 256 / Wd, M % 256 == 0 (a tile
+        * that straddles two frames gets a row of zeros between them), N % 320 == 0, W tiled (WIW_W_TILED), 16-bit output
+        * through the staged epilogue, no split-K.  The fused shortcut segment (A2 / A3, K = 9 * C1 + C2 + C3) is walked
+        * after the taps in plain channel order, as in the other K orders. */
        WIW_K_HALO32 = 1024 };
 
 typedef struct WiwGemmArgs {

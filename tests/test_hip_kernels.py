@@ -835,16 +835,34 @@ def test_conv3x3_halo_staged_kernel(hip):
     from wiw_amd import hip as H
     from wiw_amd.unet import conv_k_cmajor, conv_k_halo32
 
-    for (n, c, cout, h, w, extras) in [(2, 64, 320, 4, 64, False), (3, 192, 320, 2, 128, True), (2, 128, 640, 8, 64, True),
-                                       (5, 64, 320, 12, 64, False), (28, 320, 320, 36, 64, True), (3, 640, 640, 4, 128, True)]:
+    # (frames, C, C2, C3, Cout, H, W, vector + residual + alpha): 18 x 32 and 10 x 32 put frame edges INSIDE tiles (a zero row
+    # between the frames); C2 / C3: the fused 1x1 shortcut segment behind the taps
+    for (n, c, c2, c3, cout, h, w, extras) in [(2, 64, 0, 0, 320, 4, 64, False), (3, 192, 0, 0, 320, 2, 128, True),
+                                               (2, 128, 0, 0, 640, 8, 64, True), (5, 64, 0, 0, 320, 12, 64, False),
+                                               (28, 320, 0, 0, 320, 36, 64, True), (3, 640, 0, 0, 640, 4, 128, True),
+                                               (4, 128, 0, 0, 320, 18, 32, True), (8, 64, 0, 0, 640, 10, 32, False),
+                                               (28, 256, 0, 0, 1280, 18, 32, True), (4, 64, 128, 0, 320, 8, 64, True),
+                                               (3, 128, 64, 192, 640, 4, 128, False), (4, 192, 128, 64, 320, 18, 32, True)]:
         x = bf(rnd(n, c, h, w, seed=1))
         wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
         b = rnd(cout, seed=6)
         M = n * h * w
         assert H.Hip.conv_halo_ok(M, cout, c, h, w)
         w_tap = wt.permute(0, 2, 3, 1).reshape(cout, -1)
-        kw = dict(M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
+        kw = dict(M=M, N=cout, K=9 * c + c2 + c3, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, bias=dev_f(b))
         ref = F.conv2d(x, wt, b, padding=1)
+        w_h, w_c = conv_k_halo32(w_tap), conv_k_cmajor(w_tap, 9)
+        if c2:
+            s1 = bf(rnd(n, c2, h, w, seed=2))
+            wsc = bf(rnd(cout, c2 + c3, 1, 1, seed=5) / math.sqrt(c2 + c3))[:, :, 0, 0]
+            w_h, w_c = torch.cat([w_h, wsc], 1), torch.cat([w_c, wsc], 1)
+            kw.update(A2=dev_bf(nhwc(s1)), C2=c2)
+            src = s1
+            if c3:
+                s2 = bf(rnd(n, c3, h, w, seed=3))
+                kw.update(A3=dev_bf(nhwc(s2)), C3=c3)
+                src = torch.cat([s1, s2], dim=1)
+            ref = ref + F.conv2d(src, wsc[:, :, None, None])
         if extras:
             vec = rnd(n, cout, seed=7)
             res = bf(rnd(n, cout, h, w, seed=8))
@@ -852,18 +870,18 @@ def test_conv3x3_halo_staged_kernel(hip):
             ref = 0.75 * (ref + vec[:, :, None, None]) + res
         o_h = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
         o_t = torch.empty_like(o_h)
-        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(w_tap))), o_h, epilogue=H.K_HALO32, **kw)
-        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_cmajor(w_tap, 9))), o_t, epilogue=H.K_CMAJOR, **kw)
-        check(from_nhwc(o_h, n, h, w), ref, what=f"halo conv3x3 {c}->{cout} {n}x{h}x{w}")
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_h)), o_h, epilogue=H.K_HALO32, **kw)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_c)), o_t, epilogue=H.K_CMAJOR, **kw)
+        check(from_nhwc(o_h, n, h, w), ref, what=f"halo conv3x3 {c}|{c2}+{c3}->{cout} {n}x{h}x{w}")
         d = (o_h.float() - o_t.float()).cpu()
         rms = float(d.pow(2).mean().sqrt() / o_t.float().pow(2).mean().sqrt().cpu())
-        print(f"[halo] conv3x3 {c}->{cout} {n}x{h}x{w}: rms vs the per-tap kernel {rms:.2e}")
+        print(f"[halo] conv3x3 {c}|{c2}+{c3}->{cout} {n}x{h}x{w}: rms vs the per-tap kernel {rms:.2e}")
         assert rms <= 2e-3, "halo-staged and per-tap launches differ by more than the summation order"
         o2 = torch.empty_like(o_h)
-        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(w_tap))), o2, epilogue=H.K_HALO32, **kw)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_h)), o2, epilogue=H.K_HALO32, **kw)
         assert torch.equal(o2, o_h), "halo-staged launch is not deterministic"
     # outside the geometry: refused (W's K order belongs to this kernel)
-    n, c, cout, h, w = 2, 64, 320, 8, 32
+    n, c, cout, h, w = 2, 64, 320, 16, 16
     x = bf(rnd(n, c, h, w, seed=1))
     wt = bf(rnd(cout, c, 3, 3, seed=4))
     out = torch.empty(n * h * w, cout, dtype=torch.bfloat16, device=DEV)

@@ -29,6 +29,9 @@ def main():
         epi = parts[4] if len(parts) > 4 else 0
         taps = {0: 1, 1: 9, 2: 9, 3: 9, 4: 3}[mode]
         C1 = K // taps
+        C2 = int(os.environ.get("SC", "0")) if mode == 1 else 0   # fused shortcut segment behind the taps: K = 9 * C1 + C2
+        if C2:
+            C1 = (K - C2) // 9
         rows_in = M * 4 if mode == 2 else (M // 4 if mode == 3 else M)
         A = torch.randn(rows_in, C1, device=dev).to(torch.bfloat16)
         W = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(torch.bfloat16)
@@ -40,6 +43,8 @@ def main():
         if mode == 1 and os.environ.get("HALO"):    # halo-staged 3x3 kernel (needs TILED=1 and the served geometry below)
             epi |= H.K_HALO32
         kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi, splitk=int(os.environ.get("SPLITK", "1")))
+        if C2:
+            kw.update(A2=torch.randn(M, C2, device=dev).to(torch.bfloat16), C2=C2)
         if mode:
             frames = 28 if M % 28 == 0 else 1
             hw = M // frames

@@ -99,8 +99,11 @@ WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   
     return WiwKCur{ld_tap, ld_cc};
 }
 
-template <int MODE, bool GE, bool SK, bool HALO = false>
+// HALO_: 0 = per-tap A tiles; 1 = halo-staged A operand; 2 = halo-staged + the fused shortcut segment behind the taps (a
+// separate instantiation: the segment's per-row loader state costs the plain one 8 VGPRs and 36 bytes of scratch)
+template <int MODE, bool GE, bool SK, int HALO_ = 0>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
+    constexpr bool HALO = HALO_ != 0, HSEG = HALO_ == 2;
     static_assert(!HALO || (MODE == WIW_A_CONV3X3 && !GE && !SK), "the halo-staged A operand is a plain 3x3 convolution");
     constexpr int WSTAGE = HALO ? HB_BYTES : HSTAGE;          // bytes per ring stage
     constexpr int WOFF = HALO ? 0 : HA_BYTES;                 // offset of the W tile inside a stage
@@ -267,13 +270,29 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         }
     };
 
+    char* const halo0 = smem + 2 * HB_BYTES;                     // HALO: the two halo buffers behind the two W stages
+    int h_m0 = 0;                                                // HALO: first row of the tile in the K loop
+    const int h_kc = HSEG ? (9 * p.C1) / HK : 0x7fffffff;       // HALO: K tiles of the taps; the shortcut segment (C2 + C3) follows
     // the 9 DMA instructions of a K tile in five parts: A0 A1 | A2 A3 | W0 W1 | W2 W3 | W4 (+ advance the K cursor)
-    auto issue_part = [&](int stage, auto part_tag) {
+    auto issue_part = [&](int stage, auto part_tag, auto fseg_tag) {
         constexpr int part = decltype(part_tag)::value;
-        char* sA = smem + stage * HSTAGE + wave * 4 * 1024;
+        constexpr bool fseg = decltype(fseg_tag)::value != 0;     // HALO_ == 2: the tile being fetched is a shortcut-segment tile
+        // HALO: only the K tiles of the shortcut segment have an A tile of their own; it goes to halo buffer
+        // (ld_kt - h_kc) & 1 (ld_kt = the K tile being fetched), free since the taps' block nb - 2 + that parity was last read
+        char* sA = HALO ? halo0 + ((ld_kt - h_kc) & 1) * HALO_BUF + wave * 4 * 1024 : smem + stage * HSTAGE + wave * 4 * 1024;
         char* sB = smem + stage * WSTAGE + WOFF + wave * 5 * 1024;
         if constexpr (HALO && part < 2) {
-            // (the halo instantiation has no per-tap A tile: issue_halo below)
+            if constexpr (fseg) {
+                // the row / chunk of this lane from the lane id (the per-row loader state of the other instantiations would
+                // stay live across the K loop: 8 VGPRs this kernel does not have); M % 256 == 0: every row exists
+                const int cc = (ld_kt - h_kc) * HK, ck = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t m = h_m0 + (wave * 4 + 2 * part + u) * 8 + (lane >> 3);
+                    const char* src = cc < p.C2 ? A2b + (m * p.C2 + cc + ck) * 2 : A3b + (m * p.C3 + (cc - p.C2) + ck) * 2;
+                    glds16(src, sA + (2 * part + u) * 1024);
+                }
+            }
         } else if constexpr (part < 2) {
 #if WIW_ABLATE == 30   // timing experiment only (wrong results): the A tile of a 3x3 convolution is fetched for the centre tap
                        // alone = the LDS-DMA instruction count of a halo-staged A operand (1 of 9 A tiles per channel block)
@@ -294,49 +313,62 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         }
     };
     auto issue_all = [&](int stage) {
-        issue_part(stage, IC<0>{}); issue_part(stage, IC<1>{}); issue_part(stage, IC<2>{});
-        issue_part(stage, IC<3>{}); issue_part(stage, IC<4>{});
+        issue_part(stage, IC<0>{}, IC<0>{}); issue_part(stage, IC<1>{}, IC<0>{}); issue_part(stage, IC<2>{}, IC<0>{});
+        issue_part(stage, IC<3>{}, IC<0>{}); issue_part(stage, IC<4>{}, IC<0>{});
     };
 
     // ---- HALO: geometry (uniform), the DMA instruction -> halo position map of this wave, the tap cursor
-    char* const halo0 = smem + 2 * HB_BYTES;
+    const int h_R = HALO ? 256 / p.Wd : 1;                       // image rows per tile
     const int h_ipr = HALO ? (p.Wd + 2 + 15) >> 4 : 1;          // DMA instructions (16 pixels x 64 B) per halo row
     const int h_P = h_ipr * 16;                                  // halo pitch in pixels
-    const int h_ninstr = HALO ? (256 / p.Wd + 2) * h_ipr : 0;    // <= 36
+    // halo rows: one above, the R rows, one below — and, when tiles straddle frames (H * Wd % 256 != 0), a ZERO row between
+    // the last row of a frame and the first row of the next (what both frames' taps across that edge must read)
+    const int h_ninstr = HALO ? (h_R + 2 + (HW % HM != 0 ? 1 : 0)) * h_ipr : 0;    // <= 36
     const int h_nblk = p.C1 >> 5;                                // 32-channel blocks
-    const int h_rowbase = HALO ? ((wm * 64) / p.Wd + 1) * h_P + (wm * 64) % p.Wd + 1 : 0;   // halo pixel of this wave's row 0, tap (0, 0)
     int h_hy[5], h_jx[5];                                        // instruction j = wave + 8 i of a block: halo row, 16-pixel column
 #pragma unroll
     for (int i = 0; i < 5; ++i) { const int j = wave + 8 * i; h_hy[i] = j / h_ipr; h_jx[i] = j - h_hy[i] * h_ipr; }
     int h_tap = 0, h_blk = 0, h_next = 1, h_tile = 0;
+    int h_S[4] = {0, 0, 0, 0};                                   // halo pixel of row 0 of this wave's 16-row block mi at tap (0, 0)
+    // tile geometry: y0 = image row of the tile's first row, bpos = tile rows that belong to its frame (>= R: all of them)
+    auto tile_y0 = [&](int m0t) { return (m0t % HW) / p.Wd; };
     // instruction i of this wave for 32-channel block b of the tile whose first row is m0t (first image row y0t)
     auto issue_halo = [&](int m0t, int y0t, int b, auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
         const int j = wave + 8 * i;
         if (j >= h_ninstr) return;
-        const int iy = y0t - 1 + h_hy[i];
+        const int bpos = p.H - y0t;                              // first tile row of the NEXT frame (if < R)
+        const int hy = h_hy[i];
+        const bool split = bpos < h_R;
+        const bool gap = split && hy == bpos + 1;
+        const int r = hy - 1 - ((split && hy > bpos + 1) ? 1 : 0);           // tile row this halo row shows (-1 / R: the outer halo)
+        const int y = (split && r >= bpos) ? r - bpos : y0t + r;              // its image row in its frame
         const int ix = h_jx[i] * 16 + (lane >> 2) - 1;
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+        const bool ok = !gap && (unsigned)y < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
         const int csrc = (lane & 3) ^ ((lane >> 3) & 3);        // LDS chunk (lane & 3) of pixel hp holds source chunk ^ ((hp >> 1) & 3)
-        const char* src = ok ? Ab + (((int64_t)m0t + (h_hy[i] - 1) * p.Wd + ix) * p.C1 + b * 32 + csrc * 8) * 2 : zeros;
+        const char* src = ok ? Ab + (((int64_t)m0t + r * p.Wd + ix) * p.C1 + b * 32 + csrc * 8) * 2 : zeros;
         glds16(src, halo0 + (b & 1) * HALO_BUF + j * 1024);
     };
-    auto tile_y0 = [&](int m0t) { return (m0t % HW) / p.Wd; };
     auto issue_halo_all = [&](int m0t, int y0t, int b) {
         issue_halo(m0t, y0t, b, IC<0>{}); issue_halo(m0t, y0t, b, IC<1>{}); issue_halo(m0t, y0t, b, IC<2>{});
         issue_halo(m0t, y0t, b, IC<3>{}); issue_halo(m0t, y0t, b, IC<4>{});
     };
-    // DMA of slot `sl` (0..4) of a K tile: the five parts of the next K tile; HALO: its 5 W instructions in slots 0..2 and,
-    // in the tile where block h_next may be fetched (hdo), that block's <= 5 halo instructions in slots 2..4
-    auto issue_slot = [&](int si, auto slot_tag, bool more, bool hdo, int m0t, int y0t) {
+    // DMA of slot `sl` (0..4) of a K tile: the five parts of the next K tile.  HALO, taps: its 5 W instructions in slots 0..2
+    // and, in the tile where block h_next may be fetched (hdo), that block's <= 5 halo instructions in slots 2..4 (measured
+    // against W in the wave's read slots only and against one burst in slot 0: 1-3 % slower, profiles/r10f_halo_sched_probe.txt);
+    // HALO, shortcut segment (the tile being fetched is ld_kt >= h_kc): A | A | W | W | W like the other instantiations
+    auto issue_slot = [&](int si, auto slot_tag, auto fseg_tag, bool more, bool hdo, int m0t, int y0t) {
         constexpr int sl = decltype(slot_tag)::value;
+        constexpr bool fseg = decltype(fseg_tag)::value != 0;
         if constexpr (!HALO) {
-            if (more) issue_part(si, IC<sl>{});
+            if (more) issue_part(si, IC<sl>{}, IC<0>{});
         } else {
-            if (more) {
-                if constexpr (sl == 0) issue_part(si, IC<2>{});
-                else if constexpr (sl == 1) issue_part(si, IC<3>{});
-                else if constexpr (sl == 2) issue_part(si, IC<4>{});
+            if constexpr (fseg) {
+                if (more) issue_part(si, IC<sl>{}, IC<1>{});
+            } else if (more) {
+                if constexpr (sl == 0) issue_part(si, IC<2>{}, IC<0>{});
+                else if constexpr (sl == 1) issue_part(si, IC<3>{}, IC<0>{});
+                else if constexpr (sl == 2) issue_part(si, IC<4>{}, IC<0>{});
             }
             if (hdo) {
                 if constexpr (sl == 2) issue_halo(m0t, y0t, h_next, IC<0>{});
@@ -348,16 +380,25 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 
     f32x4 acc[4][10];
     bf16x8 fa[4], fb[5];
-    auto read_a_halo = [&]() {   // the A fragments of the next 32-deep k-step: tap h_tap of block h_blk
-        const int dy = h_tap / 3 - 1, dx = h_tap - (h_tap / 3) * 3 - 1;
-        const int hp = h_rowbase + dy * h_P + dx + frow;
-        const char* sA = halo0 + (h_blk & 1) * HALO_BUF + hp * 64 + ((fq ^ ((hp >> 1) & 3)) << 4);
+    auto read_a_halo = [&](int kt, int kk, auto cseg_tag) {
+        if constexpr (decltype(cseg_tag)::value != 0) {   // shortcut segment: a [256][64] tile in halo buffer (kt - h_kc) & 1, laid out like a ring stage's A part
+            const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
+            const char* sA = halo0 + ((kt - h_kc) & 1) * HALO_BUF + (wm * 64 + frow) * 128 + sw;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 1024);
+            for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 2048);
+            return;
+        }
+        // the A fragments of the next 32-deep k-step: tap h_tap of block h_blk.  h_S, the pitch and the 16-pixel columns are
+        // multiples of 16 (+1), so the swizzle phase of pixel h_S + tap offset + frow depends on dx and the lane only
+        const int dy = h_tap / 3 - 1, dx = h_tap - (h_tap / 3) * 3 - 1;
+        const int lp = frow * 64 + ((fq ^ (((1 + dx + frow) >> 1) & 3)) << 4);
+        const char* sA = halo0 + (h_blk & 1) * HALO_BUF + (dy * h_P + dx) * 64 + lp;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + h_S[mi] * 64);
         if (++h_tap == 9) { h_tap = 0; ++h_blk; }
     };
-    auto read_a = [&](int stage, int kk) {
-        if constexpr (HALO) { read_a_halo(); return; }
+    auto read_a = [&](int stage, int kk, int kt, auto cseg_tag) {
+        if constexpr (HALO) { read_a_halo(kt, kk, cseg_tag); return; }
         const int sw = ((kk * 4 + fq) ^ (lane & 7)) << 4;
         const char* sA = smem + stage * HSTAGE + (wm * 64 + frow) * 128 + sw;
 #pragma unroll
@@ -426,7 +467,16 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         rederive();
         setup_loader(t);
         const int y0 = HALO ? tile_y0(m0) : 0;
+        h_m0 = m0;
         h_tap = 0; h_blk = 0; h_next = 1; h_tile = 0;       // (HALO) block 0 was fetched with K tile 0; block 1 may go at once
+        if constexpr (HALO) {
+            const int bpos = p.H - y0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int rr = wm * 64 + mi * 16, r = rr / p.Wd, c = rr - r * p.Wd;
+                h_S[mi] = (r + 1 + ((bpos < h_R && r >= bpos) ? 1 : 0)) * h_P + c + 1;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -444,43 +494,48 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         //   * tile kt+1 is first read in the leading group's slot 8(kt+1) = after the lagging group's barrier 8kt+7,
         //     so every wave confirms its DMA share before its local barrier 8kt+7 (end of slot 6).
         if (lag) slot_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
+        // one K tile.  cseg / fseg (HALO_ == 2 only): this tile / the tile fetched during it belongs to the shortcut segment —
+        // compile-time, and the three kinds of tile run in three loops below: with run-time tests in ONE loop hipcc peeled
+        // iterations, moved accumulators between registers and spilled two of them inside the MFMA bursts (36 bytes of scratch,
+        // the segment launches 4-5 % SLOWER than the per-tap kernel, profiles/r10g_conv_halo_l2_sc_probe.txt)
+        auto k_tile = [&](int kt, auto cseg_tag, auto fseg_tag) {
+            constexpr bool cseg = decltype(cseg_tag)::value != 0, fseg = decltype(fseg_tag)::value != 0;
             const bool more = kt + 1 < nk;
             const int si = st_c ^ 1;
             // HALO: block h_next goes into the buffer of block h_next - 2, whose last k-step (9 h_next - 10) was read in K
             // tile (9 h_next - 10) / 2 — every wave is past that read once it has passed this tile's first barrier (same
             // argument as for the ring stage below) — and is confirmed with this tile's vmcnt(0), long before its first use
-            const bool hdo = HALO && h_next < h_nblk && kt == h_tile;
+            const bool hdo = HALO && !cseg && h_next < h_nblk && kt == h_tile;
             slot_barrier();                                    // 8kt
 #if WIW_DMA_BURST
             // a slot that issues ANY LDS-DMA pays ~180 cycles once, further instructions ~25 each (tools/trace_probe.py)
             if (more) issue_all(si);
             if (HALO && hdo) issue_halo_all(m0, y0, h_next);
 #else
-            issue_slot(si, IC<0>{}, more, hdo, m0, y0);
+            issue_slot(si, IC<0>{}, IC<fseg>{}, more, hdo, m0, y0);
 #endif
-            read_a(st_c, 0);
+            read_a(st_c, 0, kt, IC<cseg>{});
             read_b(st_c, 0, IC<0>{});
             slot_barrier();                                    // +1
 #if !WIW_DMA_BURST
-            issue_slot(si, IC<1>{}, more, hdo, m0, y0);
+            issue_slot(si, IC<1>{}, IC<fseg>{}, more, hdo, m0, y0);
 #endif
             mma(IC<0>{});
             slot_barrier();                                    // +2
 #if !WIW_DMA_BURST
-            issue_slot(si, IC<2>{}, more, hdo, m0, y0);
+            issue_slot(si, IC<2>{}, IC<fseg>{}, more, hdo, m0, y0);
 #endif
             read_b(st_c, 0, IC<1>{});
             slot_barrier();                                    // +3
 #if !WIW_DMA_BURST
-            issue_slot(si, IC<3>{}, more, hdo, m0, y0);
+            issue_slot(si, IC<3>{}, IC<fseg>{}, more, hdo, m0, y0);
 #endif
             mma(IC<1>{});
             slot_barrier();                                    // +4
 #if !WIW_DMA_BURST
-            issue_slot(si, IC<4>{}, more, hdo, m0, y0);
+            issue_slot(si, IC<4>{}, IC<fseg>{}, more, hdo, m0, y0);
 #endif
-            read_a(st_c, 1);
+            read_a(st_c, 1, kt, IC<cseg>{});
             read_b(st_c, 1, IC<0>{});
             slot_barrier();                                    // +5
             mma(IC<0>{});
@@ -494,6 +549,14 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             mma(IC<1>{});
             st_c ^= 1;
             if (HALO && hdo) { ++h_next; h_tile = (9 * h_next - 10) / 2 + 1; }
+        };
+        if constexpr (!HSEG) {
+            for (int kt = 0; kt < nk; ++kt) k_tile(kt, IC<0>{}, IC<0>{});
+        } else {
+            int kt = 0;
+            for (; kt < h_kc - 1; ++kt) k_tile(kt, IC<0>{}, IC<0>{});
+            k_tile(kt, IC<0>{}, IC<1>{});          // the last tile of the taps fetches the first tile of the segment
+            for (++kt; kt < nk; ++kt) k_tile(kt, IC<1>{}, IC<1>{});
         }
         if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
 
@@ -750,7 +813,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 }
 
-template <int MODE, bool GE, bool SK, bool HALO = false>
+template <int MODE, bool GE, bool SK, int HALO = 0>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     constexpr int SMEM = HALO ? HALO_SMEM : H_SMEM;
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
@@ -815,9 +878,10 @@ bool wiw_conv_halo_shape_ok(const WiwGemmArgs& a) {
     if (a.mode != WIW_A_CONV3X3 || !(a.epilogue & WIW_K_HALO32) || !(a.epilogue & WIW_W_TILED)) return false;
     if (a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 |
                       WIW_EPI_RES2_F32 | WIW_EPI_LNFOLD | WIW_K_CMAJOR)) return false;
-    if (a.splitk > 1 || a.C2 != 0 || a.C3 != 0 || a.A2 != nullptr || a.A3 != nullptr) return false;
-    if (a.C1 % 64 != 0 || a.K != 9 * a.C1) return false;
-    if ((a.Wd != 64 && a.Wd != 128) || a.H <= 0 || ((int64_t)a.H * a.Wd) % HM != 0 || a.M % HM != 0) return false;
+    if (a.splitk > 1) return false;
+    if (a.C1 % 64 != 0 || a.C2 % 64 != 0 || a.C3 % 64 != 0 || a.K != 9 * a.C1 + a.C2 + a.C3) return false;
+    // a 256-row tile = 256 / Wd whole image rows, at most one frame edge inside it
+    if ((a.Wd != 32 && a.Wd != 64 && a.Wd != 128) || a.H < 256 / a.Wd || a.M % HM != 0 || a.M % ((int64_t)a.H * a.Wd) != 0) return false;
     if (a.N % 8 || a.ldo % 8) return false;
     if (a.res1 && a.ldr1 % 8) return false;
     if (a.res2 && a.ldr2 % 8) return false;
@@ -835,7 +899,7 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
             wiw_set_error("gemm: WIW_K_HALO32 launch outside the halo kernel's geometry (wiw_conv_halo_ok)");
             return WIW_EINVAL;
         }
-        return launch_huge<WIW_A_CONV3X3, false, false, true>(s, a);
+        return a.C2 + a.C3 > 0 ? launch_huge<WIW_A_CONV3X3, false, false, 2>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 1>(s, a);
     }
     if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)
         switch (a.mode) {

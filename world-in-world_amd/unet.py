@@ -170,6 +170,7 @@ class UNetHIP:
         # activation window while it is still in L2; A/B knob WIW_K_TAPMAJOR=1 keeps the tap-major order)
         self.kc = 0 if os.environ.get("WIW_K_TAPMAJOR") else K_CMAJOR
         self.halo = not os.environ.get("WIW_CONV_NO_HALO")      # A/B knob: 3x3 convolutions without the halo-staged kernel
+        self.halo_sc = not os.environ.get("WIW_CONV_NO_HALO_SC")  # A/B knob: ... except those with the fused shortcut segment
         self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not self.res32
         self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
         self._prepare(state_dict)
@@ -206,9 +207,9 @@ class UNetHIP:
             x = x.reshape(x.shape[0], -1)
             w[p + ".weight"] = (conv_k_cmajor(x, 9) if self.kc else x).to(bf).contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
-            # a second copy in the K order of the halo-staged kernel for the layers of the two outer levels (N = 320 / 640
-            # at the served widths): `_conv3` picks it when the request's geometry fits (hip.conv_halo_ok), else the copy above
-            if self.halo and x.shape[0] in (320, 640) and x.shape[1] % (9 * 64) == 0:
+            # a second copy in the K order of the halo-staged kernel (N % 320 == 0: every ResnetBlock2D convolution of the
+            # served widths): `_conv3` picks it when the request's geometry fits (hip.conv_halo_ok), else the copy above
+            if self.halo and x.shape[0] % 320 == 0 and x.shape[1] % (9 * 64) == 0:
                 w[p + ".weight_h"] = conv_k_halo32(x).to(bf).contiguous()
 
         def convt(p):
@@ -236,6 +237,9 @@ class UNetHIP:
                 w[s + ".conv2sc.bias"] = (self._t(sd, s + ".conv2.bias") + self._t(sd, s + ".conv_shortcut.bias")).contiguous()
                 del w[s + ".conv2.weight"], w[s + ".conv2.bias"]
                 w.pop(s + ".conv2.weight_h", None)
+                if self.halo and self.halo_sc and x.shape[0] % 320 == 0 and w2.shape[1] % (9 * 64) == 0 and x.shape[1] % 64 == 0:
+                    w2h = conv_k_halo32(self._t(sd, s + ".conv2.weight").permute(0, 2, 3, 1).reshape(x.shape[0], -1))
+                    w[s + ".conv2sc.weight_h"] = torch.cat([w2h, x], dim=1).to(bf).contiguous()
             norm(t + ".norm1"); convt(t + ".conv1"); norm(t + ".norm2"); convt(t + ".conv2")
             for q in (s, t):  # all time_emb_proj layers are evaluated by ONE batched GEMM per step
                 tw = self._t(sd, q + ".time_emb_proj.weight")
@@ -487,8 +491,8 @@ class UNetHIP:
         xs = self._empty(M, Cout, dtype=sdt)
         if s + ".conv2sc.weight" in w:     # conv2 + 1x1 shortcut over (x1 | x2) in one implicit GEMM
             sc_ops = dict(A2=raw, C2=Cin) if raw is not None else dict(A2=x1, C2=C1, A3=x2, C3=C2)
-            hip.gemm(hn, w[s + ".conv2sc.weight"], xs, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
-                     bias=w[s + ".conv2sc.bias"], splitk=self._splitk(T * S, Cout, 9 * Cout + Cin), epilogue=epi_s | self.kc, **sc_ops)
+            self._conv3(hn, s + ".conv2sc", xs, M=M, N=Cout, C=Cout, H=H, W=W, splitk=self._splitk(T * S, Cout, 9 * Cout + Cin),
+                        epilogue=epi_s, Ksc=Cin, **sc_ops)
         else:
             if s + ".conv_shortcut.weight" in w:   # unfused A/B path: separate 1x1 GEMM, then residual
                 assert not self.res32, "WIW_UNFUSED_SHORTCUT is a 16-bit-stream A/B knob"
@@ -513,17 +517,18 @@ class UNetHIP:
                  bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s | self.kc)
         return out
 
-    def _conv3(self, x, key, out, *, M, N, C, H, W, splitk=1, epilogue=0, **kw):
-        """One 3x3 convolution (stride 1, pad 1) as an implicit GEMM: the halo-staged kernel (weight copy `key.weight_h`,
-        WIW_K_HALO32) when the geometry and the epilogue fit it, else the per-tap kernels on `key.weight`."""
+    def _conv3(self, x, key, out, *, M, N, C, H, W, splitk=1, epilogue=0, Ksc=0, **kw):
+        """One 3x3 convolution (stride 1, pad 1; Ksc > 0: + the fused 1x1 shortcut segment over A2 | A3 in `kw`) as an implicit
+        GEMM: the halo-staged kernel (weight copy `key.weight_h`, WIW_K_HALO32) when the geometry and the epilogue fit it,
+        else the per-tap kernels on `key.weight`."""
         w = self.w
         wh = w.get(key + ".weight_h")
         if wh is not None and splitk <= 1 and not epilogue and isinstance(wh, TiledW) and self.hip.conv_halo_ok(M, N, C, H, W):
-            self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
+            self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
                           epilogue=K_HALO32, **kw)
         else:
-            self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
-                          splitk=splitk, epilogue=epilogue | self.kc, **kw)
+            self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=A_CONV3X3, H=H, Wd=W,
+                          bias=w[key + ".bias"], splitk=splitk, epilogue=epilogue | self.kc, **kw)
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
         """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer."""
