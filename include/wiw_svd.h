@@ -126,7 +126,7 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
         * their algorithmic reads (1.39 GB per launch at 2.4 TB/s).  The fused shortcut segment (C2 + C3) stays behind the
         * taps.  Pure permutation of K: the host re-orders W (`unet.py`), results differ only by fp32 summation order. */
        WIW_K_CMAJOR = 512,
-       /* WIW_A_CONV3X3 only, ABI 12: HALO-STAGED A operand.  K index of W (and of the kernel's walk) in 32-channel blocks,
+       /* WIW_A_CONV3X3 and WIW_A_CONV3X3_UP, ABI 12: HALO-STAGED A operand.  K index of W (and of the kernel's walk) in 32-channel blocks,
         *     k = ((c / 32) * 9 + tap) * 32 + c % 32,
         * and the kernel (256x320 tile) stages, per 32-channel block, the (R + 2) x (Wd + 2) pixel neighbourhood of its
         * R = 256 / Wd image rows in LDS ONCE; the nine taps are nine shifted reads of that image instead of nine LDS-DMA
@@ -135,7 +135,8 @@ enum { WIW_EPI_GEGLU = 1, WIW_EPI_SILU = 2, WIW_EPI_OUT_F32 = 4,
         * of W in one of the other orders for other geometries): Wd = 32, 64 or 128, H >= 256 / Wd, M % 256 == 0 (a tile
         * that straddles two frames gets a row of zeros between them), N % 320 == 0, W tiled (WIW_W_TILED), 16-bit output
         * through the staged epilogue, no split-K.  The fused shortcut segment (A2 / A3, K = 9 * C1 + C2 + C3) is walked
-        * after the taps in plain channel order, as in the other K orders. */
+        * after the taps in plain channel order, as in the other K orders.  WIW_A_CONV3X3_UP: the staged image is the
+        * low-resolution input (R / 2 + 2 rows of Wd / 2 + 2 pixels); Wd = 64 or 128, H even, (H * Wd) % 256 == 0, no segment. */
        WIW_K_HALO32 = 1024 };
 
 typedef struct WiwGemmArgs {

@@ -880,6 +880,25 @@ def test_conv3x3_halo_staged_kernel(hip):
         o2 = torch.empty_like(o_h)
         hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(w_h)), o2, epilogue=H.K_HALO32, **kw)
         assert torch.equal(o2, o_h), "halo-staged launch is not deterministic"
+    # nearest x2 upsample + 3x3: the staged image is the low-resolution input
+    for (n, c, cout, h, w) in [(2, 64, 320, 4, 32), (3, 128, 640, 6, 64), (5, 192, 320, 18, 32), (28, 640, 640, 18, 32)]:
+        x = bf(rnd(n, c, h, w, seed=1))
+        wt = bf(rnd(cout, c, 3, 3, seed=4) / math.sqrt(9 * c))
+        b = rnd(cout, seed=6)
+        M = n * 4 * h * w
+        assert H.Hip.conv_halo_ok(M, cout, c, 2 * h, 2 * w, up=True)
+        w_tap = wt.permute(0, 2, 3, 1).reshape(cout, -1)
+        kw = dict(M=M, N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3_UP, H=2 * h, Wd=2 * w, bias=dev_f(b))
+        ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), wt, b, padding=1)
+        o_h = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+        o_t = torch.empty_like(o_h)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(w_tap))), o_h, epilogue=H.K_HALO32, **kw)
+        hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_cmajor(w_tap, 9))), o_t, epilogue=H.K_CMAJOR, **kw)
+        check(from_nhwc(o_h, n, 2 * h, 2 * w), ref, what=f"halo up + conv3x3 {c}->{cout} {n}x{h}x{w}")
+        d = (o_h.float() - o_t.float()).cpu()
+        rms = float(d.pow(2).mean().sqrt() / o_t.float().pow(2).mean().sqrt().cpu())
+        print(f"[halo] up + conv3x3 {c}->{cout} {n}x{h}x{w}: rms vs the per-tap kernel {rms:.2e}")
+        assert rms <= 2e-3
     # outside the geometry: refused (W's K order belongs to this kernel)
     n, c, cout, h, w = 2, 64, 320, 16, 16
     x = bf(rnd(n, c, h, w, seed=1))

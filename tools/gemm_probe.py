@@ -40,7 +40,7 @@ def main():
         bias = torch.randn(N, device=dev)
         if mode and os.environ.get("KCMAJOR"):      # channel-block-major K walk (random weights: no re-ordering needed for timing)
             epi |= H.K_CMAJOR
-        if mode == 1 and os.environ.get("HALO"):    # halo-staged 3x3 kernel (needs TILED=1 and the served geometry below)
+        if mode in (1, 3) and os.environ.get("HALO"):    # halo-staged 3x3 kernel (needs TILED=1 and the served geometry below)
             epi |= H.K_HALO32
         kw = dict(M=M, N=N, K=K, C1=C1, mode=mode, bias=bias, epilogue=epi, splitk=int(os.environ.get("SPLITK", "1")))
         if C2:

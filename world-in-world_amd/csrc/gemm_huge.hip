@@ -104,7 +104,12 @@ WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   
 template <int MODE, bool GE, bool SK, int HALO_ = 0>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     constexpr bool HALO = HALO_ != 0, HSEG = HALO_ == 2;
-    static_assert(!HALO || (MODE == WIW_A_CONV3X3 && !GE && !SK), "the halo-staged A operand is a plain 3x3 convolution");
+    static_assert(!HALO || ((MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_UP) && !GE && !SK) , "the halo-staged A operand is a plain 3x3 convolution");
+    static_assert(!HSEG || MODE == WIW_A_CONV3X3, "the shortcut segment belongs to the stride-1 convolution");
+    // UPH: nearest x2 upsample + 3x3 (WIW_A_CONV3X3_UP).  The staged image is the LOW-resolution input: tap (dy, dx) of output
+    // pixel (y, x) reads input pixel ((y + dy) >> 1, (x + dx) >> 1), and the zero padding of the upsampled image is exactly
+    // the out-of-range input coordinates — R / 2 + 2 input rows of Wd / 2 + 2 pixels per tile (a quarter of the pixels)
+    constexpr bool UPH = HALO && MODE == WIW_A_CONV3X3_UP;
     constexpr int WSTAGE = HALO ? HB_BYTES : HSTAGE;          // bytes per ring stage
     constexpr int WOFF = HALO ? 0 : HA_BYTES;                 // offset of the W tile inside a stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,11 +324,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 
     // ---- HALO: geometry (uniform), the DMA instruction -> halo position map of this wave, the tap cursor
     const int h_R = HALO ? 256 / p.Wd : 1;                       // image rows per tile
-    const int h_ipr = HALO ? (p.Wd + 2 + 15) >> 4 : 1;          // DMA instructions (16 pixels x 64 B) per halo row
+    const int h_ipr = HALO ? ((UPH ? p.Wd >> 1 : p.Wd) + 2 + 15) >> 4 : 1;   // DMA instructions (16 pixels x 64 B) per halo row
     const int h_P = h_ipr * 16;                                  // halo pitch in pixels
     // halo rows: one above, the R rows, one below — and, when tiles straddle frames (H * Wd % 256 != 0), a ZERO row between
     // the last row of a frame and the first row of the next (what both frames' taps across that edge must read)
-    const int h_ninstr = HALO ? (h_R + 2 + (HW % HM != 0 ? 1 : 0)) * h_ipr : 0;    // <= 36
+    const int h_ninstr = HALO ? (UPH ? (h_R >> 1) + 2 : h_R + 2 + (HW % HM != 0 ? 1 : 0)) * h_ipr : 0;    // <= 36
     const int h_nblk = p.C1 >> 5;                                // 32-channel blocks
     int h_hy[5], h_jx[5];                                        // instruction j = wave + 8 i of a block: halo row, 16-pixel column
 #pragma unroll
@@ -337,6 +342,16 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         constexpr int i = decltype(i_tag)::value;
         const int j = wave + 8 * i;
         if (j >= h_ninstr) return;
+        if constexpr (UPH) {     // input rows y0 / 2 - 1 ... of the tile's frame (tiles are whole rows of one frame, y0 even)
+            const int iy = (y0t >> 1) - 1 + h_hy[i];
+            const int ix = h_jx[i] * 16 + (lane >> 2) - 1;
+            const bool ok = (unsigned)iy < (unsigned)(p.H >> 1) && (unsigned)ix < (unsigned)(p.Wd >> 1);
+            const int csrc = (lane & 3) ^ ((lane >> 3) & 3);
+            const int64_t fb = (int64_t)(m0t / HW) * (HW >> 2);
+            const char* src = ok ? Ab + ((fb + iy * (p.Wd >> 1) + ix) * p.C1 + b * 32 + csrc * 8) * 2 : zeros;
+            glds16(src, halo0 + (b & 1) * HALO_BUF + j * 1024);
+            return;
+        }
         const int bpos = p.H - y0t;                              // first tile row of the NEXT frame (if < R)
         const int hy = h_hy[i];
         const bool split = bpos < h_R;
@@ -391,6 +406,17 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         // the A fragments of the next 32-deep k-step: tap h_tap of block h_blk.  h_S, the pitch and the 16-pixel columns are
         // multiples of 16 (+1), so the swizzle phase of pixel h_S + tap offset + frow depends on dx and the lane only
         const int dy = h_tap / 3 - 1, dx = h_tap - (h_tap / 3) * 3 - 1;
+        if constexpr (UPH) {
+            // Wd >= 64: the wave's 64 rows lie in ONE output row r = h_S[1]; block mi starts at input column h_S[0] + 8 mi.
+            // Lanes 2k, 2k + 1 (shifted by dx) read the same input pixel: same address, a broadcast
+            const int fx = (frow + dx) >> 1;                                            // -1 ... 8
+            const int lp = fx * 64 + ((fq ^ (((1 + fx) >> 1) & 3)) << 4);
+            const char* sA = halo0 + (h_blk & 1) * HALO_BUF + ((((h_S[1] + dy) >> 1) + 1) * h_P + h_S[0]) * 64 + lp;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) fa[mi] = *(const bf16x8*)(sA + mi * 512);
+            if (++h_tap == 9) { h_tap = 0; ++h_blk; }
+            return;
+        }
         const int lp = frow * 64 + ((fq ^ (((1 + dx + frow) >> 1) & 3)) << 4);
         const char* sA = halo0 + (h_blk & 1) * HALO_BUF + (dy * h_P + dx) * 64 + lp;
 #pragma unroll
@@ -469,7 +495,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         const int y0 = HALO ? tile_y0(m0) : 0;
         h_m0 = m0;
         h_tap = 0; h_blk = 0; h_next = 1; h_tile = 0;       // (HALO) block 0 was fetched with K tile 0; block 1 may go at once
-        if constexpr (HALO) {
+        if constexpr (UPH) {
+            const int rr = wm * 64, r = rr / p.Wd;
+            h_S[0] = ((rr - r * p.Wd) >> 1) + 1;        // halo column of the wave's first pixel
+            h_S[1] = r;                                  // its output row inside the tile
+        } else if constexpr (HALO) {
             const int bpos = p.H - y0;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
@@ -875,7 +905,10 @@ bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
 
 // WIW_K_HALO32 launches (include/wiw_svd.h): geometry and epilogue the HALO instantiation takes
 bool wiw_conv_halo_shape_ok(const WiwGemmArgs& a) {
-    if (a.mode != WIW_A_CONV3X3 || !(a.epilogue & WIW_K_HALO32) || !(a.epilogue & WIW_W_TILED)) return false;
+    if ((a.mode != WIW_A_CONV3X3 && a.mode != WIW_A_CONV3X3_UP) || !(a.epilogue & WIW_K_HALO32) || !(a.epilogue & WIW_W_TILED)) return false;
+    if (a.mode == WIW_A_CONV3X3_UP) {   // whole output rows of ONE frame per tile, an even first row
+        if ((a.Wd != 64 && a.Wd != 128) || (a.H & 1) || ((int64_t)a.H * a.Wd) % HM != 0 || a.C2 != 0 || a.C3 != 0) return false;
+    }
     if (a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 |
                       WIW_EPI_RES2_F32 | WIW_EPI_LNFOLD | WIW_K_CMAJOR)) return false;
     if (a.splitk > 1) return false;
@@ -899,6 +932,7 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
             wiw_set_error("gemm: WIW_K_HALO32 launch outside the halo kernel's geometry (wiw_conv_halo_ok)");
             return WIW_EINVAL;
         }
+        if (a.mode == WIW_A_CONV3X3_UP) return launch_huge<WIW_A_CONV3X3_UP, false, false, 1>(s, a);
         return a.C2 + a.C3 > 0 ? launch_huge<WIW_A_CONV3X3, false, false, 2>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 1>(s, a);
     }
     if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)

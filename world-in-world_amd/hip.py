@@ -252,10 +252,15 @@ class Hip:
 
     # ---- operators
     @staticmethod
-    def conv_halo_ok(M: int, N: int, C1: int, H: int, Wd: int) -> bool:
+    def conv_halo_ok(M: int, N: int, C1: int, H: int, Wd: int, up: bool = False) -> bool:
         """Geometry the halo-staged 3x3 convolution kernel takes (WIW_K_HALO32; the C side re-checks: wiw_conv_halo_ok):
-        a 256-row tile is whole image rows, of at most two frames."""
-        return Wd in (32, 64, 128) and H >= 256 // Wd and M % 256 == 0 and M % (H * Wd) == 0 and C1 % 64 == 0 and N % 320 == 0
+        a 256-row tile is whole image rows, of at most two frames (up = behind the nearest x2 upsample, H x Wd the output
+        size: of one frame, Wd >= 64)."""
+        if M % 256 or M % (H * Wd) or C1 % 64 or N % 320:
+            return False
+        if up:
+            return Wd in (64, 128) and H % 2 == 0 and (H * Wd) % 256 == 0
+        return Wd in (32, 64, 128) and H >= 256 // Wd
 
     def gemm(self, A, W, out, *, M, N, K, C1, A2=None, C2=0, A3=None, C3=0, mode=A_DENSE, H=0, Wd=0, T=0, bias=None, rowvec=None,
              rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0, beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0,

@@ -517,17 +517,18 @@ class UNetHIP:
                  bias=w[t + ".conv2.bias"], alpha=1.0 - a, res1=xs, ldr1=Cout, beta1=1.0, epilogue=epi_s | self.kc)
         return out
 
-    def _conv3(self, x, key, out, *, M, N, C, H, W, splitk=1, epilogue=0, Ksc=0, **kw):
-        """One 3x3 convolution (stride 1, pad 1; Ksc > 0: + the fused 1x1 shortcut segment over A2 | A3 in `kw`) as an implicit
-        GEMM: the halo-staged kernel (weight copy `key.weight_h`, WIW_K_HALO32) when the geometry and the epilogue fit it,
-        else the per-tap kernels on `key.weight`."""
+    def _conv3(self, x, key, out, *, M, N, C, H, W, splitk=1, epilogue=0, Ksc=0, mode=A_CONV3X3, **kw):
+        """One 3x3 convolution (stride 1, pad 1; Ksc > 0: + the fused 1x1 shortcut segment over A2 | A3 in `kw`; mode
+        A_CONV3X3_UP: behind a nearest x2 upsample, H x W the OUTPUT size) as an implicit GEMM: the halo-staged kernel (weight
+        copy `key.weight_h`, WIW_K_HALO32) when the geometry and the epilogue fit it, else the per-tap kernels on `key.weight`."""
         w = self.w
         wh = w.get(key + ".weight_h")
-        if wh is not None and splitk <= 1 and not epilogue and isinstance(wh, TiledW) and self.hip.conv_halo_ok(M, N, C, H, W):
-            self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=A_CONV3X3, H=H, Wd=W, bias=w[key + ".bias"],
+        if (wh is not None and splitk <= 1 and not epilogue and isinstance(wh, TiledW)
+                and self.hip.conv_halo_ok(M, N, C, H, W, up=mode == A_CONV3X3_UP)):
+            self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W, bias=w[key + ".bias"],
                           epilogue=K_HALO32, **kw)
         else:
-            self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=A_CONV3X3, H=H, Wd=W,
+            self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W,
                           bias=w[key + ".bias"], splitk=splitk, epilogue=epilogue | self.kc, **kw)
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
@@ -659,8 +660,7 @@ class UNetHIP:
                  C1=cfg.time_embed_dim, bias=w["temb_all.bias"], epilogue=EPI_OUT_F32)
         epi_s = EPI_OUT_F32 if self.res32 else 0     # residual-stream outputs (fp32 when residual_fp32)
         x = self._empty(M, ch[0], dtype=self.sdt)
-        hip.gemm(x_in, w["conv_in.weight"], x, M=M, N=ch[0], K=9 * CIN_PAD, C1=CIN_PAD, mode=A_CONV3X3, H=h, Wd=w_,
-                 bias=w["conv_in.bias"], epilogue=epi_s | self.kc)
+        self._conv3(x_in, "conv_in", x, M=M, N=ch[0], C=CIN_PAD, H=h, W=w_, epilogue=epi_s)
         skips = [(x, ch[0])]
         H, W, C = h, w_, ch[0]
         for i in range(n):
@@ -699,8 +699,7 @@ class UNetHIP:
                 H, W, M = H * 2, W * 2, M * 4
                 y = self._empty(M, C, dtype=self.sdt)
                 q = f"{p}.upsamplers.0.conv"
-                hip.gemm(hip.cast16(x) if self.res32 else x, w[q + ".weight"], y, M=M, N=C, K=9 * C, C1=C, mode=A_CONV3X3_UP,
-                         H=H, Wd=W, bias=w[q + ".bias"], epilogue=epi_s | self.kc)
+                self._conv3(hip.cast16(x) if self.res32 else x, q, y, M=M, N=C, C=C, H=H, W=W, epilogue=epi_s, mode=A_CONV3X3_UP)
                 x = y
         xn = hip.groupnorm(x, C, None, 0, M, H * W, w["conv_norm_out.weight"], w["conv_norm_out.bias"], 1e-5, True)
         out = self._empty(M, cfg.out_channels, dtype=torch.float32)
