@@ -65,7 +65,8 @@ def nhwc(x):
 # kernels
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["fp16", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(4096 + 40, 320, 640), (300, 1280, 320), (33000, 640, 1280)])
+@pytest.mark.parametrize("M,N,K", [(4096 + 40, 320, 640), (300, 1280, 320), (33000, 640, 1280),
+                                   (51200 + 40, 320, 640), (25700, 640, 320)])   # the last three: the 256x320 tile's F32E instantiation
 def test_gemm_fp32_residuals(name, M, N, K):
     """out = alpha (A W^T + bias + vec[row group]) + beta1 res1 + beta2 res2 with fp32 residuals: fp32 output (exact up to
     the accumulation order) and 16-bit output (one rounding of the fp32 sum)."""
@@ -142,6 +143,70 @@ def test_conv_fp32_stream_epilogues(name):
              K=9 * C, C1=C, mode=A_CONV3X3, H=8, Wd=8, res1=nhwc(rk).contiguous().to(DEV), ldr1=C, beta1=1.0, splitk=3,
              epilogue=EPI_OUT_F32)
     mx, rms = rel(outk, nhwc(ref))
+    assert mx <= 2e-5 and rms <= 3e-6
+
+
+@pytest.mark.parametrize("name", ["fp16", "bf16"])
+def test_conv_fp32_stream_on_the_256x320_tile(name):
+    """The fp32-stream epilogue of `gemm_huge_kernel<…, F32E>` (round 4, second half) at sizes the 256x320 tile takes: halo-staged
+    (plain, shortcut segment, upsample) and per-tap 3x3 convolutions and the temporal convolution, fp32 output, fp32 residual,
+    per-frame vector — against fp32 torch on the operands the kernel sees."""
+    from wiw_amd.hip import A_CONV3X3, A_CONV3X3_UP, A_CONV_T3, EPI_OUT_F32, K_CMAJOR, K_HALO32, TiledW
+    from wiw_amd.unet import conv_k_cmajor, conv_k_halo32
+
+    hip, dt = get_hip(name), DTYPES[name]
+    B, T, Cin, Cout, H, W = 2, 14, 128, 320, 36, 64
+    n = B * T
+    M = n * H * W
+    x = rnd(n, Cout, H, W, seed=1).to(dt)
+    raw = rnd(n, Cin, H, W, seed=2).to(dt)
+    res = rnd(n, Cout, H, W, seed=3) * 2.0
+    vec = rnd(n, Cout, seed=4)
+    w2 = (rnd(Cout, Cout, 3, 3, seed=5) / math.sqrt(9 * Cout)).to(dt)
+    wsc = (rnd(Cout, Cin, seed=6) / math.sqrt(Cin)).to(dt)
+    b = rnd(Cout, seed=7)
+    w_tap = w2.permute(0, 2, 3, 1).reshape(Cout, -1)
+    xd, resd = nhwc(x).contiguous().to(DEV), nhwc(res).contiguous().to(DEV)
+    conv = F.conv2d(x.float(), w2.float(), b, padding=1)
+    ref_a = conv + F.conv2d(raw.float(), wsc.float()[:, :, None, None])
+    ref_b = 0.75 * (conv + vec[:, :, None, None]) + res
+    for (label, wk, epi) in (("halo", conv_k_halo32(w_tap), K_HALO32), ("per-tap", conv_k_cmajor(w_tap, 9), K_CMAJOR)):
+        out = torch.empty(M, Cout, dtype=torch.float32, device=DEV)
+        hip.gemm(xd, TiledW(torch.cat([wk, wsc], 1).contiguous().to(DEV)), out, M=M, N=Cout, K=9 * Cout + Cin, C1=Cout,
+                 mode=A_CONV3X3, H=H, Wd=W, A2=nhwc(raw).contiguous().to(DEV), C2=Cin, bias=b.to(DEV), epilogue=EPI_OUT_F32 | epi)
+        mx, rms = rel(out, nhwc(ref_a))
+        print(f"[res32 {name}] 256x320 tile, conv3x3 + shortcut ({label}) -> fp32: max_rel={mx:.2e} rms_rel={rms:.2e}")
+        assert mx <= 2e-5 and rms <= 3e-6
+        hip.gemm(xd, TiledW(wk.contiguous().to(DEV)), out, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
+                 bias=b.to(DEV), rowvec=vec.to(DEV), rowvec_ld=Cout, rows_per_vec=H * W, res1=resd, ldr1=Cout, beta1=1.0, alpha=0.75,
+                 epilogue=EPI_OUT_F32 | epi)
+        mx, rms = rel(out, nhwc(ref_b))
+        print(f"[res32 {name}] 256x320 tile, conv3x3 + vector + fp32 residual ({label}) -> fp32: max_rel={mx:.2e} rms_rel={rms:.2e}")
+        assert mx <= 2e-5 and rms <= 3e-6
+        out16 = torch.empty(M, Cout, dtype=dt, device=DEV)      # fp32 residual, 16-bit output: ONE rounding of the same sum
+        hip.gemm(xd, TiledW(wk.contiguous().to(DEV)), out16, M=M, N=Cout, K=9 * Cout, C1=Cout, mode=A_CONV3X3, H=H, Wd=W,
+                 bias=b.to(DEV), rowvec=vec.to(DEV), rowvec_ld=Cout, rows_per_vec=H * W, res1=resd, ldr1=Cout, beta1=1.0, alpha=0.75,
+                 epilogue=epi)
+        assert torch.equal(out16.cpu(), out.cpu().to(dt))
+    xs = rnd(n, Cout, H // 2, W // 2, seed=8).to(dt)
+    ref_u = F.conv2d(F.interpolate(xs.float(), scale_factor=2.0, mode="nearest"), w2.float(), b, padding=1)
+    for (label, wk, epi) in (("halo", conv_k_halo32(w_tap), K_HALO32), ("per-tap", conv_k_cmajor(w_tap, 9), K_CMAJOR)):
+        out = torch.empty(M, Cout, dtype=torch.float32, device=DEV)
+        hip.gemm(nhwc(xs).contiguous().to(DEV), TiledW(wk.contiguous().to(DEV)), out, M=M, N=Cout, K=9 * Cout, C1=Cout,
+                 mode=A_CONV3X3_UP, H=H, Wd=W, bias=b.to(DEV), epilogue=EPI_OUT_F32 | epi)
+        mx, rms = rel(out, nhwc(ref_u))
+        print(f"[res32 {name}] 256x320 tile, upsample + conv3x3 ({label}) -> fp32: max_rel={mx:.2e} rms_rel={rms:.2e}")
+        assert mx <= 2e-5 and rms <= 3e-6
+    a = 0.3
+    wt = (rnd(Cout, Cout, 3, 1, 1, seed=9) / math.sqrt(3 * Cout)).to(dt)
+    x5 = x.float().reshape(B, T, Cout, H, W).permute(0, 2, 1, 3, 4)
+    ct = F.conv3d(x5, wt.float(), b, padding=(1, 0, 0)).permute(0, 2, 1, 3, 4).reshape(n, Cout, H, W)
+    out = torch.empty(M, Cout, dtype=torch.float32, device=DEV)
+    Wt = conv_k_cmajor(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(Cout, -1), 3)
+    hip.gemm(xd, TiledW(Wt.contiguous().to(DEV)), out, M=M, N=Cout, K=3 * Cout, C1=Cout, mode=A_CONV_T3, H=H, Wd=W, T=T,
+             bias=b.to(DEV), alpha=1.0 - a, res1=resd, ldr1=Cout, beta1=1.0, epilogue=EPI_OUT_F32 | K_CMAJOR)
+    mx, rms = rel(out, nhwc(res + (1.0 - a) * ct))
+    print(f"[res32 {name}] 256x320 tile, temporal conv + AlphaBlender, fp32 residual -> fp32: max_rel={mx:.2e} rms_rel={rms:.2e}")
     assert mx <= 2e-5 and rms <= 3e-6
 
 

@@ -1098,8 +1098,11 @@ int launch(hipStream_t s, const WiwGemmArgs& a) {
             return WIW_EINVAL;
         }
     }
-    // fp32 residual stream (ABI 11): the F32E instantiation on aligned shapes (everything else with these bits: the scalar
-    // direct path of the common instantiation)
+    // fp32 residual stream (ABI 11): the 256x320 tile's F32E instantiations where that tile applies (round 4, second half),
+    // else the F32E instantiation of this file on aligned shapes (everything else with these bits: the scalar direct path of
+    // the common instantiation)
+    if ((a.epilogue & (WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32 | WIW_EPI_OUT_F32)) && (!force || force[0] == 'h') && wiw_gemm_huge_ok(a))
+        return wiw_gemm_huge_launch(s, a);
     if ((a.epilogue & (WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32 | WIW_EPI_OUT_F32)) &&
         !(a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)) && a.N % 4 == 0 && a.ldo % 4 == 0 &&
         (a.res1 == nullptr || a.ldr1 % 4 == 0) && (a.res2 == nullptr || a.ldr2 % 4 == 0) &&

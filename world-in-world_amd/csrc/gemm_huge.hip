@@ -101,8 +101,14 @@ WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   
 
 // HALO_: 0 = per-tap A tiles; 1 = halo-staged A operand; 2 = halo-staged + the fused shortcut segment behind the taps (a
 // separate instantiation: the segment's per-row loader state costs the plain one 8 VGPRs and 36 bytes of scratch)
-template <int MODE, bool GE, bool SK, int HALO_ = 0>
+// F32E: the fp32 residual stream (WIW_EPI_OUT_F32 / _RES1_F32 / _RES2_F32, include/wiw_svd.h): no 16-bit staging — bias,
+// per-frame vector and both residuals are added to the fp32 accumulators in the fragment layout (a lane holds 4 consecutive
+// columns of a row: 16-byte fp32 / 8-byte 16-bit accesses in 64-byte row runs) and the sum is rounded once, or not at all.
+// gemm.hip's 256x160 / 128x160 kernels have carried this epilogue since ABI 11; here it is its own instantiation for the
+// same reason as there (compiled into the common one its residual registers cost every launch scratch).
+template <int MODE, bool GE, bool SK, int HALO_ = 0, bool F32E = false>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
+    static_assert(!F32E || (!GE && !SK), "the fp32-stream epilogue: plain launches only");
     constexpr bool HALO = HALO_ != 0, HSEG = HALO_ == 2;
     static_assert(!HALO || ((MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_UP) && !GE && !SK) , "the halo-staged A operand is a plain 3x3 convolution");
     static_assert(!HSEG || MODE == WIW_A_CONV3X3, "the shortcut segment belongs to the stride-1 convolution");
@@ -662,8 +668,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             }
             wave_lds_sync();
         };
-        if (!GE && !SK) stage_pass(IC<0>{});
-        if (GE) {
+        if (!GE && !SK && !F32E) stage_pass(IC<0>{});
+        if (F32E) {
+            // (operands are fetched per half pass in part 2)
+        } else if (GE) {
             if (p.bias) {
 #pragma unroll
                 for (int ni = 0; ni < 10; ++ni) bvf[ni] = *(const float4*)(p.bias + tile_nw * 160 + ni * 16 + fq * 4);
@@ -708,6 +716,56 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                     }
                 }
             }
+        } else if constexpr (F32E) {
+            const bool out_f32 = (p.epilogue & WIW_EPI_OUT_F32) != 0;
+            const bool r1_f32 = (p.epilogue & WIW_EPI_RES1_F32) != 0, r2_f32 = (p.epilogue & WIW_EPI_RES2_F32) != 0;
+            auto ld4 = [&](const void* base, bool f32, int64_t off) -> float4 {
+                if (f32) return *(const float4*)((const float*)base + off);
+                const uint2 u = *(const uint2*)((const uint16_t*)base + off);
+                const wiw_f32x2 a = unpack2(u.x), b = unpack2(u.y);
+                return float4{a.x, a.y, b.x, b.y};
+            };
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = mw0 + mi * 16 + frow;
+                const bool m_ok = m < p.M;
+                const int mc = m_ok ? m : p.M - 1;
+                const float* rv = p.rowvec ? p.rowvec + (int64_t)(mc / p.rows_per_vec) * p.rowvec_ld : nullptr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {       // half passes of 5 column blocks: 2 x 20 residual registers in flight
+                    float4 rr1[5], rr2[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int n = tile_nw * 160 + (h * 5 + j) * 16 + fq * 4;
+                        const bool ok = m_ok && n < p.N;
+                        rr1[j] = (p.res1 && ok) ? ld4(p.res1, r1_f32, (int64_t)m * p.ldr1 + n) : float4{0.f, 0.f, 0.f, 0.f};
+                        rr2[j] = (p.res2 && ok) ? ld4(p.res2, r2_f32, (int64_t)m * p.ldr2 + n) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int n = tile_nw * 160 + (h * 5 + j) * 16 + fq * 4;
+                        if (m_ok && n < p.N) {
+                            f32x4 v = acc[mi][h * 5 + j];
+                            if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                            if (rv) { const float4 b = *(const float4*)(rv + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                            v[0] *= p.alpha; v[1] *= p.alpha; v[2] *= p.alpha; v[3] *= p.alpha;
+                            const float4 f = rr1[j], g = rr2[j];
+                            v[0] += p.beta1 * f.x + p.beta2 * g.x; v[1] += p.beta1 * f.y + p.beta2 * g.y;
+                            v[2] += p.beta1 * f.z + p.beta2 * g.z; v[3] += p.beta1 * f.w + p.beta2 * g.w;
+                            if (out_f32) {
+                                float* d = (float*)p.out + (int64_t)m * p.ldo + n;
+                                __builtin_nontemporal_store(v[0], d); __builtin_nontemporal_store(v[1], d + 1);
+                                __builtin_nontemporal_store(v[2], d + 2); __builtin_nontemporal_store(v[3], d + 3);
+                            } else {
+                                uint32_t* d = (uint32_t*)((uint16_t*)p.out + (int64_t)m * p.ldo + n);
+                                __builtin_nontemporal_store(pack2bf(v[0], v[1]), d);
+                                __builtin_nontemporal_store(pack2bf(v[2], v[3]), d + 1);
+                            }
+                        }
+                    }
+                }
+            }
+            // (conditional stores: the next tile waits with vmcnt(0), pending_stores stays 0)
         } else {
             uint4* dump = g_dump_h + (blockIdx.x & 511) * 64 + lane;
             // plain path, step (b) of a 16-row pass: row-major, 8 consecutive columns per lane, bias / vector / residual math
@@ -843,7 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 }
 
-template <int MODE, bool GE, bool SK, int HALO = 0>
+template <int MODE, bool GE, bool SK, int HALO = 0, bool F32E = false>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     constexpr int SMEM = HALO ? HALO_SMEM : H_SMEM;
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
@@ -851,7 +909,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK, HALO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK, HALO, F32E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -867,7 +925,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     static const char* sn_env = getenv("WIW_GEMM_SN");
     const int stagger = ((stg_env ? atoi(stg_env) : 0) & 255) | ((sn_env ? atoi(sn_env) & 15 : 0) << 8);
-    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK, HALO>), dim3((unsigned)grid), dim3(512), SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK, HALO, F32E>), dim3((unsigned)grid), dim3(512), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }
 
@@ -877,14 +935,17 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
 // (nearly) every CU one.  Everything else stays on gemm.hip's tiles.
 bool wiw_gemm_huge_ok(const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
-    if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) return false;
+    const bool f32 = (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) != 0;   // F32E instantiations (plain only)
+    if (a.epilogue & (WIW_EPI_SILU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU)) return false;
+    if (f32 && (ge || a.splitk > 1 || getenv("WIW_GEMM_HUGE_NO_F32"))) return false;
     // partial last N tile (the VAE's 256 / 512-channel layers): only without GEGLU and when 320-wide tiles idle no more
     // MFMA columns than 160-wide ones would
     if (a.N % HN != 0 && (ge || ((a.N + HN - 1) / HN) * HN > ((a.N + 159) / 160) * 160)) return false;
     const int n_valid = ge ? a.n_out : a.N;
-    if (n_valid % 8 || a.ldo % 8) return false;
-    if (a.res1 && a.ldr1 % 8) return false;
-    if (a.res2 && a.ldr2 % 8) return false;
+    const int al = f32 ? 4 : 8;             // fragment-layout accesses are 4 columns wide, staged rows 8
+    if (n_valid % al || a.ldo % al) return false;
+    if (a.res1 && a.ldr1 % al) return false;
+    if (a.res2 && a.ldr2 % al) return false;
     if ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) || a.rowvec_ld % 4) return false;
     // short K (< 10 K tiles) with GEGLU: the output tile's epilogue dominates and the smaller tile's finer granularity wins
     // (K = 320 GEGLU -6 %).  Plain epilogues at K = 320 were +-2 % while this kernel spilled; spill-free (round 4) the
@@ -909,15 +970,16 @@ bool wiw_conv_halo_shape_ok(const WiwGemmArgs& a) {
     if (a.mode == WIW_A_CONV3X3_UP) {   // whole output rows of ONE frame per tile, an even first row
         if ((a.Wd != 64 && a.Wd != 128) || (a.H & 1) || ((int64_t)a.H * a.Wd) % HM != 0 || a.C2 != 0 || a.C3 != 0) return false;
     }
-    if (a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_OUT_F32 | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_RES1_F32 |
-                      WIW_EPI_RES2_F32 | WIW_EPI_LNFOLD | WIW_K_CMAJOR)) return false;
+    if (a.epilogue & (WIW_EPI_GEGLU | WIW_EPI_SILU | WIW_EPI_GELU | WIW_EPI_QUICK_GELU | WIW_EPI_LNFOLD | WIW_K_CMAJOR)) return false;
     if (a.splitk > 1) return false;
+    const bool f32 = (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) != 0;
+    const int al = f32 ? 4 : 8;
     if (a.C1 % 64 != 0 || a.C2 % 64 != 0 || a.C3 % 64 != 0 || a.K != 9 * a.C1 + a.C2 + a.C3) return false;
     // a 256-row tile = 256 / Wd whole image rows, at most one frame edge inside it
     if ((a.Wd != 32 && a.Wd != 64 && a.Wd != 128) || a.H < 256 / a.Wd || a.M % HM != 0 || a.M % ((int64_t)a.H * a.Wd) != 0) return false;
-    if (a.N % 8 || a.ldo % 8) return false;
-    if (a.res1 && a.ldr1 % 8) return false;
-    if (a.res2 && a.ldr2 % 8) return false;
+    if (a.N % al || a.ldo % al) return false;
+    if (a.res1 && a.ldr1 % al) return false;
+    if (a.res2 && a.ldr2 % al) return false;
     if ((((uintptr_t)a.bias | (uintptr_t)a.rowvec) & 15) || a.rowvec_ld % 4) return false;
     if (a.N % HN != 0) return false;
     return true;
@@ -932,8 +994,22 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
             wiw_set_error("gemm: WIW_K_HALO32 launch outside the halo kernel's geometry (wiw_conv_halo_ok)");
             return WIW_EINVAL;
         }
-        if (a.mode == WIW_A_CONV3X3_UP) return launch_huge<WIW_A_CONV3X3_UP, false, false, 1>(s, a);
-        return a.C2 + a.C3 > 0 ? launch_huge<WIW_A_CONV3X3, false, false, 2>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 1>(s, a);
+        const bool f32h = (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) != 0;
+        if (a.mode == WIW_A_CONV3X3_UP)
+            return f32h ? launch_huge<WIW_A_CONV3X3_UP, false, false, 1, true>(s, a) : launch_huge<WIW_A_CONV3X3_UP, false, false, 1>(s, a);
+        if (a.C2 + a.C3 > 0)
+            return f32h ? launch_huge<WIW_A_CONV3X3, false, false, 2, true>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 2>(s, a);
+        return f32h ? launch_huge<WIW_A_CONV3X3, false, false, 1, true>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 1>(s, a);
+    }
+    if (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) {      // fp32 residual stream (never GEGLU / split-K: huge_ok)
+        switch (a.mode) {
+            case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, false, 0, true>(s, a);
+            default: return launch_huge<WIW_A_CONV_T3, false, false, 0, true>(s, a);
+        }
     }
     if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)
         switch (a.mode) {

@@ -523,10 +523,10 @@ class UNetHIP:
         copy `key.weight_h`, WIW_K_HALO32) when the geometry and the epilogue fit it, else the per-tap kernels on `key.weight`."""
         w = self.w
         wh = w.get(key + ".weight_h")
-        if (wh is not None and splitk <= 1 and not epilogue and isinstance(wh, TiledW)
+        if (wh is not None and splitk <= 1 and not (epilogue & ~EPI_OUT_F32) and isinstance(wh, TiledW)
                 and self.hip.conv_halo_ok(M, N, C, H, W, up=mode == A_CONV3X3_UP)):
             self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W, bias=w[key + ".bias"],
-                          epilogue=K_HALO32, **kw)
+                          epilogue=K_HALO32 | epilogue, **kw)
         else:
             self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W,
                           bias=w[key + ".bias"], splitk=splitk, epilogue=epilogue | self.kc, **kw)
