@@ -41,7 +41,7 @@ MODE_NAMES = {0: "gemm_kernel<dense>", 1: "gemm_kernel<conv3x3>", 2: "gemm_kerne
               3: "gemm_kernel<conv3x3_up>", 4: "gemm_kernel<conv_t3>"}
 
 
-# the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK>
+# the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK, HALO, F32E>
 # = the 256x320 tile (gemm_huge.hip), gemm_kernel<MODE, WAVES, STAGES, GEGLU, LNFOLD, F32E> = the 256x160 / 128x160 tiles
 MODE_TEMPLATES = {
     0: ["gemm_huge_kernel<0, false, false, 0, false>", "gemm_huge_kernel<0, true, false, 0, false>", "gemm_kernel<0, 8, 3, false, false, false>",

@@ -1001,16 +1001,6 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
             return f32h ? launch_huge<WIW_A_CONV3X3, false, false, 2, true>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 2>(s, a);
         return f32h ? launch_huge<WIW_A_CONV3X3, false, false, 1, true>(s, a) : launch_huge<WIW_A_CONV3X3, false, false, 1>(s, a);
     }
-    if (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) {      // fp32 residual stream (never GEGLU / split-K: huge_ok)
-        switch (a.mode) {
-            case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, false, 0, true>(s, a);
-            case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false, 0, true>(s, a);
-            case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false, 0, true>(s, a);
-            case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false, 0, true>(s, a);
-            case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, false, 0, true>(s, a);
-            default: return launch_huge<WIW_A_CONV_T3, false, false, 0, true>(s, a);
-        }
-    }
     if (a.splitk > 1) {   // pass 1 of a split-K launch (gemm.hip's launch() hands over the fp32 workspace as `out`)
         switch (a.mode) {
             case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, true>(s, a);
@@ -1019,6 +1009,16 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
             case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, true>(s, a);
             case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, true>(s, a);
             default: return launch_huge<WIW_A_CONV_T3, false, true>(s, a);
+        }
+    }
+    if (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) {      // fp32 residual stream (never GEGLU: huge_ok; pass 1 of a split-K launch, whose `out` is the fp32 workspace, was taken above)
+        switch (a.mode) {
+            case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false, 0, true>(s, a);
+            case WIW_A_CONV3X3_S2P: return launch_huge<WIW_A_CONV3X3_S2P, false, false, 0, true>(s, a);
+            default: return launch_huge<WIW_A_CONV_T3, false, false, 0, true>(s, a);
         }
     }
     switch (a.mode) {
