@@ -46,7 +46,7 @@ extern "C" {
                                  stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
                                  wiw_cast_f32_to_16, wiw_calib_mfma;
                              12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
-                                 statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok */
+                                 statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream */
 
 int wiw_abi_version(void);
 
@@ -240,6 +240,14 @@ int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, con
                        const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
                        float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
                        int C_in, int hidden, int ln, float ln_eps);
+/* ABI 12: the same operator on the fp32 RESIDUAL STREAM (ABI 11): f32 bit 0 = `out` is fp32 [M][ldo], bit 1 = res1 is
+ * fp32, bit 2 = res2 is fp32 (leading dimensions in elements).  Bias, per-frame vector and residuals are added to the fp32
+ * accumulators in the fragment layout and the sum is rounded once (not at all for an fp32 `out`).  The in-kernel LayerNorm
+ * (`ln`) still reads a 16-bit X. */
+int wiw_ffn_geglu_f32stream(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                       const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
+                       float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
+                       int C_in, int hidden, int ln, float ln_eps, int f32);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) in NHWC, split into statistics + fused normalise/affine/SiLU.

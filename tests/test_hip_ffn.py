@@ -228,3 +228,34 @@ def test_ffn_fp16_build():
     out = torch.empty(M, C, dtype=dt, device=DEV)
     hip16.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, res1=r1.to(DEV), ldr1=C, beta1=1.0)
     check(out, oracle(x, wt, dt, res1=r1, beta1=1.0), dt, "ffn fp16 build")
+
+
+@pytest.mark.parametrize("M,rpv", [(700, 100), (3 * 9216 // 8, 9216 // 8), (130, 7), (256 * 128 + 77, 4096)])
+def test_ffn_fp32_residual_stream(hip, M, rpv):
+    """`wiw_ffn_geglu_f32stream` (ABI 12): fp32 res1 / res2 and an fp32 output — fp32 accumulator + bias + vector + residuals,
+    no rounding; a 16-bit output is the ONE rounding of the same sum; mixed 16-bit res1 + fp32 res2."""
+    dt = torch.bfloat16
+    wt = make_weights(dt, seed=21)
+    x = rnd(M, C, seed=11).to(dt)
+    r1, r2 = rnd(M, C, seed=12) * 3.0, rnd(M, C, seed=14)
+    nv = -(-M // rpv)
+    rv = rnd(nv, C, seed=13)
+    a = 0.3
+    kw = dict(rowvec=rv.to(DEV), rowvec_ld=C, rows_per_vec=rpv, ldr1=C, beta1=1.0 - a, ldr2=C, beta2=a, alpha=1.0 - a)
+    ref = oracle(x, wt, dt, rowvec=rv, rows_per_vec=rpv, res1=r1, beta1=1.0 - a, res2=r2, beta2=a, alpha=1.0 - a)
+    out32 = torch.full((M, C), float("nan"), dtype=torch.float32, device=DEV)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out32, M, res1=r1.to(DEV), res2=r2.to(DEV), **kw)
+    check(out32, ref, dt, f"ffn fp32 stream M={M} rpv={rpv}")
+    out16 = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out16, M, res1=r1.to(DEV), res2=r2.to(DEV), **kw)
+    assert torch.equal(out16.cpu(), out32.cpu().to(dt)), "16-bit output must be the ONE rounding of the fp32 result"
+    r1h = r1.to(dt)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out32, M, res1=r1h.to(DEV), res2=r2.to(DEV), **kw)
+    check(out32, ref - (1.0 - a) * r1 + (1.0 - a) * r1h.float(), dt, f"ffn fp32 stream, 16-bit res1 M={M}")
+    # against the staged 16-bit kernel on 16-bit residuals: the same value up to the staging's extra rounding
+    r2h = r2.to(dt)
+    o_st = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o_st, M, res1=r1h.to(DEV), res2=r2h.to(DEV), **kw)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out32, M, res1=r1h.to(DEV), res2=r2h.float().to(DEV), **kw)
+    d = (o_st.float() - out32).abs().max() / out32.abs().max()
+    assert float(d) <= 1.2e-2

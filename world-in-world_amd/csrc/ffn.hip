@@ -231,9 +231,14 @@ struct FfnArgs {
     const uint16_t* res2;   // [M][ldr2] or null
     uint16_t* out;          // [M][ldo]
     int M, ldx, ldo, ldr1, ldr2, rowvec_ld, rows_per_vec, ln;
+    int f32;                // F32E: bit 0 out, bit 1 res1, bit 2 res2 are fp32 (leading dimensions in ELEMENTS)
     float alpha, beta1, beta2, ln_eps;
 };
 
+// F32E (round 4, the fp32 residual stream of ABI 11 in this kernel): res1 / res2 / out may be fp32 (p.f32 bits 1 / 2 / 0); the
+// Y accumulators then take bias, per-frame vector and residuals in the FRAGMENT layout (a lane holds 4 consecutive columns of
+// a row: 16-byte fp32 / 8-byte 16-bit accesses) and are rounded once, or not at all — no 16-bit staging in between.
+template <bool F32E>
 __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -637,7 +642,55 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                         wave_lds_sync();
                     };
                     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+                    if constexpr (F32E) {
+                        const bool out_f32 = (p.f32 & 1) != 0, r1_f32 = (p.f32 & 2) != 0, r2_f32 = (p.f32 & 4) != 0;
+                        auto ld4 = [&](const void* base, bool f32, int64_t off) -> float4 {
+                            if (f32) return *(const float4*)((const float*)base + off);
+                            const uint2 u = *(const uint2*)((const uint16_t*)base + off);
+                            const wiw_f32x2 a = unpack2(u.x), b = unpack2(u.y);
+                            return float4{a.x, a.y, b.x, b.y};
+                        };
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            const int m = mw0 + mi * 16 + frow;
+                            const bool m_ok = m < p.M;
+                            const float* rv = p.rowvec ? p.rowvec + (int64_t)((m_ok ? m : p.M - 1) / p.rows_per_vec) * p.rowvec_ld : nullptr;
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {      // quarter passes of 5 column blocks: 2 x 20 residual registers in flight
+                                float4 rr1[5], rr2[5];
+#pragma unroll
+                                for (int j = 0; j < 5; ++j) {
+                                    const int n = (h * 5 + j) * 16 + fq * 4;
+                                    rr1[j] = (p.res1 && m_ok) ? ld4(p.res1, r1_f32, (int64_t)m * p.ldr1 + n) : float4{0.f, 0.f, 0.f, 0.f};
+                                    rr2[j] = (p.res2 && m_ok) ? ld4(p.res2, r2_f32, (int64_t)m * p.ldr2 + n) : float4{0.f, 0.f, 0.f, 0.f};
+                                }
+#pragma unroll
+                                for (int j = 0; j < 5; ++j) {
+                                    const int n = (h * 5 + j) * 16 + fq * 4;
+                                    if (m_ok) {
+                                        f32x4 v = accY[mi][h * 5 + j];
+                                        if (p.b2) { const float4 b = *(const float4*)(p.b2 + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                                        if (rv) { const float4 b = *(const float4*)(rv + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                                        v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+                                        const float4 f = rr1[j], g = rr2[j];
+                                        v[0] += p.beta1 * f.x + p.beta2 * g.x; v[1] += p.beta1 * f.y + p.beta2 * g.y;
+                                        v[2] += p.beta1 * f.z + p.beta2 * g.z; v[3] += p.beta1 * f.w + p.beta2 * g.w;
+                                        if (out_f32) {
+                                            float* d = (float*)p.out + (int64_t)m * p.ldo + n;
+                                            __builtin_nontemporal_store(v[0], d); __builtin_nontemporal_store(v[1], d + 1);
+                                            __builtin_nontemporal_store(v[2], d + 2); __builtin_nontemporal_store(v[3], d + 3);
+                                        } else {
+                                            uint32_t* d = (uint32_t*)(p.out + (int64_t)m * p.ldo + n);
+                                            __builtin_nontemporal_store(pack2bf(v[0], v[1]), d);
+                                            __builtin_nontemporal_store(pack2bf(v[2], v[3]), d + 1);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    } else {
                     pass(I0{}, I0{}); pass(I0{}, I1{}); pass(I1{}, I0{}); pass(I1{}, I1{});
+                    }
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -664,10 +717,12 @@ extern "C" int wiw_ffn_hwid_read(unsigned* out) {
 }
 #endif
 
-extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
-                                  const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
-                                  int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
-                                  int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps) {
+namespace {
+template <bool F32E>
+int ffn_launch(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+               const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
+               int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
+               int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps, int f32) {
     WIW_REQUIRE(X && W1 && b1 && W2 && out, "ffn_geglu: null X / W1 / b1 / W2 / out pointer");
     WIW_REQUIRE(C_in == C && hidden == HID, "ffn_geglu: built for C = 320, hidden = 1280 (the UNet's first level); use wiw_gemm_bf16 elsewhere");
     WIW_REQUIRE(M > 0 && M < (1ll << 31) - BM, "ffn_geglu: bad M");
@@ -682,7 +737,7 @@ extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const vo
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_LAUNCH) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel<F32E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_LAUNCH) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -697,9 +752,28 @@ extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const vo
     a.rowvec = rowvec; a.res1 = (const uint16_t*)res1; a.res2 = (const uint16_t*)res2; a.out = (uint16_t*)out;
     a.M = (int)M; a.ldx = ldx; a.ldo = ldo; a.ldr1 = ldr1; a.ldr2 = ldr2; a.rowvec_ld = rowvec_ld;
     a.rows_per_vec = rows_per_vec > 0 ? rows_per_vec : 1; a.ln = ln;
-    a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2; a.ln_eps = ln_eps;
+    a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2; a.ln_eps = ln_eps; a.f32 = f32;
     const int tiles = (int)((M + BM - 1) / BM);
     const int grid = tiles < num_cu ? tiles : num_cu;
-    hipLaunchKernelGGL(ffn_kernel, dim3((unsigned)grid), dim3(512), SMEM_LAUNCH, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ffn_kernel<F32E>, dim3((unsigned)grid), dim3(512), SMEM_LAUNCH, (hipStream_t)stream, a);
     return wiw_check_launch("wiw_ffn_geglu_bf16");
+}
+}  // namespace
+
+extern "C" int wiw_ffn_geglu_bf16(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                                  const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
+                                  int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
+                                  int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps) {
+    return ffn_launch<false>(stream, X, ldx, W1, b1, W2, b2, rowvec, rowvec_ld, rows_per_vec, res1, ldr1, beta1, res2, ldr2, beta2,
+                             alpha, out, ldo, M, C_in, hidden, ln, ln_eps, 0);
+}
+
+// ABI 12: the same operator on the fp32 residual stream — f32 bit 0: `out` is fp32, bit 1: res1, bit 2: res2 (include/wiw_svd.h)
+extern "C" int wiw_ffn_geglu_f32stream(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                                       const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
+                                       int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
+                                       int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps, int f32) {
+    WIW_REQUIRE(f32 >= 0 && f32 < 8, "ffn_geglu_f32stream: f32 is a 3-bit mask (out, res1, res2)");
+    return ffn_launch<true>(stream, X, ldx, W1, b1, W2, b2, rowvec, rowvec_ld, rows_per_vec, res1, ldr1, beta1, res2, ldr2, beta2,
+                            alpha, out, ldo, M, C_in, hidden, ln, ln_eps, f32);
 }

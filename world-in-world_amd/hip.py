@@ -105,6 +105,9 @@ EXPORTS = {
     "wiw_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "wiw_ffn_geglu_f32stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                     C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "wiw_clip_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -342,7 +345,16 @@ class Hip:
         flops = 2.0 * M * (2 * FFN_HIDDEN * FFN_C + FFN_C * FFN_HIDDEN)
         nbytes = 2.0 * M * FFN_C * (2 + (res1 is not None) + (res2 is not None)) + 2.0 * 3 * FFN_HIDDEN * FFN_C
 
+        f32 = ((out.dtype == torch.float32) * 1 + (res1 is not None and res1.dtype == torch.float32) * 2
+               + (res2 is not None and res2.dtype == torch.float32) * 4)
+
         def launch():
+            if f32:      # fp32 residual stream: the F32E instantiation (fragment-layout epilogue, one rounding)
+                self._ck(self.lib.wiw_ffn_geglu_f32stream(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec),
+                                                          rowvec_ld, rows_per_vec, _p(res1), ldr1, beta1, _p(res2), ldr2, beta2,
+                                                          alpha, _p(out), ldo, M, FFN_C, FFN_HIDDEN, 1 if ln else 0, ln_eps, f32),
+                         "wiw_ffn_geglu_f32stream")
+                return
             self._ck(self.lib.wiw_ffn_geglu_bf16(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec),
                                                  rowvec_ld, rows_per_vec, _p(res1), ldr1, beta1, _p(res2), ldr2, beta2, alpha,
                                                  _p(out), ldo, M, FFN_C, FFN_HIDDEN, 1 if ln else 0, ln_eps),

@@ -171,8 +171,10 @@ class UNetHIP:
         self.kc = 0 if os.environ.get("WIW_K_TAPMAJOR") else K_CMAJOR
         self.halo = not os.environ.get("WIW_CONV_NO_HALO")      # A/B knob: 3x3 convolutions without the halo-staged kernel
         self.halo_sc = not os.environ.get("WIW_CONV_NO_HALO_SC")  # A/B knob: ... except those with the fused shortcut segment
-        self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not self.res32
-        self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
+        # (fp32 stream: the fused kernel's F32E epilogue takes the fp32 residual / output; its in-kernel LayerNorm reads a
+        # 16-bit x, so there the norm stays the f32in LayerNorm pass)
+        self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not (self.res32 and os.environ.get("WIW_FF_UNFUSED_RES32"))
+        self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN") and not self.res32
         self._prepare(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -409,7 +411,7 @@ class UNetHIP:
         if (p + ".ffn.w1") in self.w:     # C = 320: ONE kernel, the [M, 4C] hidden tensor never exists (ffn.hip)
             ln = ln_input is not None
             assert not ln or (p + ".ffn.w1ln") in self.w
-            out = self._empty(M, Cn)
+            out = self._empty(M, Cn, dtype=torch.float32 if (stream and self.res32) else self.dtype)
             kw = {k: v for k, v in epi_kw.items() if k in ("rowvec", "rowvec_ld", "rows_per_vec", "res1", "ldr1", "beta1",
                                                            "res2", "ldr2", "beta2", "alpha")}
             assert len(kw) == len(epi_kw), f"unsupported FeedForward epilogue arguments: {set(epi_kw) - set(kw)}"
