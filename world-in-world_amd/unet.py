@@ -525,8 +525,13 @@ class UNetHIP:
         copy `key.weight_h`, WIW_K_HALO32) when the geometry and the epilogue fit it, else the per-tap kernels on `key.weight`."""
         w = self.w
         wh = w.get(key + ".weight_h")
+        # The two kernels sum K in different orders, so WHICH one runs must not depend on the batch in flight: the geometry
+        # test is made on the rows of ONE candidate as well (18 x 32 frames straddle tiles: 28 CFG frames of a candidate are
+        # 63 whole tiles, the 14 frames of a candidate without CFG are not — then every batch size takes the per-tap kernel)
+        up = mode == A_CONV3X3_UP
         if (wh is not None and splitk <= 1 and not (epilogue & ~EPI_OUT_F32) and isinstance(wh, TiledW)
-                and self.hip.conv_halo_ok(M, N, C, H, W, up=mode == A_CONV3X3_UP)):
+                and self.hip.conv_halo_ok(M, N, C, H, W, up=up)
+                and self.hip.conv_halo_ok(M // max(getattr(self, "_ncand", 1), 1), N, C, H, W, up=up)):
             self.hip.gemm(x, wh, out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W, bias=w[key + ".bias"],
                           epilogue=K_HALO32 | epilogue, **kw)
         else:
@@ -657,6 +662,7 @@ class UNetHIP:
         frames = cond.Bc * T
         M = frames * h * w_
         assert x_in.shape == (M, CIN_PAD) and (h % (1 << (n - 1)) == 0) and (w_ % (1 << (n - 1)) == 0)
+        self._ncand = cond.B        # `_conv3` decides from ONE candidate's rows (the bit-exact batch contract)
         temb_all = self._empty(frames, self.temb_total, dtype=torch.float32)
         hip.gemm(emb_silu, w["temb_all.weight"], temb_all, M=frames, N=self.temb_total, K=cfg.time_embed_dim,
                  C1=cfg.time_embed_dim, bias=w["temb_all.bias"], epilogue=EPI_OUT_F32)
