@@ -17,6 +17,12 @@
 // every SIMD one wave reads LDS / issues DMA while its partner issues 20 MFMAs back to back):
 //     R(k0: A, W[0:5]) | M | R(k0: W[5:10]) | M | R(k1: A, W[0:5]) | M | R(k1: W[5:10]), confirm next tile | M
 // DMA of K tile kt+1 (9 instructions per wave) is issued 2|2|2|2|1 in slots 0..4 of tile kt.
+//
+// Instantiations (template <MODE, GE, SK, HALO_, F32E>): GE = GEGLU epilogue (dense), SK = split-K pass 1 (raw fp32 slabs),
+// HALO_ = 1 / 2: the 3x3 convolutions (stride 1, and behind a nearest x2 upsample) with a halo-staged A operand, 2 = plus the
+// fused shortcut segment (round 4: 6 instead of 9 DMA instructions per wave and K tile, see the constants below), F32E = the
+// fragment-layout epilogue of the fp32 residual stream.  Each is its own instantiation because this kernel lives at the
+// 256-VGPR limit: a feature compiled into the common one costs every launch registers or scratch.
 #include <stdlib.h>
 #ifndef WIW_DMA_BURST
 #define WIW_DMA_BURST 0   // 1: all DMA instructions of a K tile in ONE slot; 0: spread over five slots (measured: burst -2...-5 % on this tile, +2...+4 % on the 256x160 tile and the temporal block)
