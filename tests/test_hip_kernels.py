@@ -275,6 +275,39 @@ def test_groupnorm_is_deterministic(hip):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[3], outs[4])
 
 
+@pytest.mark.parametrize("units,rpu,C,rpb", [(3, 16384 + 48, 64, 16), (2, 5000, 320, 16), (5, 640, 128, 16), (1, 37, 32, 16),
+                                            (4, 9216, 320, 128)])
+def test_groupnorm_statistics_in_one_launch(hip, units, rpu, C, rpb):
+    """ABI 12: the second reduction stage runs inside the statistics launch — the block that finishes last for a part of 32
+    blocks merges the part, the block that finds the unit's parts complete merges those (up to 33 parts here: the part loop runs
+    9 times; partial last parts; a unit of ONE block).  Against fp64 torch statistics, bit-identical over repeated launches
+    (whichever blocks finish last), counters back at zero after every launch."""
+    rows = units * rpu
+    x = bf(rnd(rows, C, seed=3) * 2.0 + rnd(1, C, seed=4) * 5.0)          # per-channel offsets: |mean| >> std in some groups
+    xd = dev_bf(x)
+    stats = torch.zeros(units * 64, dtype=torch.float32, device=DEV)
+    scratch = torch.empty(int(hip.lib.wiw_groupnorm_scratch_floats(rows, rpu, rpb)), dtype=torch.float32, device=DEV)
+    ncnt = int(hip.lib.wiw_groupnorm_counters(rows, rpu, rpb))
+    splits = -(-rpu // rpb)
+    assert ncnt == units * (-(-splits // 32) + 1)
+    cnt = torch.zeros(ncnt, dtype=torch.int32, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    runs = []
+    for _ in range(4):
+        stats.fill_(float("nan"))
+        assert hip.lib.wiw_groupnorm_stats(s, xd.data_ptr(), C, None, 0, rows, rpu, rpb, stats.data_ptr(), scratch.data_ptr(),
+                                           cnt.data_ptr()) == 0
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0, "counters must be left at zero"
+        runs.append(stats.clone())
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    st = runs[0].view(units, 32, 2).cpu().double()
+    ref = x.double().view(units, rpu, 32, C // 32).transpose(1, 2).reshape(units, 32, -1)
+    m, v = ref.mean(-1), ref.var(-1, unbiased=False)
+    assert float((st[..., 0] - m).abs().max() / m.abs().max()) <= 2e-6
+    assert float(((st[..., 1] - v).abs() / v).max()) <= 2e-5
+
+
 @pytest.mark.parametrize("rows,C", [(100, 64), (777, 320), (64, 1280), (50, 2048)])
 def test_layernorm(hip, rows, C):
     x = bf(rnd(rows, C, seed=1) * 1.7 + 0.3)
