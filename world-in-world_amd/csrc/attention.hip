@@ -100,23 +100,29 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
     // 64 rows of QK for K, 128 bytes of a V^T row); only the last tile needs the clamped / zero-filled form.
     const int rsub = lane >> 3, pos = lane & 7;
     const int nkt = (S + KB - 1) / KB;
-    const char* kp[NI];
-    const char* vp[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int r = (wave * NI + i) * 8 + rsub;          // row of the tile (key for K, d for V^T)
-        kp[i] = (const char*)(QK + (row0 + r) * ldqk + k_col_off + h * 64 + (pos ^ (r & 7)) * 8);
-        vp[i] = (const char*)(Vt + (int64_t)(h * 64 + r) * ldvt + row0 + (pos ^ ((r >> 1) & 7)) * 8);
-    }
+    // ONE K and ONE V^T pointer per lane (round 4): instruction i > 0 of a tile reads rows 8 i further on — for K a uniform
+    // byte offset (the chunk swizzle (r & 7) does not change), for V^T a uniform offset +- 64 bytes (its swizzle (r >> 1) & 7
+    // flips bit 2).  With four 64-bit pointers hipcc kept one in scratch (126 VGPRs at the 4-waves-per-SIMD cap): two
+    // scratch loads, a scratch store and — before the fourth DMA could be issued — an s_waitcnt vmcnt(0) that also waited
+    // for the three DMA loads just issued, i.e. a full memory round trip per tile and wave.
+    const int r0 = wave * NI * 8 + rsub;                    // row of the tile for instruction 0 (key for K, d for V^T)
+    const char* kp0 = (const char*)(QK + (row0 + r0) * ldqk + k_col_off + h * 64 + (pos ^ (r0 & 7)) * 8);
+    const char* vp0 = (const char*)(Vt + (int64_t)(h * 64 + r0) * ldvt + row0 + (pos ^ ((r0 >> 1) & 7)) * 8);
     const int64_t kstep = (int64_t)KB * ldqk * 2;
+    const int64_t k8 = (int64_t)8 * ldqk * 2;               // 8 K rows
+    // V^T rows 8 further on: the chunk position pos ^ sw becomes pos ^ sw ^ 4
+    const int64_t v8 = (int64_t)8 * ldvt * 2 + ((((pos ^ ((r0 >> 1) & 7)) & 4) != 0) ? -64 : 64);
+    auto kp_ = [&](int i) -> const char* { return i == 0 ? kp0 : kp0 + k8; };
+    auto vp_ = [&](int i) -> const char* { return i == 0 ? vp0 : vp0 + v8; };
+    static_assert(NI <= 2, "instruction i > 1 of a tile would flip the V^T swizzle back");
     auto issue = [&](int stage, int kt) {
         char* sK = smem + stage * KV_STAGE + wave * NI * 1024;
         char* sV = smem + stage * KV_STAGE + 8192 + wave * NI * 1024;
         if ((kt + 1) * KB <= S) {   // full tile (wave-uniform)
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                glds16(kp[i], sK + i * 1024);
-                glds16(vp[i], sV + i * 1024);
+                glds16(kp_(i), sK + i * 1024);
+                glds16(vp_(i), sV + i * 1024);
             }
         } else {
 #pragma unroll
@@ -124,15 +130,14 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
                 const int r = (wave * NI + i) * 8 + rsub;
                 // K rows past the end re-read the last key (masked to -inf below); V^T chunks past the end read zeros
                 const int key = kt * KB + r;
-                const char* ksrc = key < S ? kp[i] : kp[i] - (int64_t)(key - (S - 1)) * ldqk * 2;
+                const char* ksrc = key < S ? kp_(i) : kp_(i) - (int64_t)(key - (S - 1)) * ldqk * 2;
                 glds16(ksrc, sK + i * 1024);
                 const int key0 = kt * KB + (pos ^ ((r >> 1) & 7)) * 8;
-                glds16(key0 < S ? vp[i] : zeros, sV + i * 1024);
+                glds16(key0 < S ? vp_(i) : zeros, sV + i * 1024);
             }
         }
 #ifndef WIW_ATTN_STATIC_KV   // ablation build: every tile re-reads KV tile 0 (cache-hot operands)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) { kp[i] += kstep; vp[i] += KB * 2; }
+        kp0 += kstep; vp0 += KB * 2;
 #endif
     };
 
