@@ -41,18 +41,19 @@ MODE_NAMES = {0: "gemm_kernel<dense>", 1: "gemm_kernel<conv3x3>", 2: "gemm_kerne
               3: "gemm_kernel<conv3x3_up>", 4: "gemm_kernel<conv_t3>"}
 
 
-# the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK, HALO, F32E>
+# the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK, HALO, F32E, A1>
 # = the 256x320 tile (gemm_huge.hip), gemm_kernel<MODE, WAVES, STAGES, GEGLU, LNFOLD, F32E> = the 256x160 / 128x160 tiles
 MODE_TEMPLATES = {
-    0: ["gemm_huge_kernel<0, false, false, 0, false>", "gemm_huge_kernel<0, true, false, 0, false>", "gemm_kernel<0, 8, 3, false, false, false>",
+    0: ["gemm_huge_kernel<0, false, false, 0, false, true>", "gemm_huge_kernel<0, true, false, 0, false, true>",
+        "gemm_huge_kernel<0, false, false, 0, false, false>", "gemm_huge_kernel<0, true, false, 0, false, false>", "gemm_kernel<0, 8, 3, false, false, false>",
         "gemm_kernel<0, 8, 3, true, false, false>", "gemm_kernel<0, 4, 2, false, false, false>",
         "gemm_kernel<0, 4, 2, true, false, false>"],
-    1: ["gemm_huge_kernel<1, false, false, 1, false>", "gemm_huge_kernel<1, false, false, 2, false>", "gemm_huge_kernel<1, false, false, 0, false>",
-        "gemm_huge_kernel<1, false, true, 0, false>", "gemm_kernel<1, 8, 3, false, false, false>",
+    1: ["gemm_huge_kernel<1, false, false, 1, false, false>", "gemm_huge_kernel<1, false, false, 2, false, false>", "gemm_huge_kernel<1, false, false, 0, false, false>",
+        "gemm_huge_kernel<1, false, true, 0, false, false>", "gemm_kernel<1, 8, 3, false, false, false>",
         "gemm_kernel<1, 4, 2, false, false, false>", "splitk_reduce_kernel"],
-    2: ["gemm_huge_kernel<2, false, false, 0, false>", "gemm_kernel<2, 8, 3, false, false, false>", "gemm_kernel<2, 4, 2, false, false, false>"],
-    3: ["gemm_huge_kernel<3, false, false, 1, false>", "gemm_huge_kernel<3, false, false, 0, false>", "gemm_kernel<3, 8, 3, false, false, false>", "gemm_kernel<3, 4, 2, false, false, false>"],
-    4: ["gemm_huge_kernel<4, false, false, 0, false>", "gemm_kernel<4, 8, 3, false, false, false>", "gemm_kernel<4, 4, 2, false, false, false>"],
+    2: ["gemm_huge_kernel<2, false, false, 0, false, false>", "gemm_kernel<2, 8, 3, false, false, false>", "gemm_kernel<2, 4, 2, false, false, false>"],
+    3: ["gemm_huge_kernel<3, false, false, 1, false, false>", "gemm_huge_kernel<3, false, false, 0, false, false>", "gemm_kernel<3, 8, 3, false, false, false>", "gemm_kernel<3, 4, 2, false, false, false>"],
+    4: ["gemm_huge_kernel<4, false, false, 0, false, false>", "gemm_kernel<4, 8, 3, false, false, false>", "gemm_kernel<4, 4, 2, false, false, false>"],
 }
 
 

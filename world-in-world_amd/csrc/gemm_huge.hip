@@ -112,7 +112,10 @@ WIW_DEV WiwKCur wiw_advance_k(WiwKCur c, const int Ctot, const bool cmajor) {   
 // columns of a row: 16-byte fp32 / 8-byte 16-bit accesses in 64-byte row runs) and the sum is rounded once, or not at all.
 // gemm.hip's 256x160 / 128x160 kernels have carried this epilogue since ABI 11; here it is its own instantiation for the
 // same reason as there (compiled into the common one its residual registers cost every launch scratch).
-template <int MODE, bool GE, bool SK, int HALO_ = 0, bool F32E = false>
+// A1 (dense mode): ONE source (C2 = 0) and every row present (M % 256 = 0) — the A fetch then has no exec-masked row test
+// and no concat-source test in front of it.  As a template argument: compiled out, the two tests cost the long-K dense
+// launches 3-4 % (profiles/r10v_dense_a_fetch_tests_ablation.txt); behind a uniform run-time flag the gain was < 1 %.
+template <int MODE, bool GE, bool SK, int HALO_ = 0, bool F32E = false, bool A1 = false>
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     static_assert(!F32E || (!GE && !SK), "the fp32-stream epilogue: plain launches only");
     constexpr bool HALO = HALO_ != 0, HSEG = HALO_ == 2;
@@ -250,8 +253,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         }
     };
 
+    static_assert(!A1 || (MODE == WIW_A_DENSE && !SK), "A1 is a dense-mode loader variant");
     auto a_src = [&](int i, int tap, int cc) -> const char* {
         if (MODE == WIW_A_DENSE) {
+            if constexpr (A1) return Ab + ((int64_t)a_m[i] * p.C1 + cc + chunk * 8) * 2;
             if (!a_ok[i]) return zeros;
             if (cc < p.C1) return Ab + ((int64_t)a_m[i] * p.C1 + cc + chunk * 8) * 2;
             return A2b + ((int64_t)a_m[i] * p.C2 + (cc - p.C1) + chunk * 8) * 2;
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     }
 }
 
-template <int MODE, bool GE, bool SK, int HALO = 0, bool F32E = false>
+template <int MODE, bool GE, bool SK, int HALO = 0, bool F32E = false, bool A1 = false>
 int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     constexpr int SMEM = HALO ? HALO_SMEM : H_SMEM;
     // one-time, thread-safe setup per template instantiation: opt in to > 64 KiB of dynamic LDS, read the CU count
@@ -915,7 +920,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK, HALO, F32E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)gemm_huge_kernel<MODE, GE, SK, HALO, F32E, A1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -931,7 +936,7 @@ int launch_huge(hipStream_t s, const WiwGemmArgs& a) {
     static const char* stg_env = getenv("WIW_GEMM_STAGGER");
     static const char* sn_env = getenv("WIW_GEMM_SN");
     const int stagger = ((stg_env ? atoi(stg_env) : 0) & 255) | ((sn_env ? atoi(sn_env) & 15 : 0) << 8);
-    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK, HALO, F32E>), dim3((unsigned)grid), dim3(512), SMEM, s, a, stagger);
+    hipLaunchKernelGGL((gemm_huge_kernel<MODE, GE, SK, HALO, F32E, A1>), dim3((unsigned)grid), dim3(512), SMEM, s, a, stagger);
     return wiw_check_launch("wiw_gemm_bf16(huge)");
 }
 
@@ -995,6 +1000,7 @@ extern "C" int wiw_conv_halo_ok(const WiwGemmArgs* args) { return args != nullpt
 
 int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
     const bool ge = (a.epilogue & WIW_EPI_GEGLU) != 0;
+    const bool a1 = a.mode == WIW_A_DENSE && a.C2 == 0 && a.M % HM == 0 && !getenv("WIW_GEMM_NO_A1");   // the A1 loader variant
     if (a.epilogue & WIW_K_HALO32) {
         if (!wiw_conv_halo_shape_ok(a)) {
             wiw_set_error("gemm: WIW_K_HALO32 launch outside the halo kernel's geometry (wiw_conv_halo_ok)");
@@ -1019,7 +1025,8 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
     }
     if (a.epilogue & (WIW_EPI_OUT_F32 | WIW_EPI_RES1_F32 | WIW_EPI_RES2_F32)) {      // fp32 residual stream (never GEGLU: huge_ok; pass 1 of a split-K launch, whose `out` is the fp32 workspace, was taken above)
         switch (a.mode) {
-            case WIW_A_DENSE: return launch_huge<WIW_A_DENSE, false, false, 0, true>(s, a);
+            case WIW_A_DENSE: return a1 ? launch_huge<WIW_A_DENSE, false, false, 0, true, true>(s, a)
+                                        : launch_huge<WIW_A_DENSE, false, false, 0, true>(s, a);
             case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false, 0, true>(s, a);
             case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false, 0, true>(s, a);
             case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false, 0, true>(s, a);
@@ -1028,7 +1035,9 @@ int wiw_gemm_huge_launch(hipStream_t s, const WiwGemmArgs& a) {
         }
     }
     switch (a.mode) {
-        case WIW_A_DENSE: return ge ? launch_huge<WIW_A_DENSE, true, false>(s, a) : launch_huge<WIW_A_DENSE, false, false>(s, a);
+        case WIW_A_DENSE:
+            if (a1) return ge ? launch_huge<WIW_A_DENSE, true, false, 0, false, true>(s, a) : launch_huge<WIW_A_DENSE, false, false, 0, false, true>(s, a);
+            return ge ? launch_huge<WIW_A_DENSE, true, false>(s, a) : launch_huge<WIW_A_DENSE, false, false>(s, a);
         case WIW_A_CONV3X3: return launch_huge<WIW_A_CONV3X3, false, false>(s, a);
         case WIW_A_CONV3X3_S2: return launch_huge<WIW_A_CONV3X3_S2, false, false>(s, a);
         case WIW_A_CONV3X3_UP: return launch_huge<WIW_A_CONV3X3_UP, false, false>(s, a);
