@@ -368,7 +368,7 @@ def test_reference_trajectory_25_steps_served_width(name, res32, golden):
     assert rms <= gate and rms_w <= gate_w
 
 
-# 1.25 x the round-4 measurement (profiles/r10u_gpu_suite_*.log: 6.42e-4, 9.04e-4, 7.69e-3); both fp16 configurations are
+# 1.25 x the round-4 measurement (profiles/r10y_gpu_suite_*.log: 6.42e-4, 9.04e-4, 7.69e-3); both fp16 configurations are
 # inside north_star's 1e-3 on this workload too
 CONFIG0_GATES = {("fp16", True): 8.0e-4, ("fp16", False): 1.0e-3, ("bf16", False): 9.6e-3}
 
