@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 12  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 13  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -46,7 +46,8 @@ extern "C" {
                                  stores, wiw_groupnorm_stats_f32in / wiw_groupnorm_apply_stats_f32in / wiw_layernorm_f32in /
                                  wiw_cast_f32_to_16, wiw_calib_mfma;
                              12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
-                                 statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream */
+                                 statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream;
+                             13: wiw_attn_spatial_ps_bf16 (32x32x16 spatial attention on a pre-scaled Q) */
 
 int wiw_abi_version(void);
 
@@ -184,6 +185,15 @@ int wiw_conv_halo_ok(const WiwGemmArgs* args);
  * ---------------------------------------------------------------------------------------------- */
 int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt,
                           void* O, int ldo, int frames, int S, int heads, float scale, const void* zeros);
+
+/* The same operator on a PRE-SCALED Q (ABI 13): the caller folded log2(e) / sqrt(64) into the to_q rows of the q|k|v
+ * projection before their rounding to 16 bits (dp/models/attention_processor.py:2358-2366 computes the three projections
+ * separately and F.scaled_dot_product_attention, :2383, applies 1/sqrt(d)), so that Q.K is the base-2 exponent itself.
+ * S % 128 == 0, S >= 256 (the 72x128, 36x64 and 32x32 levels): v_mfma_f32_32x32x16 kernel, the softmax of one 32-key half
+ * tile issued between the matrix instructions of the next (csrc/attention32.hip); other S: the kernel above with scale = 1.
+ * Same operand layouts as wiw_attn_spatial_bf16; ldo % 8 == 0. */
+int wiw_attn_spatial_ps_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt,
+                             void* O, int ldo, int frames, int S, int heads, const void* zeros);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal self-attention over the T (<= 16) frames of every spatial site, head_dim 64:

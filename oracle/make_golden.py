@@ -31,6 +31,8 @@ Fixtures written (all fp32 unless noted):
                            tiny random VAE/CLIP; image latents / CLIP embeds captured at the UNet boundary
   pipeline_full_16x32.npz  the same __call__ for the FULL 25 steps with the served-width UNet at a 16x32 latent (T = 14):
                            final latents + every 5th step, fp32 and fp32-on-16-bit-rounded-weights (`pipeline_full`, ~1 h)
+  unet_northstar_72x128.npz  ONE fp32 forward of the served UNet at the BENCHMARKED size, sample (2,14,8,72,128) (`unet_northstar`, ~20 min):
+                           fp32 output + the fp32-math outputs on fp16- / bf16-rounded weights as fp16 differences; inputs from a seed
   pipeline_config0_32x32.npz  BASELINE config 0 (256x256x8, 10 steps) through the same __call__, served-width UNet built for 8 frames
 """
 import os
@@ -256,6 +258,45 @@ def gen_unet_full(ns):
          added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(),
          out_ref_bf16_weights_fp32_math=out_w.numpy(), out_ref_bf16=out_bf16.float().numpy(),
          out_ref_fp16_weights_fp32_math=out_w16.numpy(), out_ref_fp16=out_fp16.float().numpy())
+
+
+def gen_unet_northstar(ns):
+    """ONE forward of the reference UNet at the BENCHMARKED size: sample (2, 14, 8, 72, 128) = 576x1024x14
+    with CFG, S = 9216 keys in the spatial attention, 18 432-site temporal batches, GroupNorm units of 2.6 M elements — what the
+    16x32 fixtures do not exercise.  Inputs are NOT stored (8 MB): `unet_inputs(cfg, 1, 72, 128, seed=31)` regenerates them
+    (numpy's frozen legacy RandomState), a float64 checksum pins them.  Stored: the fp32 output (4 MB) and, as float16
+    DIFFERENCES from it, the fp32-arithmetic outputs on fp16- and bf16-rounded weights (the error floor of any 16-bit-weight
+    evaluation; the difference is ~1e-3 of the output so its fp16 rounding is ~1e-6 of it).  ~5-8 min per forward on 8 cores.
+    reference: dp/models/unets/unet_spatio_temporal_condition.py:402-575."""
+    import time
+    cfg = UNetConfig()
+    h, w = 72, 128
+    t = 0.68666  # t_12 of the 25-step table (sigma 15.59), as unet_full_16x32
+    sample, ehs, tids, acts = unet_inputs(cfg, 1, h, w, seed=31)
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    args = (torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids))
+    outs = {}
+    for tag, dt in (("fp32", None), ("fp16w", torch.float16), ("bf16w", torch.bfloat16)):
+        if os.environ.get("WIW_NORTHSTAR_ONLY") and tag not in os.environ["WIW_NORTHSTAR_ONLY"].split(","):
+            continue
+        m = ref_unet(ns, cfg, seed=4)
+        if dt is not None:
+            for prm in m.parameters():
+                prm.data = prm.data.to(dt).to(torch.float32)
+        t0 = time.time()
+        with torch.no_grad():
+            outs[tag] = m(*args, return_dict=False, added_action_ids=aid)[0].numpy()
+        print(f"northstar {tag}: {time.time() - t0:.0f} s, rms {np.sqrt((outs[tag].astype(np.float64) ** 2).mean()):.5f}", flush=True)
+        del m
+    extra = {}
+    if "fp16w" in outs:
+        extra["diff_fp16_weights_fp32_math"] = (outs["fp16w"] - outs["fp32"]).astype(np.float16)
+    if "bf16w" in outs:
+        extra["diff_bf16_weights_fp32_math"] = (outs["bf16w"] - outs["fp32"]).astype(np.float16)
+    save("unet_northstar_72x128.npz", weight_seed=np.array(4), input_seed=np.array(31), timestep=np.array(t, dtype=np.float32),
+         latent_hw=np.array([h, w]), sample_checksum=np.array(sample.astype(np.float64).sum()),
+         sample_abs_checksum=np.array(np.abs(sample.astype(np.float64)).sum()),
+         added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=outs["fp32"], **extra)
 
 
 def gen_schema(ns):
@@ -560,7 +601,8 @@ def main():
     torch.set_num_threads(8)
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
                 pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
-                pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0, manip=gen_manip)
+                pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0, manip=gen_manip,
+                unet_northstar=gen_unet_northstar)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
     for name, fn in gens.items():
         if not only or name in only:

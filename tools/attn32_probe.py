@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Round 5: the 32x32x16 spatial attention (wiw_attn_spatial_ps_bf16) against torch SDPA in fp32 and against the first form,
+at the level shapes; correctness (max / rms deviation of both kernels from the fp32 result on the same 16-bit operands) and
+HIP-event timing.  CHECK=0 skips the reference (PMC / timing-only runs); SHAPES=9216x5,2304x10 selects."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import wiw_amd  # noqa: E402,F401
+from wiw_amd import hip as H  # noqa: E402
+
+PRESCALE = 0.125 * 1.4426950408889634
+
+
+def main():
+    dev = torch.device("cuda:0")
+    hip = H.Hip(dev)
+    dt = hip.dtype
+    iters = int(os.environ.get("ITERS", "10"))
+    check = os.environ.get("CHECK", "1") != "0"
+    shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("SHAPES", "9216x5,2304x10,1024x5,256x10").split(",")]
+    for S, heads in shapes:
+        frames = int(os.environ.get("FRAMES", "28"))
+        C, M = heads * 64, frames * S
+        g = torch.Generator(device=dev).manual_seed(S + heads)
+        q = torch.randn(M, C, device=dev, generator=g)
+        k = torch.randn(M, C, device=dev, generator=g)
+        v = torch.randn(M, C, device=dev, generator=g)
+        if os.environ.get("SPIKE"):   # a few large keys late in the sequence: forces the rescale branch
+            k[S // 2 + 7] *= 6.0
+            k[S - 3] *= 9.0
+        qk = torch.cat([q, k], dim=1).to(dt).contiguous()
+        qk_ps = torch.cat([q * PRESCALE, k], dim=1).to(dt).contiguous()
+        vt = v.to(dt).t().contiguous()
+        o1 = torch.empty(M, C, dtype=dt, device=dev)
+        o2 = torch.empty(M, C, dtype=dt, device=dev)
+        hip.attn_spatial(qk, 2 * C, C, vt, M, o1, C, frames, S, heads, 0.125)
+        hip.attn_spatial_ps(qk_ps, 2 * C, C, vt, M, o2, C, frames, S, heads)
+        torch.cuda.synchronize()
+        if check:
+            nf = min(frames, 4)
+            def ref(qq, scale):
+                Q = qq[: nf * S, :C].float().view(nf, S, heads, 64).transpose(1, 2)
+                K = qq[: nf * S, C:].float().view(nf, S, heads, 64).transpose(1, 2)
+                V = vt.t()[: nf * S].float().view(nf, S, heads, 64).transpose(1, 2)
+                return torch.nn.functional.scaled_dot_product_attention(Q, K, V, scale=scale).transpose(1, 2).reshape(nf * S, C)
+            r1 = ref(qk, 0.125)
+            r2 = ref(qk_ps, 0.125 / PRESCALE)   # exp(s / ln2-domain): softmax(q' k ln 2) on the pre-scaled operands
+            for name, o, r in (("v1", o1, r1), ("v2-32x32", o2, r2)):
+                d = (o[: nf * S].float() - r)
+                print(f"   {name:9s} vs fp32 SDPA: max {d.abs().max().item():.3e}  rms {d.pow(2).mean().sqrt().item():.3e}  "
+                      f"(ref rms {r.pow(2).mean().sqrt().item():.3e})  nan {int(torch.isnan(o.float()).sum().item())}", flush=True)
+            d12 = (o1.float() - o2.float())
+            print(f"   v1 - v2 (all frames): max {d12.abs().max().item():.3e} rms {d12.pow(2).mean().sqrt().item():.3e}")
+        for name, fn in (("v1", lambda: hip.attn_spatial(qk, 2 * C, C, vt, M, o1, C, frames, S, heads, 0.125)),
+                         ("v2-32x32", lambda: hip.attn_spatial_ps(qk_ps, 2 * C, C, vt, M, o2, C, frames, S, heads))):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            fl = 4.0 * frames * heads * S * S * 64
+            print(f"attn_spatial {name:9s} frames={frames} S={S} heads={heads}: {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

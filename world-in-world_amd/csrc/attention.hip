@@ -24,6 +24,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef WIW_ATTN_MIN_WAVES
 #define WIW_ATTN_MIN_WAVES 2   // launch-bounds hint (waves per SIMD); the kernel needs 126 VGPRs = 4 waves per SIMD on its own
 #endif                         // (5: capped at 96 VGPRs, 27 spilled in the tile loop: 7.2 instead of 3.5 ms at S = 9216)
+#ifndef WIW_ATTN_PRIO
+#define WIW_ATTN_PRIO 0   // A/B: s_setprio 1 around the softmax (1) or around the two MFMA bursts (2) of a tile
+#endif
 #ifndef WIW_ATTN_ABLATE
 #define WIW_ATTN_ABLATE 0   // timing experiments only (results wrong): 1 no max / exp2 (P = bf16(S)), 2 no K/V DMA + no tile
 #endif                      // barrier (stale stage 0), 4 no P.V MFMAs, 8 no Q.K MFMAs
@@ -169,6 +172,9 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
         const char* sV = sK + 8192;
         // ---- S^T = K . Q^T  (4 key frags x 2 query frags x 2 d steps)
         f32x4 s[4][2];
+#if WIW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             // Which key sits in which row of a fragment is free.  Row i of fragment kf holds key
@@ -196,6 +202,11 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
         // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag.
         // Scores stay unscaled: p = exp2(s*c - m) with c = log2(e)/sqrt(d) folded into one FMA; the running max
         // m is kept in the scaled domain.  v_exp_f32 is used raw (arguments <= 0; denormal results flush to 0).
+#if WIW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#elif WIW_ATTN_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
         if ((kt + 1) * KB > S) {   // wave-uniform: only the last, partial tile masks keys >= S
 #pragma unroll
             for (int f = 0; f < 2; ++f)
@@ -258,6 +269,11 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
 #endif
         // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps); both operands in the natural K enumeration
         // thanks to the key permutation of the S^T fragments above
+#if WIW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#elif WIW_ATTN_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int drow = d * 16 + fr;
@@ -281,6 +297,9 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
                 }
             }
         }
+#if WIW_ATTN_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if !(WIW_ATTN_ABLATE & 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
 }  // namespace
 
 static int attn_spatial_launch(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O, int ldo,
-                               int frames, int S, int heads, float scale, const void* zeros, float* lse) {
+                               int frames, int S, int heads, float scale_log2e, const void* zeros, float* lse) {
     WIW_REQUIRE(QK && Vt && O && zeros, "attn_spatial: null pointer");
     WIW_REQUIRE(frames > 0 && S > 0 && heads > 0, "attn_spatial: bad sizes");
     WIW_REQUIRE(S % 8 == 0, "attn_spatial: S (= h*w of the level) must be a multiple of 8");
@@ -413,7 +432,7 @@ static int attn_spatial_launch(void* stream, const void* QK, int ldqk, int k_col
     WIW_REQUIRE(nb < (1ll << 31), "attn_spatial: grid too large");
 #define WIW_ATTN_LAUNCH(NW, WL)                                                                                                    \
     hipLaunchKernelGGL((attn_spatial_kernel<NW, WL>), dim3((unsigned)nb), dim3(NW * 64), 0, (hipStream_t)stream, (const uint16_t*)QK, \
-                       ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale * LOG2E,            \
+                       ldqk, k_col_off, (const uint16_t*)Vt, ldvt, (uint16_t*)O, ldo, S, heads, q_tiles, scale_log2e,              \
                        (const char*)zeros, lse)
     if (lse) WIW_ATTN_LAUNCH(4, true);
     else if (big) WIW_ATTN_LAUNCH(8, false);
@@ -425,14 +444,21 @@ static int attn_spatial_launch(void* stream, const void* QK, int ldqk, int k_col
 extern "C" int wiw_attn_spatial_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
                                      int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
                                      const void* zeros) {
-    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, zeros, nullptr);
+    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale * LOG2E, zeros, nullptr);
+}
+
+// The first form on operands whose Q is pre-scaled by log2(e) / sqrt(d) (wiw_attn_spatial_ps_bf16, attention32.hip): the
+// sequences the 32x32x16 kernel does not take (S % 128 != 0 or S < 256: the 18x32 / 9x16 levels)
+int wiw_attn_spatial_prescaled_fallback(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt, int64_t ldvt, void* O,
+                                        int ldo, int frames, int S, int heads, const void* zeros) {
+    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, 1.0f, zeros, nullptr);
 }
 
 extern "C" int wiw_attn_spatial_lse_bf16(void* stream, const void* QK, int ldqk, int k_col_off, const void* Vt,
                                          int64_t ldvt, void* O, int ldo, int frames, int S, int heads, float scale,
                                          const void* zeros, float* lse) {
     WIW_REQUIRE(lse, "attn_spatial_lse: null lse pointer");
-    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, zeros, lse);
+    return attn_spatial_launch(stream, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale * LOG2E, zeros, lse);
 }
 
 extern "C" int wiw_attn_temporal_bf16(void* stream, const void* QKV, int ldqkv, void* O, int ldo, int batch, int T,

@@ -93,6 +93,8 @@ EXPORTS = {
     "wiw_gemm_bf16": (C.c_int, [C.c_void_p, C.POINTER(WiwGemmArgs)]),
     "wiw_attn_spatial_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "wiw_attn_spatial_ps_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wiw_attn_spatial_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "wiw_attn_bwd_given_lse_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -205,7 +207,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 12:
+        if self.lib.wiw_abi_version() != 13:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -318,6 +320,13 @@ class Hip:
         self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
             self.lib.wiw_attn_spatial_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
                                            frames, S, heads, scale, self.zeros.data_ptr()), "wiw_attn_spatial_bf16"))
+        return O
+
+    def attn_spatial_ps(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads):
+        """Spatial attention on a Q that the projection pre-scaled by ATTN_PRESCALE = log2(e) / sqrt(64) (csrc/attention32.hip)."""
+        self._timed("attn_spatial", 4.0 * frames * heads * S * S * 64, 8.0 * frames * S * heads * 64, lambda: self._ck(
+            self.lib.wiw_attn_spatial_ps_bf16(self._stream(), _p(QK), ldqk, k_col_off, _p(Vt), ldvt, _p(O), ldo,
+                                              frames, S, heads, self.zeros.data_ptr()), "wiw_attn_spatial_ps_bf16"))
         return O
 
     def attn_temporal(self, QKV, ldqkv, O, ldo, batch, T, S, heads, scale):
