@@ -47,6 +47,18 @@ WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((
 #define WIW_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
 
+#ifndef WIW_A32_FORM
+#define WIW_A32_FORM 2    // 2: hand-placed gaps (every MFMA gap its own scheduling region); 1: the first correct form
+#endif
+#ifndef WIW_A32_LSUM_MFMA
+#define WIW_A32_LSUM_MFMA 1   // form 2: row sums by a 16x16x32 MFMA on the P registers (1) or by v_add_f32 (0)
+#endif
+#ifndef WIW_A32_ABLATE
+#define WIW_A32_ABLATE 0   // timing experiments only (results wrong): 1 no softmax VALU (exp / pack / max / decision), 2 no K/V
+#endif                     // DMA + no tile barrier, 4 no LDS reads, 8 Q.K MFMAs independent (C = 0 each), 16 no P.V MFMAs
+#ifndef WIW_A32_WAVES
+#define WIW_A32_WAVES 3   // waves per SIMD the register budget is cut for (3: 168 VGPRs, 2: 256)
+#endif
 #ifndef WIW_A32_SCHED
 #define WIW_A32_SCHED 1   // 1: sched_group_barrier interleave inside the segments; 0: hipcc's own order (A/B)
 #endif
@@ -98,7 +110,10 @@ constexpr float A2_THR = 8.0f;
 #define A32_INTERLEAVE(NV)
 #endif
 
-__global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
+struct Ph0 { static constexpr int value = 0; };
+struct Ph1 { static constexpr int value = 1; };
+
+__global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
                                                                 const uint16_t* __restrict__ Vt, int64_t ldvt,
                                                                 uint16_t* __restrict__ O, int ldo, int S, int heads, int q_tiles) {
     __shared__ __attribute__((aligned(16))) char smem[A2_NSTAGE * A2_STAGE];
@@ -134,14 +149,14 @@ __global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* 
     const int64_t flip = (sl0 & 4) ? -64 : 64;
     const int64_t k8 = (int64_t)8 * ldqk * 2 + flip, v8 = (int64_t)8 * ldvt * 2 + flip;
     const int64_t kstep = (int64_t)64 * ldqk * 2;
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage, bool adv = true) {   // adv (wave-uniform): step the source to the next tile afterwards
         char* sK = smem + stage * A2_STAGE + wave * 2048;
         glds16(kp, sK);
         glds16(kp + k8, sK + 1024);
         glds16(vp, sK + 8192);
         glds16(vp + v8, sK + 8192 + 1024);
-        kp += kstep;
-        vp += 128;
+        kp += adv ? kstep : 0;
+        vp += adv ? 128 : 0;
     };
 
     // ---- LDS read addresses of this lane: A-operand fragment (row li of a 32-row block, 16-byte chunk 2 ks + hi)
@@ -170,13 +185,255 @@ __global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* 
         for (int i = 0; i < 4; ++i) a[i] += d;
     };
 
+#if WIW_A32_FORM == 2
+    f32x16 S0, S1, o[2];
+#else
     f32x16 S0, S1, negm, o[2];
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float ls0 = 0.f, ls1 = 0.f;     // this lane's share (its 16 of every 32 keys) of the row sum, two chains
     union { uint32_t u[4]; bf16x8 v; } pb[2];   // P^T B operands of the two key steps of a half tile
     bf16x8 fa[4], fb[4];
+    const int nkt = S / 64;
 
+#if WIW_A32_FORM == 2
+    // ================= hand-placed form: every MFMA gap is its own scheduling region =================
+    // LDS reads are asm statements (they stay in their gap; hipcc's IR-level sinking otherwise moves a plain load next to
+    // its user) with ONE s_waitcnt per fragment set at the end of the segment that issued it (cdna guide 5.7 form ii).
+#define A32_DSR_(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define A32_WAIT4_(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#if WIW_A32_ABLATE & 4
+#define A32_DSR(dst, addr, off)
+#define A32_WAIT4(f) asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#else
+#define A32_DSR(dst, addr, off) A32_DSR_(dst, addr, off)
+#define A32_WAIT4(f) A32_WAIT4_(f)
+#endif
+#define A32_GAP                                                 \
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 16, 0);       \
+    __builtin_amdgcn_sched_barrier(0);
+    float p[16];
+#if WIW_A32_LSUM_MFMA
+    // Row sums on the matrix pipe: one v_mfma_f32_16x16x32 per key step reads the SAME P registers as its B operand.  Under
+    // the 16x16x32 operand map lane l supplies column l & 15, k group l >> 4 — i.e. column n collects query n (k groups 0, 2)
+    // and query n + 16 (k groups 1, 3); an A operand whose row 0 is ones on k groups {0, 2} and row 1 ones on {1, 3} gives
+    // D[0][n] = sum_k P[k][n], D[1][n] = sum_k P[k][n + 16]: registers 0 / 1 of lanes 0..15.  32 v_add per tile less, for 4
+    // half-size MFMAs (the matrix pipe is the one with idle time; a SIMD retires about one instruction per 5.3 cycles
+    // whatever its wave count, profiles/r11d_pmc_attn.csv, so the instruction count is the cost).
+    f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 onesA;
+    {
+        const bool on = lane == 0 || lane == 32 || lane == 17 || lane == 49;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) onesA[e] = on ? (short)WIW_ONE16 : (short)0;
+    }
+#define A32_LSUM(ks) lacc = WIW_MFMA(onesA, pb[ks].v, lacc)
+#else
+#define A32_LSUM(ks)
+#endif
+    // The accumulator of a Q.K segment starts at -m.  hipcc cannot take a 16-register C operand that differs from D without
+    // copying it first (8 v_mov_b64 per block; behind the rescale branch it keeps TWO live copies of the block), and a fill
+    // from a scalar costs the same.  The matrix pipe does it in ONE instruction: X = A1 . Bm with A1[i][0] = 1, Bm[0][n] = -m_n
+    // (everything else 0, C = 0).  For that product to be exact m is kept on the 16-bit grid of the operand type (it only has
+    // to bound the exponents), so a raise m -> m' has an exactly representable difference and exp2(m - m') rescales O and l
+    // consistently.
+    bf16x8 initA, initB;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { initA[e] = 0; initB[e] = 0; }
+    initA[0] = hi == 0 ? (short)WIW_ONE16 : (short)0;
+    float mref;   // the reference of this lane's query (a 16-bit-representable value)
+    // One half iteration = a Q.K segment producing Xp (half tile PH of tile j) and a P.V segment consuming Xc (the half tile
+    // before it), 9 MFMA gaps with <= 4 VALU issues each (a 32x32x16 MFMA hides four: tools/ubench/mfma_fill.hip T1):
+    // exponentials and packs of Xc first (the P.V MFMAs need them), then the maximum of the fresh block.
+#if WIW_A32_ABLATE & 1
+#define A32_EXP(x) (x)
+#define A32_PACK(dst, a, b)
+#define A32_MAX3(a, b, c) (a)
+#else
+#define A32_EXP(x) __builtin_amdgcn_exp2f(x)
+#define A32_PACK(dst, a, b) dst = pack2bf(a, b)
+#define A32_MAX3(a, b, c) max3r(a, b, c)
+#endif
+#if WIW_A32_ABLATE & 8
+#define A32_QKC(X) zero
+#else
+#define A32_QKC(X) X
+#endif
+#if WIW_A32_ABLATE & 16
+#define A32_PV(acc, a, b) asm volatile("" : "+v"(acc) : "v"(a), "v"(b))
+#else
+#define A32_PV(acc, a, b) acc = WIW_MFMA32(a, b, acc)
+#endif
+    auto half = [&](auto ph_tag, auto sync_tag, f32x16& Xc, f32x16& Xp, int j, int& stage) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool SYNC = decltype(sync_tag)::value != 0;
+        constexpr int VK = PH == 0 ? 2 : 0;              // key step (of the tile) of the consumed half tile's first V fragment
+        constexpr int KOFF = PH == 0 ? 4096 : 0;         // next K fragments: K(j, h1) after phase 0, K(j+1, h0) after phase 1
+        const int nstage = stage == A2_NSTAGE - 1 ? 0 : stage + 1;
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        // ---- Q.K segment
+        Xp = WIW_MFMA32(initA, initB, zero);
+        A32_DSR(fa[0], vaddr[VK], 0);
+        A32_DSR(fa[1], vaddr[VK], 4096);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = A32_EXP(Xc[e]);
+        A32_GAP
+        Xp = WIW_MFMA32(fb[0], qf[0], A32_QKC(Xp));
+        A32_DSR(fa[2], vaddr[VK + 1], 0);
+#pragma unroll
+        for (int e = 4; e < 8; ++e) p[e] = A32_EXP(Xc[e]);
+        A32_GAP
+        Xp = WIW_MFMA32(fb[1], qf[1], A32_QKC(Xp));
+        A32_DSR(fa[3], vaddr[VK + 1], 4096);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) A32_PACK(pb[0].u[e], p[2 * e], p[2 * e + 1]);
+        A32_GAP
+        Xp = WIW_MFMA32(fb[2], qf[2], A32_QKC(Xp));
+#pragma unroll
+        for (int e = 8; e < 12; ++e) p[e] = A32_EXP(Xc[e]);
+        A32_GAP
+        Xp = WIW_MFMA32(fb[3], qf[3], A32_QKC(Xp));
+#pragma unroll
+        for (int e = 12; e < 16; ++e) p[e] = A32_EXP(Xc[e]);
+        if (PH == 1) advance(kaddr, nstage);
+        A32_GAP
+        if (PH == 1 && SYNC && !(WIW_A32_ABLATE & 2)) {   // tile j+1 visible to everybody; the stage of tile j-1 is free for tile j+2.  NO branch here
+            // (hipcc sinks the segment's VALU work below a conditional block): past the end of the sequence the DMA re-reads
+            // the last tile into the free stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(nstage == A2_NSTAGE - 1 ? 0 : nstage + 1, j + 3 < nkt);
+        }
+        A32_WAIT4(fa);
+        // ---- P.V segment
+        A32_PV(o[0], fa[0], pb[0].v);
+        A32_DSR(fb[0], kaddr[0], KOFF);
+        A32_DSR(fb[1], kaddr[1], KOFF);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) A32_PACK(pb[1].u[e], p[8 + 2 * e], p[8 + 2 * e + 1]);
+#if WIW_A32_LSUM_MFMA
+        A32_LSUM(0);
+#else
+        float t0 = p[0] + p[1], t1 = p[2] + p[3], t2 = p[4] + p[5], t3 = p[6] + p[7];
+#endif
+        A32_GAP
+        A32_PV(o[1], fa[1], pb[0].v);
+        A32_DSR(fb[2], kaddr[2], KOFF);
+#if !WIW_A32_LSUM_MFMA
+        t0 += t1; t2 += t3;
+        ls0 += t0; ls1 += t2;
+        float u0 = p[8] + p[9], u1 = p[10] + p[11], u2 = p[12] + p[13], u3 = p[14] + p[15];
+#endif
+        const float ma = A32_MAX3(Xp[0], Xp[1], Xp[2]), mb = A32_MAX3(Xp[3], Xp[4], Xp[5]), mc = A32_MAX3(Xp[6], Xp[7], Xp[8]);
+        A32_GAP
+        A32_PV(o[0], fa[2], pb[1].v);
+        A32_DSR(fb[3], kaddr[3], KOFF);
+        const float md = A32_MAX3(Xp[9], Xp[10], Xp[11]), me = A32_MAX3(Xp[12], Xp[13], Xp[14]);
+        const float mf = A32_MAX3(ma, mb, Xp[15]), mg = A32_MAX3(mc, md, me);
+#if WIW_A32_LSUM_MFMA
+        A32_LSUM(1);
+#else
+        u0 += u1; u2 += u3;
+#endif
+        A32_GAP
+        A32_PV(o[1], fa[3], pb[1].v);
+        const float mx = (WIW_A32_ABLATE & 1) ? 0.f : max2r(mf, mg);
+#if !WIW_A32_LSUM_MFMA
+        ls0 += u0; ls1 += u2;
+#endif
+        if (PH == 0) advance(vaddr, stage);
+        A32_GAP
+        A32_WAIT4(fb);
+        // Raise the reference where a score of Xp exceeds it by more than 2^THR (wave-uniform branch, rare after the first
+        // tiles).  Everything at the old scale is here: O and l (all P.V MFMAs and row sums so far) and Xp.
+        if (__builtin_amdgcn_ballot_w64(mx > A2_THR) != 0) {
+            const float mq = partner_max(mx);
+            const float m_new = bf2f(f2bf(mref + (mq > A2_THR ? mq : 0.f)));   // on the 16-bit grid; unchanged where mq <= THR
+            const float delta = m_new - mref;                                    // exact
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Xp[r] -= delta;
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+            }
+            mref = m_new;
+            initB[0] = hi == 0 ? (short)f2bf(-m_new) : (short)0;
+#if WIW_A32_LSUM_MFMA
+            lacc[0] *= alpha;                                                     // lanes 0..15: query n ...
+            lacc[1] *= __shfl(alpha, (lane & 15) + 16);                           // ... and query n + 16 (its factor lives in lane n + 16)
+#else
+            ls0 *= alpha;
+            ls1 *= alpha;
+#endif
+        }
+        if (PH == 1) stage = nstage;
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight; the first half tile decides the initial reference
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue(2, nkt > 3);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) A32_DSR(fa[ks], kaddr[ks], 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) A32_DSR(fb[ks], kaddr[ks], 4096);
+    A32_WAIT4(fa);
+    {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        S0 = WIW_MFMA32(fa[0], qf[0], z);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) S0 = WIW_MFMA32(fa[ks], qf[ks], S0);
+        const float m0 = bf2f(f2bf(partner_max(max16(S0))));   // on the 16-bit grid (see initB)
+        mref = m0;
+        initB[0] = hi == 0 ? (short)f2bf(-m0) : (short)0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S0[r] -= m0;
+        }
+    }
+    A32_WAIT4(fb);
+    int stage = 0;
+    half(Ph1{}, Ph0{}, S0, S1, 0, stage);
+    for (int j = 1; j < nkt; ++j) {
+        half(Ph0{}, Ph1{}, S1, S0, j, stage);
+        half(Ph1{}, Ph1{}, S0, S1, j, stage);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last two DMA issues (re-reads of the last tile) have landed
+    // ---- epilogue: the second half of the last tile (vaddr points at the last tile)
+    A32_DSR(fa[0], vaddr[2], 0);
+    A32_DSR(fa[1], vaddr[2], 4096);
+    A32_DSR(fa[2], vaddr[3], 0);
+    A32_DSR(fa[3], vaddr[3], 4096);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(S1[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pb[0].u[e] = pack2bf(p[2 * e], p[2 * e + 1]);
+        pb[1].u[e] = pack2bf(p[8 + 2 * e], p[8 + 2 * e + 1]);
+    }
+#if WIW_A32_LSUM_MFMA
+    A32_LSUM(0);
+    A32_LSUM(1);
+#else
+    ls0 += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[8] + p[9]) + (p[10] + p[11]));
+    ls1 += ((p[4] + p[5]) + (p[6] + p[7])) + ((p[12] + p[13]) + (p[14] + p[15]));
+#endif
+    A32_WAIT4(fa);
+    o[0] = WIW_MFMA32(fa[0], pb[0].v, o[0]);
+    o[1] = WIW_MFMA32(fa[1], pb[0].v, o[1]);
+    o[0] = WIW_MFMA32(fa[2], pb[1].v, o[0]);
+    o[1] = WIW_MFMA32(fa[3], pb[1].v, o[1]);
+#else
+    // ================= first correct form (sched_group_barrier pattern per segment): kept as the A/B reference =================
     // exp / row sum / pack of key step ks (registers 8 ks .. 8 ks + 7) of a score block
     auto softmax_step = [&](const f32x16& X, int ks) {
         float p[8];
@@ -215,7 +472,6 @@ __global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* 
         }
     };
 
-    const int nkt = S / 64;
     // ---- prologue: tiles 0 and 1 in flight, tile 0's first half decides the initial reference
     issue(0);
     issue(1);
@@ -231,11 +487,12 @@ __global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* 
         S0 = WIW_MFMA32(fa[0], qf[0], z);
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) S0 = WIW_MFMA32(fa[ks], qf[ks], S0);
-        const float m0 = partner_max(max16(S0));
+        const float m0 = bf2f(f2bf(partner_max(max16(S0))));   // on the 16-bit grid (see initB)
+        mref = m0;
+        initB[0] = hi == 0 ? (short)f2bf(-m0) : (short)0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             S0[r] -= m0;
-            negm[r] = -m0;
         }
     }
     // segment C of tile 0
@@ -312,9 +569,17 @@ __global__ __launch_bounds__(256, 3) void attn_spatial32_kernel(const uint16_t* 
     pv(fa, 0);
     pv(fa, 1);
 
+#endif
+
     // ---- normalise and store.  Lane (q, hi) holds O[q][32 db + 8 i + 4 hi + (0..3)] in registers 4 i .. 4 i + 3 of o[db]; a
     // v_permlane32_swap per packed word gives the lower lane d = 16 j .. + 7 and the upper lane d = 16 j + 8 .. + 15: 16-byte stores
+#if WIW_A32_LSUM_MFMA && WIW_A32_FORM == 2
+    (void)ls0; (void)ls1;
+    const float l_lo = __shfl(lacc[0], li & 15), l_hi = __shfl(lacc[1], li & 15);   // query li: lane li & 15, register li >> 4
+    const float l = li < 16 ? l_lo : l_hi;
+#else
     const float l = xor32_sum(ls0 + ls1);
+#endif
     const float inv = 1.0f / l;
     uint16_t* dst = O + (row0 + qrow) * ldo + h * 64 + hi * 8;
 #pragma unroll
