@@ -73,6 +73,8 @@ def test_argument_validation_without_gpu(lib_path):
     assert b"T <= 16" in lib.wiw_last_error()
     assert lib.wiw_attn_spatial_bf16(None, 1, 128, 64, 1, 8, 1, 64, 1, 4, 1, 0.125, 1) == -1
     assert b"multiple of 8" in lib.wiw_last_error()
+    assert lib.wiw_attn_spatial_ps_bf16(None, 1, 128, 64, 1, 8, 1, 60, 1, 256, 1, 1) == -1
+    assert b"misaligned" in lib.wiw_last_error()
     # fused FeedForward: built for the 320 / 1280 level only; misaligned pointers are refused
     assert lib.wiw_ffn_geglu_bf16(None, 16, 640, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 640, 128,
                                   640, 2560, 0, 1e-5) == -1

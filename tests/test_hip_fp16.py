@@ -162,6 +162,25 @@ def test_attn_spatial(hip, frames, S, heads):
     check(o, ref, max_tol=3e-3, rms_tol=1e-3, what=f"attn_spatial S={S} h={heads}")
 
 
+@pytest.mark.parametrize("frames,S,heads", [(2, 256, 5), (1, 1024, 1), (1, 200, 2)])
+def test_attn_spatial_prescaled(hip, frames, S, heads):
+    """The fp16 build of the 32x32x16 kernel (v_mfma_f32_32x32x16_f16) and of its fallback; one late key forces the raise."""
+    C = heads * 64
+    qkv = rnd(frames * S, 3 * C, seed=21)
+    qkv[S - 9, C:2 * C] *= 5.0
+    ps = math.log2(math.e) / 8.0
+    qs, k, v = h16(qkv[:, :C] * ps), h16(qkv[:, C:2 * C]), h16(qkv[:, 2 * C:])
+    o = torch.empty(frames * S, C, dtype=H16, device=DEV)
+    hip.attn_spatial_ps(dev16(torch.cat([qs, k], dim=1)), 2 * C, C, dev16(v.t().contiguous()), frames * S, o, C, frames, S, heads)
+
+    def hd(t):
+        return t.reshape(frames, S, heads, 64).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(hd(qs / ps), hd(k), hd(v)).transpose(1, 2).reshape(frames * S, C)
+    assert torch.isfinite(o.float()).all()
+    check(o, ref, max_tol=3e-3, rms_tol=1e-3, what=f"attn_spatial_ps S={S} h={heads}")
+
+
 @pytest.mark.parametrize("B,T,S,heads", [(1, 14, 80, 5), (2, 3, 8, 2), (1, 14, 16, 20)])
 def test_temporal_attn_block(hip, B, T, S, heads):
     from wiw_amd.unet import pack_temporal_qkv

@@ -212,6 +212,60 @@ def test_attn_spatial(hip, frames, S, heads):
     check(o.reshape(frames, S, C), sdpa(q, k, v, heads), max_tol=2e-2, rms_tol=8e-3, what=f"attn_spatial S={S} h={heads}")
 
 
+PRESCALE = math.log2(math.e) / 8.0   # what unet.py folds into the to_q rows (ATTN_PRESCALE)
+
+
+@pytest.mark.parametrize("frames,S,heads", [(2, 256, 1), (1, 1024, 3), (3, 384, 2), (2, 144, 2), (1, 576, 5), (1, 8, 2), (2, 200, 1)])
+def test_attn_spatial_prescaled(hip, frames, S, heads):
+    """wiw_attn_spatial_ps_bf16: the 32x32x16 kernel (S % 128 == 0, S >= 256) and its fallback, against fp32 softmax attention
+    on the SAME rounded operands (the pre-scaled Q is what the kernel is handed; the reference divides the factor out)."""
+    C = heads * 64
+    q, k, v = (rnd(frames, S, C, seed=s, scale=sc) for s, sc in ((1, 1.5), (2, 1.5), (3, 1.0)))
+    qs, k, v = bf(q * PRESCALE), bf(k), bf(v)
+    qk = dev_bf(torch.cat([qs, k], -1).reshape(frames * S, 2 * C))
+    vt = dev_bf(v.reshape(frames * S, C).t())
+    o = torch.empty(frames * S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial_ps(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads)
+    check(o.reshape(frames, S, C), sdpa(qs / PRESCALE, k, v, heads), max_tol=2e-2, rms_tol=8e-3, what=f"attn_spatial_ps S={S} h={heads}")
+
+
+@pytest.mark.parametrize("S", [256, 1024])
+def test_attn_spatial_prescaled_raises_the_reference(hip, S):
+    """Keys with huge scores LATE in the sequence (and one in the second tile) force the 32x32x16 kernel's rare branch: the
+    reference is raised on the integer grid, O / l / the pending P operands / the block in flight are rescaled (T13)."""
+    frames, heads, C = 2, 1, 64
+    q, k, v = rnd(frames, S, C, seed=1), rnd(frames, S, C, seed=2), rnd(frames, S, C, seed=3)
+    k[0, S - 56] = q[0, 17] * 6.0
+    k[0, 70] = q[0, 17] * 3.0
+    k[1, S // 2 + 5] = q[1, 100] * 9.0
+    k[1, S // 2 + 37] = q[1, 101] * 12.0
+    qs, k, v = bf(q * PRESCALE), bf(k), bf(v)
+    qk = dev_bf(torch.cat([qs, k], -1).reshape(frames * S, 2 * C))
+    vt = dev_bf(v.reshape(frames * S, C).t())
+    o = torch.empty(frames * S, C, dtype=torch.bfloat16, device=DEV)
+    hip.attn_spatial_ps(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads)
+    assert torch.isfinite(o.float()).all()
+    check(o.reshape(frames, S, C), sdpa(qs / PRESCALE, k, v, heads), max_tol=2e-2, rms_tol=8e-3, what="attn_spatial_ps rescale")
+
+
+def test_attn_spatial_prescaled_long_sequence_many_blocks(hip):
+    """A level-1-sized problem on the 32x32x16 kernel: 36 KV tiles per block, 1152 blocks over the XCD remap; and bit-exact
+    repeatability (no atomics, fixed order)."""
+    frames, S, heads = 8, 2304, 8
+    C = heads * 64
+    qkv = rnd(frames * S, 3 * C, seed=21)
+    qs, k, v = bf(qkv[:, :C] * PRESCALE), bf(qkv[:, C:2 * C]), bf(qkv[:, 2 * C:])
+    qk = dev_bf(torch.cat([qs, k], dim=1))
+    vt = dev_bf(v.t().contiguous())
+    o = torch.empty(frames * S, C, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.empty_like(o)
+    hip.attn_spatial_ps(qk, 2 * C, C, vt, frames * S, o, C, frames, S, heads)
+    hip.attn_spatial_ps(qk, 2 * C, C, vt, frames * S, o2, C, frames, S, heads)
+    ref = sdpa((qs / PRESCALE).reshape(frames, S, C), k.reshape(frames, S, C), v.reshape(frames, S, C), heads).reshape(frames * S, C)
+    check(o, ref, what="attn_spatial_ps 8 x 2304 x 8 heads")
+    assert torch.equal(o, o2)
+
+
 def test_attn_spatial_online_softmax_rescale(hip):
     """One key with a huge score in a LATE tile forces the running-max rescale branch (every tile)."""
     frames, S, heads, C = 1, 256, 1, 64

@@ -31,20 +31,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define WIW_ATTN_ABLATE 0   // timing experiments only (results wrong): 1 no max / exp2 (P = bf16(S)), 2 no K/V DMA + no tile
 #endif                      // barrier (stale stage 0), 4 no P.V MFMAs, 8 no Q.K MFMAs
 
-// v_max_f32 / v_max3_f32 without the canonicalising self-max hipcc puts in front of fmaxf (IEEE NaN quieting): the softmax
-// loop is VALU-ISSUE bound (tools/ubench/mfma_valu_overlap.hip: next to a streaming MFMA partner a wave gets ONE VALU issue
-// per MFMA, the rest costs ~5.4 cycles each), so every instruction of it counts.  A NaN score still ends in a NaN row
-// (its exp2 is NaN whatever the reference maximum is).
-WIW_DEV float max_raw(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-WIW_DEV float max3_raw(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// v_max_f32 / v_max3_f32 without the canonicalising self-max hipcc puts in front of fmaxf (IEEE NaN quieting): the file is built
+// with -fno-honor-nans, under which the BUILTIN gives the bare instruction (the softmax loop is VALU-issue bound, every
+// instruction of it counts; a NaN score still ends in a NaN row, its exp2 is NaN whatever the reference maximum is).
+// Round 5: these were asm statements until the 32x32x16 kernel (attention32.hip) showed what that risks — they read MFMA
+// results, and hipcc pads the MFMA -> VALU read hazard only for instructions it models.
+WIW_DEV float max_raw(float a, float b) { return __builtin_fmaxf(a, b); }
+WIW_DEV float max3_raw(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 WIW_DEV float xor16_max_raw(float x) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return max_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));

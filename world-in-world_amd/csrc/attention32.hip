@@ -48,7 +48,7 @@ WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((
 #endif
 
 #ifndef WIW_A32_FORM
-#define WIW_A32_FORM 2    // 2: hand-placed gaps (every MFMA gap its own scheduling region); 1: the first correct form
+#define WIW_A32_FORM 3    // 3: three-deep pipeline, Q.K and P.V MFMAs alternate; 2: hand-placed gaps, one segment per operand; 1: the first correct form
 #endif
 #ifndef WIW_A32_LSUM_MFMA
 #define WIW_A32_LSUM_MFMA 1   // form 2: row sums by a 16x16x32 MFMA on the P registers (1) or by v_add_f32 (0)
@@ -57,7 +57,7 @@ WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((
 #define WIW_A32_ABLATE 0   // timing experiments only (results wrong): 1 no softmax VALU (exp / pack / max / decision), 2 no K/V
 #endif                     // DMA + no tile barrier, 4 no LDS reads, 8 Q.K MFMAs independent (C = 0 each), 16 no P.V MFMAs
 #ifndef WIW_A32_WAVES
-#define WIW_A32_WAVES 3   // waves per SIMD the register budget is cut for (3: 168 VGPRs, 2: 256)
+#define WIW_A32_WAVES 3   // waves per SIMD the register budget is cut for (3: 168 VGPRs — form 3 fits without a spill; 2: 256)
 #endif
 #ifndef WIW_A32_SCHED
 #define WIW_A32_SCHED 1   // 1: sched_group_barrier interleave inside the segments; 0: hipcc's own order (A/B)
@@ -69,19 +69,13 @@ WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((
 #define WIW_A32_VALU_B 8   // ... in segments B / D
 #endif
 
-WIW_DEV float max3r(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-WIW_DEV float max2r(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// The LDS reads of a segment feed the NEXT segment's MFMAs; LLVM's IR-level sinking would move them next to their users
-// (sched_barrier only fences the machine scheduler).  An empty asm that reads the fragments keeps them in their segment.
-WIW_DEV void pin4(const bf16x8 (&f)[4]) { asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3])); }
+// v_max3_f32 / v_max_f32 through the BUILTIN (the file is built with -fno-honor-nans, so no canonicalising self-max is added).
+// NOT through an asm statement: these read MFMA results, and hipcc pads the MFMA -> VALU read hazard (up to 12 wait states
+// behind an 8-pass MFMA) only for instructions it models — an asm v_max3 issued too early reads a partly written
+// accumulator.  Round 5 found exactly that: the maximum only steers the raise decision, so results stayed inside the
+// tolerance but differed by an ulp from launch to launch (tools/attn32_probe.py REPEATS).
+WIW_DEV float max3r(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+WIW_DEV float max2r(float a, float b) { return __builtin_fmaxf(a, b); }
 WIW_DEV float max16(const f32x16& x) {   // 8 instructions, depth 3
     const float a = max3r(x[0], x[1], x[2]), b = max3r(x[3], x[4], x[5]), c = max3r(x[6], x[7], x[8]);
     const float d = max3r(x[9], x[10], x[11]), e = max3r(x[12], x[13], x[14]);
@@ -92,7 +86,10 @@ WIW_DEV float partner_max(float x) {   // max over the two lanes (hi = 0, 1) of 
     return max2r(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-constexpr int A2_STAGE = 16384, A2_NSTAGE = 3;
+#ifndef WIW_A32_DBG
+#define WIW_A32_DBG 0   // race hunting: 1 barrier at the top of every tile, 2 vmcnt(0) right after each DMA issue, 4 four ring stages
+#endif
+constexpr int A2_STAGE = 16384, A2_NSTAGE = (WIW_A32_DBG & 4) ? 4 : 3;
 constexpr float A2_THR = 8.0f;
 
 // mask values of __builtin_amdgcn_sched_group_barrier (LLVM SchedGroupMask)
@@ -116,7 +113,7 @@ struct Ph1 { static constexpr int value = 1; };
 __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(const uint16_t* __restrict__ QK, int ldqk, int k_col_off,
                                                                 const uint16_t* __restrict__ Vt, int64_t ldvt,
                                                                 uint16_t* __restrict__ O, int ldo, int S, int heads, int q_tiles) {
-    __shared__ __attribute__((aligned(16))) char smem[A2_NSTAGE * A2_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[A2_NSTAGE * A2_STAGE + ((WIW_A32_DBG & 16) ? 16384 : 0) + ((WIW_A32_DBG & 32) ? 8192 : 0)];   // DBG 16: pad to 64 KB (2 blocks per CU); 32: to 56 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
@@ -157,6 +154,7 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
         glds16(vp + v8, sK + 8192 + 1024);
         kp += adv ? kstep : 0;
         vp += adv ? 128 : 0;
+        if (WIW_A32_DBG & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     // ---- LDS read addresses of this lane: A-operand fragment (row li of a 32-row block, 16-byte chunk 2 ks + hi)
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
         for (int i = 0; i < 4; ++i) a[i] += d;
     };
 
-#if WIW_A32_FORM == 2
+#if WIW_A32_FORM >= 2
     f32x16 S0, S1, o[2];
 #else
     f32x16 S0, S1, negm, o[2];
@@ -197,7 +195,207 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
     bf16x8 fa[4], fb[4];
     const int nkt = S / 64;
 
-#if WIW_A32_FORM == 2
+#if WIW_A32_FORM == 3
+    // ================= three-deep pipeline: no two consecutive MFMAs on the same accumulator =================
+    // Measured on form 2 (profiles/r11f_attn32_ablation.txt): the five DEPENDENT 32x32x16 MFMAs of a Q.K segment cost 23 % of
+    // the kernel (a dependent MFMA issues ~56 cycles after its predecessor, an independent one after 32) and hide VALU work
+    // that needs no hiding.  Here half k issues   I  P0 Q0 P1 Q1 P2 Q2 P3 Q3   — Q.K of block X_k (I = the -m initialisation)
+    // alternating with P.V of block X_(k-2), accumulators Xq, o[0], Xq, o[1], ... — while the VALU exponentiates X_(k-1):
+    // three blocks in flight (X_k produced, X_(k-1) -> P, P of X_(k-2) consumed).  <= 4 VALU issues per gap.
+    //   * a K / V^T fragment register set is refilled right after the MFMA that read it, for the half after this one: every
+    //     LDS read has 7+ MFMA gaps to land (counted lgkmcnt waits, never 0 in the steady state);
+    //   * the raise decision for X_(k-1) sits after gap 2 (its maximum needs Q3 of the previous half).  At that point P.V of
+    //     X_(k-2) is one MFMA in: the rare branch therefore also rescales the not yet consumed P operands — exactly, because
+    //     the reference lives on the INTEGER grid (and on the 16-bit grid of the operand type, see initB): a raise is a power
+    //     of two — and takes the raise off X_k, whose accumulation has started from the old -m (cdna guide T13 (a));
+    //   * one barrier per tile, after gap 2 of the second half: tile j+1 becomes visible (its K is first read in gap 3), the
+    //     stage of tile j-1 (last read: V^T fragments refilled during the first half) is handed to DMA(j+2).
+#define A32_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+// A wait statement names ONLY registers whose reads it covers: "+v" on a register with a read still in flight would license
+// hipcc to copy it (a v_mov of stale data; cdna guide 5.7: "forms (ii)/(iii) pin order, not register allocation").
+#define A32_WAITF(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
+#define A32_WAIT3(n, f) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]))
+#define A32_WAIT1(n, r) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r))
+#define A32_GAP                                                 \
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);        \
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, 16, 0);       \
+    __builtin_amdgcn_sched_barrier(0);
+    float p[8];
+    f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};   // row sums on the matrix pipe: see form 2 below
+    bf16x8 onesA, initA, initB;
+    {
+        const bool on = lane == 0 || lane == 32 || lane == 17 || lane == 49;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            onesA[e] = on ? (short)WIW_ONE16 : (short)0;
+            initA[e] = 0;
+            initB[e] = 0;
+        }
+        initA[0] = hi == 0 ? (short)WIW_ONE16 : (short)0;
+    }
+    float mref;   // the reference of this lane's query: an integer representable in the 16-bit operand type
+    auto grid = [](float x) { return bf2f(f2bf(__builtin_rintf(x))); };
+    union PB { uint32_t u[4]; bf16x8 v; };
+    PB pbA[2], pbB[2];   // P^T B operands (two key steps) of the even / odd blocks
+    // vaddr starts one stage BEHIND tile 0: the second half of a tile moves it to that tile's stage before its V^T refills
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vaddr[i] += (A2_NSTAGE - 1) * A2_STAGE;
+
+    auto half3 = [&](auto ph_tag, auto sync_tag, auto qk_tag, auto pv_tag, f32x16& Xq, f32x16& Xe, PB(&pbN)[2], PB(&pbO)[2], int j,
+                     int& stage) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool SYNC = decltype(sync_tag)::value != 0, DO_QK = decltype(qk_tag)::value != 0, DO_PV = decltype(pv_tag)::value != 0;
+        constexpr bool FULL = DO_QK && DO_PV;
+        constexpr int VK = PH == 0 ? 2 : 0;        // V^T refill: V(j-1, h1) during the first half, V(j, h0) during the second
+        constexpr int KOFF = PH == 0 ? 4096 : 0;   // K refill: K(j, h1) / K(j+1, h0)
+        const int nstage = stage == A2_NSTAGE - 1 ? 0 : stage + 1;
+        f32x16 zero;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        // ---- gap 0: I
+        if (FULL) {   // every fragment read but the two youngest (fa[3], fb[3] of the previous half) has landed
+            A32_WAIT3(2, fa);
+            A32_WAIT3(2, fb);
+        } else {
+            A32_WAITF(0, fa);
+            A32_WAITF(0, fb);
+        }
+        if (DO_QK) Xq = WIW_MFMA32(initA, initB, zero);
+        if (DO_PV) lacc = WIW_MFMA(onesA, pbO[1].v, lacc);
+        if (PH == 1) advance(vaddr, stage);
+        A32_GAP
+        // ---- gap 1: P0
+        if (DO_PV) o[0] = WIW_MFMA32(fa[0], pbO[0].v, o[0]);
+        A32_DSR(fa[0], vaddr[VK], 0);
+        const float ma = max3r(Xe[0], Xe[1], Xe[2]), mb = max3r(Xe[3], Xe[4], Xe[5]), mc = max3r(Xe[6], Xe[7], Xe[8]);
+        const float md = max3r(Xe[9], Xe[10], Xe[11]);
+        A32_GAP
+        // ---- gap 2: Q0
+        if (DO_QK) Xq = WIW_MFMA32(fb[0], qf[0], Xq);
+        const float me = max3r(Xe[12], Xe[13], Xe[14]);
+        const float mx = max2r(max3r(ma, mb, Xe[15]), max3r(mc, md, me));
+        A32_GAP
+        if (__builtin_amdgcn_ballot_w64(mx > A2_THR) != 0) {   // wave-uniform, rare after the first tiles
+            const float mq = partner_max(mx);
+            const float m_new = grid(mref + (mq > A2_THR ? mq : 0.f));   // unchanged where mq <= THR
+            const float delta = m_new - mref;                              // an integer: alpha is a power of two
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Xe[r] -= delta;
+                if (DO_QK) Xq[r] -= delta;
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+            }
+            if (DO_PV) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const wiw_f32x2 v = unpack2(pbO[ks].u[e]);
+                        pbO[ks].u[e] = pack2bf(v.x * alpha, v.y * alpha);
+                    }
+            }
+            lacc[0] *= alpha;                               // lanes 0..15: query n ...
+            lacc[1] *= __shfl(alpha, (lane & 15) + 16);     // ... and query n + 16 (its factor lives in lane n + 16)
+            mref = m_new;
+            initB[0] = hi == 0 ? (short)f2bf(-m_new) : (short)0;
+        }
+        if (PH == 1 && SYNC) {   // NO branch here (hipcc sinks VALU work below a conditional block): past the end of the
+            // sequence the DMA re-reads the last tile into the free stage
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(1)" ::: "memory");   // my DMA(j+1) pieces; my reads of tile j-1's stage
+            __syncthreads();
+            issue(nstage == A2_NSTAGE - 1 ? 0 : nstage + 1, j + 3 < nkt);
+        }
+        if (PH == 1) advance(kaddr, nstage);
+        // ---- gap 3: P1
+        if (DO_PV) o[1] = WIW_MFMA32(fa[1], pbO[0].v, o[1]);
+        A32_DSR(fa[1], vaddr[VK], 4096);
+        if (DO_QK) A32_DSR(fb[0], kaddr[0], KOFF);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(Xe[e]);
+        A32_GAP
+        // ---- gap 4: Q1
+        if (DO_QK) {
+            Xq = WIW_MFMA32(fb[1], qf[1], Xq);
+            A32_DSR(fb[1], kaddr[1], KOFF);
+        }
+#pragma unroll
+        for (int e = 4; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(Xe[e]);
+        A32_GAP
+        // ---- gap 5: P2
+        if (DO_PV) o[0] = WIW_MFMA32(fa[2], pbO[1].v, o[0]);
+        A32_DSR(fa[2], vaddr[VK + 1], 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pbN[0].u[e] = pack2bf(p[2 * e], p[2 * e + 1]);
+        A32_GAP
+        // ---- gap 6: Q2
+        if (DO_QK) {
+            Xq = WIW_MFMA32(fb[2], qf[2], Xq);
+            A32_DSR(fb[2], kaddr[2], KOFF);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(Xe[8 + e]);
+        A32_GAP
+        // ---- gap 7: P3 (fa[3] was refilled in gap 7 of the previous half: 7 younger reads may be in flight)
+        if (FULL) A32_WAIT1(7, fa[3]); else A32_WAITF(0, fa);
+        if (DO_PV) o[1] = WIW_MFMA32(fa[3], pbO[1].v, o[1]);
+        A32_DSR(fa[3], vaddr[VK + 1], 4096);
+#pragma unroll
+        for (int e = 4; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(Xe[8 + e]);
+        A32_GAP
+        // ---- gap 8: Q3
+        if (DO_QK) {
+            if (FULL) A32_WAIT1(7, fb[3]); else A32_WAITF(0, fb);
+            Xq = WIW_MFMA32(fb[3], qf[3], Xq);
+            A32_DSR(fb[3], kaddr[3], KOFF);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pbN[1].u[e] = pack2bf(p[2 * e], p[2 * e + 1]);
+        lacc = WIW_MFMA(onesA, pbN[0].v, lacc);
+        A32_GAP
+        if (PH == 1) stage = nstage;
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight; block X_0 (C = 0) decides the initial reference
+    issue(0);
+    issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue(2, nkt > 3);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) A32_DSR(fa[ks], kaddr[ks], 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) A32_DSR(fb[ks], kaddr[ks], 4096);
+    A32_WAITF(4, fa);
+    {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        S0 = WIW_MFMA32(fa[0], qf[0], z);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) S0 = WIW_MFMA32(fa[ks], qf[ks], S0);
+        const float m0 = grid(partner_max(max16(S0)));
+        mref = m0;
+        initB[0] = hi == 0 ? (short)f2bf(-m0) : (short)0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S0[r] -= m0;
+    }
+    int stage = 0;
+    half3(Ph1{}, Ph0{}, Ph1{}, Ph0{}, S1, S0, pbA, pbB, 0, stage);                  // k = 1: Q.K of X_1, exp of X_0
+    for (int j = 1; j < nkt; ++j) {
+        half3(Ph0{}, Ph1{}, Ph1{}, Ph1{}, S0, S1, pbB, pbA, j, stage);              // k = 2 j
+        half3(Ph1{}, Ph1{}, Ph1{}, Ph1{}, S1, S0, pbA, pbB, j, stage);              // k = 2 j + 1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last two DMA issues (re-reads of the last tile) have landed
+    half3(Ph0{}, Ph0{}, Ph0{}, Ph1{}, S0, S1, pbB, pbA, nkt, stage);                // k = 2 nkt: exp of the last block, P.V of the one before
+    A32_WAITF(0, fa);
+    lacc = WIW_MFMA(onesA, pbB[1].v, lacc);
+    o[0] = WIW_MFMA32(fa[0], pbB[0].v, o[0]);
+    o[1] = WIW_MFMA32(fa[1], pbB[0].v, o[1]);
+    o[0] = WIW_MFMA32(fa[2], pbB[1].v, o[0]);
+    o[1] = WIW_MFMA32(fa[3], pbB[1].v, o[1]);
+#elif WIW_A32_FORM == 2
     // ================= hand-placed form: every MFMA gap is its own scheduling region =================
     // LDS reads are asm statements (they stay in their gap; hipcc's IR-level sinking otherwise moves a plain load next to
     // its user) with ONE s_waitcnt per fragment set at the end of the segment that issued it (cdna guide 5.7 form ii).
@@ -487,12 +685,11 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
         S0 = WIW_MFMA32(fa[0], qf[0], z);
 #pragma unroll
         for (int ks = 1; ks < 4; ++ks) S0 = WIW_MFMA32(fa[ks], qf[ks], S0);
-        const float m0 = bf2f(f2bf(partner_max(max16(S0))));   // on the 16-bit grid (see initB)
-        mref = m0;
-        initB[0] = hi == 0 ? (short)f2bf(-m0) : (short)0;
+        const float m0 = partner_max(max16(S0));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             S0[r] -= m0;
+            negm[r] = -m0;
         }
     }
     // segment C of tile 0
@@ -516,6 +713,7 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
 
     int stage = 1;   // stage of tile j
     for (int j = 1; j < nkt; ++j) {
+        if (WIW_A32_DBG & 1) __syncthreads();
         // ---- A: S0 = K(j,h0).Q - m  |  S1 key step 0  |  reads V(j-1,h1) (vaddr still points at tile j-1)
         qk(S0, fb);
         softmax_step(S1, 0);
@@ -546,6 +744,11 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
         if (j + 1 < nkt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (WIW_A32_DBG & 8) {   // poison the stage of tile j-1 (what DMA(j+2) overwrites with three stages): who still reads it?
+                const int pst = stage == 0 ? A2_NSTAGE - 1 : stage - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint4*)(smem + pst * A2_STAGE + (i * 256 + tid) * 16) = uint4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};
+            }
             if (j + 2 < nkt) issue(nstage == A2_NSTAGE - 1 ? 0 : nstage + 1);
         }
         // ---- D: O += V(j,h0).P0  |  S0 key step 1, max of S1  |  reads K(j+1,h0)
@@ -573,7 +776,7 @@ __global__ __launch_bounds__(256, WIW_A32_WAVES) void attn_spatial32_kernel(cons
 
     // ---- normalise and store.  Lane (q, hi) holds O[q][32 db + 8 i + 4 hi + (0..3)] in registers 4 i .. 4 i + 3 of o[db]; a
     // v_permlane32_swap per packed word gives the lower lane d = 16 j .. + 7 and the upper lane d = 16 j + 8 .. + 15: 16-byte stores
-#if WIW_A32_LSUM_MFMA && WIW_A32_FORM == 2
+#if (WIW_A32_LSUM_MFMA && WIW_A32_FORM == 2) || WIW_A32_FORM == 3
     (void)ls0; (void)ls1;
     const float l_lo = __shfl(lacc[0], li & 15), l_hi = __shfl(lacc[1], li & 15);   // query li: lane li & 15, register li >> 4
     const float l = li < 16 ? l_lo : l_hi;

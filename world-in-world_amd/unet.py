@@ -32,6 +32,7 @@ from .hip import (A_CONV3X3, A_CONV3X3_S2, A_CONV3X3_UP, A_CONV_T3, A_DENSE, EPI
 from .weights import validate_state_dict
 
 CIN_PAD = 64  # conv_in input channels padded 8 -> 64 so it runs on the MFMA conv kernel
+ATTN_PRESCALE = math.log2(math.e) / math.sqrt(64.0)   # folded into the spatial to_q rows: wiw_attn_spatial_ps_bf16 takes exp2(Q.K)
 
 
 def sinusoid(t: np.ndarray, dim: int) -> np.ndarray:
@@ -157,7 +158,6 @@ class UNetHIP:
         self.alpha: Dict[str, float] = {}
         self.no_splitk = bool(os.environ.get("WIW_NO_SPLITK"))     # A/B knob
         self.ln_fold = bool(os.environ.get("WIW_LN_FOLD")) if fold_layernorm is None else bool(fold_layernorm)
-        self.swapped_vt = bool(os.environ.get("WIW_SWAPPED_VT"))   # A/B knob: V^T by a swapped-operand GEMM (round 1)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         # fused FeedForward kernel of the 320-channel level (ffn.hip); A/B knobs: WIW_FF_UNFUSED=1 -> two GEMMs again,
         # WIW_FFN_NO_LN=1 -> fused FeedForward behind a separate LayerNorm pass
@@ -280,15 +280,16 @@ class UNetHIP:
             norm(p + ".norm"); lin(p + ".proj_in"); lin(p + ".proj_out")
             b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
             norm(b + ".norm1"); norm(b + ".norm3"); norm(t + ".norm_in"); norm(t + ".norm1"); norm(t + ".norm3")
-            w[b + ".attn1.to_qk.weight"] = torch.cat([self._t(sd, b + ".attn1.to_q.weight"),
-                                                      self._t(sd, b + ".attn1.to_k.weight")]).to(bf).contiguous()
-            wqkv = torch.cat([self._t(sd, b + ".attn1.to_q.weight"), self._t(sd, b + ".attn1.to_k.weight"),
+            # to_q rows PRE-SCALED by log2(e) / sqrt(64) in fp32, before their one rounding to 16 bits: the spatial attention
+            # kernel (csrc/attention32.hip) then has the base-2 exponent straight out of Q.K (attention_processor.py:2383
+            # applies 1/sqrt(d) inside F.scaled_dot_product_attention)
+            wqkv = torch.cat([self._t(sd, b + ".attn1.to_q.weight") * ATTN_PRESCALE, self._t(sd, b + ".attn1.to_k.weight"),
                               self._t(sd, b + ".attn1.to_v.weight")])
             w[b + ".attn1.to_qkv.weight"] = wqkv.to(bf).contiguous()
             if self._fold_ln(wqkv.shape[1]) and wqkv.shape[0] % 160 == 0:   # norm1 folded into the q|k|v projection
                 w[b + ".attn1.to_qkv.lnfold.weight"], w[b + ".attn1.to_qkv.lnfold.st"] = fold_layernorm(
                     wqkv, None, self._t(sd, b + ".norm1.weight"), self._t(sd, b + ".norm1.bias"), bf)
-            lin(b + ".attn1.to_v", bias=False); lin(b + ".attn1.to_out.0")
+            lin(b + ".attn1.to_out.0")
             w[t + ".attn1.to_qkv.weight"] = torch.cat([self._t(sd, t + ".attn1.to_q.weight"),
                                                        self._t(sd, t + ".attn1.to_k.weight"),
                                                        self._t(sd, t + ".attn1.to_v.weight")]).to(bf).contiguous()
@@ -552,31 +553,24 @@ class UNetHIP:
         legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
         # LayerNorm folded into its consumer GEMM where that GEMM runs on the 256x160 tile (`_fold_ln`): the projection
         # reads the RAW residual stream, the kernel derives mean / rstd of its rows from the operand fragments
-        fold_qkv = (b + ".attn1.to_qkv.lnfold.weight") in w and not self.swapped_vt
+        fold_qkv = (b + ".attn1.to_qkv.lnfold.weight") in w
         fold_ff = ((b + ".ff.net.0.proj.lnfold.weight") in w or (b + ".ff.ffn.w1ln") in w) and not legacy
         a = xn
         if self.res32:
-            assert not (fold_qkv or fold_ff or legacy or self.swapped_vt), "A/B knobs of the 16-bit stream"
+            assert not (fold_qkv or fold_ff or legacy), "A/B knobs of the 16-bit stream"
         if not fold_qkv:
             a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
         vt = self._empty(Cn, M)
         o = self._empty(M, Cn)
-        if self.swapped_vt:     # A/B knob (round-1 form): V^T = Wv . a^T as a second, operand-swapped GEMM
-            qk = self._empty(M, 2 * Cn)
-            hip.gemm(a, w[b + ".attn1.to_qk.weight"], qk, M=M, N=2 * Cn, K=Cn, C1=Cn)
-            hip.gemm(w[b + ".attn1.to_v.weight"], a, vt, M=Cn, N=M, K=Cn, C1=Cn)
-            hip.attn_spatial(qk, 2 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
+        # ONE q|k|v projection (the activation is read once), then a 64x64-tiled transpose of the V columns
+        qkv = self._empty(M, 3 * Cn)
+        if fold_qkv:
+            hip.gemm(h, w[b + ".attn1.to_qkv.lnfold.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn,
+                     lnfold=w[b + ".attn1.to_qkv.lnfold.st"], ln_eps=1e-5)
         else:
-            # ONE q|k|v projection (the activation is read once, N = 3C fills the tiles better than the 320-row swapped
-            # GEMM did: 200 us -> 45 + 65 us at the C = 320 level), then a 64x64-tiled transpose of the V columns
-            qkv = self._empty(M, 3 * Cn)
-            if fold_qkv:
-                hip.gemm(h, w[b + ".attn1.to_qkv.lnfold.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn,
-                         lnfold=w[b + ".attn1.to_qkv.lnfold.st"], ln_eps=1e-5)
-            else:
-                hip.gemm(a, w[b + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
-            hip.transpose(qkv, 3 * Cn, 2 * Cn, M, Cn, vt, M)
-            hip.attn_spatial(qkv, 3 * Cn, Cn, vt, M, o, Cn, frames, S, heads, scale)
+            hip.gemm(a, w[b + ".attn1.to_qkv.weight"], qkv, M=M, N=3 * Cn, K=Cn, C1=Cn)
+        hip.transpose(qkv, 3 * Cn, 2 * Cn, M, Cn, vt, M)
+        hip.attn_spatial_ps(qkv, 3 * Cn, Cn, vt, M, o, Cn, frames, S, heads)    # Q arrives pre-scaled (to_qkv weights)
         # The adds that follow a GEMM in the reference — the single-key cross-attention output (one vector per CFG item,
         # attention.py:545-551, 740-743) and the frame-position embedding (transformer_temporal.py:352-353) — ride in that
         # GEMM's epilogue as its per-row-group vector, so every LayerNorm below is a plain one-read / one-write pass.
