@@ -420,11 +420,11 @@ def northstar_inputs(g):
 
 
 # rms gates at the benchmarked size: (vs the reference's fp32 output, vs the reference in fp32 math on the same rounded weights).
-# fp16 + fp32 stream: north_star's 1e-3; the others 1.2 x the round-5 measurement (profiles/r12*_northstar_parity.log)
+# fp16 + fp32 stream: north_star's 1e-3; the others 1.2 x the round-5 measurement (profiles/r12h_gpu_partial_with_northstar_parity.log)
 NORTHSTAR_GATES = {
-    ("fp16", True): (1.0e-3, 1.0e-3),
-    ("fp16", False): (1.6e-3, 1.6e-3),
-    ("bf16", False): (1.3e-2, 1.3e-2),
+    ("fp16", True): (1.0e-3, 1.0e-3),      # north_star; measured 9.13e-4 / 9.15e-4 (16x32: 8.61e-4; weight-rounding floor 7.8e-4)
+    ("fp16", False): (1.55e-3, 1.57e-3),   # measured 1.283e-3 / 1.300e-3
+    ("bf16", False): (1.26e-2, 1.25e-2),   # measured 1.044e-2 / 1.041e-2 (weight-rounding floor 7.1e-3)
 }
 
 

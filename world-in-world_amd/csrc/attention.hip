@@ -24,9 +24,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef WIW_ATTN_MIN_WAVES
 #define WIW_ATTN_MIN_WAVES 2   // launch-bounds hint (waves per SIMD); the kernel needs 126 VGPRs = 4 waves per SIMD on its own
 #endif                         // (5: capped at 96 VGPRs, 27 spilled in the tile loop: 7.2 instead of 3.5 ms at S = 9216)
-#ifndef WIW_ATTN_PRIO
-#define WIW_ATTN_PRIO 0   // A/B: s_setprio 1 around the softmax (1) or around the two MFMA bursts (2) of a tile
-#endif
 #ifndef WIW_ATTN_ABLATE
 #define WIW_ATTN_ABLATE 0   // timing experiments only (results wrong): 1 no max / exp2 (P = bf16(S)), 2 no K/V DMA + no tile
 #endif                      // barrier (stale stage 0), 4 no P.V MFMAs, 8 no Q.K MFMAs
@@ -165,9 +162,6 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
         const char* sV = sK + 8192;
         // ---- S^T = K . Q^T  (4 key frags x 2 query frags x 2 d steps)
         f32x4 s[4][2];
-#if WIW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf) {
             // Which key sits in which row of a fragment is free.  Row i of fragment kf holds key
@@ -195,11 +189,6 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
         // ---- online softmax over keys (rows of S^T); lane owns query column fr of each query frag.
         // Scores stay unscaled: p = exp2(s*c - m) with c = log2(e)/sqrt(d) folded into one FMA; the running max
         // m is kept in the scaled domain.  v_exp_f32 is used raw (arguments <= 0; denormal results flush to 0).
-#if WIW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#elif WIW_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
-#endif
         if ((kt + 1) * KB > S) {   // wave-uniform: only the last, partial tile masks keys >= S
 #pragma unroll
             for (int f = 0; f < 2; ++f)
@@ -262,11 +251,6 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
 #endif
         // ---- O^T += V^T . P^T  (4 d frags x 2 query frags x 2 key steps); both operands in the natural K enumeration
         // thanks to the key permutation of the S^T fragments above
-#if WIW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#elif WIW_ATTN_PRIO == 1
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int drow = d * 16 + fr;
@@ -290,9 +274,6 @@ __global__ __launch_bounds__(NWV * 64, WIW_ATTN_MIN_WAVES) void attn_spatial_ker
                 }
             }
         }
-#if WIW_ATTN_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #if !(WIW_ATTN_ABLATE & 2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
