@@ -308,7 +308,9 @@ def main():
             **({"graph_error": den.graph_error} if den.graph_error else {}),
             "eager_ms_per_forward": round(1e3 * hl["eager"][0] / hl["eager"][1], 3) if hl["eager"][1] else None,
             "graph_replay_ms_per_forward": round(1e3 * hl["graph"][0] / hl["graph"][1], 3) if hl["graph"][1] else None,
-            "forwards": {"eager": hl["eager"][1], "graph": hl["graph"][1]}}
+            "forwards": {"eager": hl["eager"][1], "graph": hl["graph"][1]},
+            "note": "Euler steps that carry per-launch HIP events (every --event-every-th) run EAGERLY on the graph's static "
+                    "buffers inside the timed region; the others are graph replays"}
         fwd_per_step = args.num_inference_steps * (Btot / world if strong else B)   # candidate-forwards per GPU
         algo = ALGO_TFLOP_PER_FORWARD * (h * w) / (72 * 128) * fwd_per_step  # linear in pixels & candidates
         if not args.tiny:
@@ -483,6 +485,8 @@ def extras(args, cfg, unet, device, req, elapsed):
       batch8      one 25-step rollout of 8 candidates on this GPU = the per-GPU work of BASELINE configs 2 / 3
       fp16        one rollout with the fp16 library (the reference's served dtype, eval_inference.py:294)
       fp16_res32  the same with the residual stream in fp32: the configuration gated at <= 1e-3 vs the reference's fp32 output
+      end_to_end  ONE whole request through the worker: CLIP + VAE encode, loop, temporal VAE decode (own
+                  row with its TFLOP/s), PIL resize, uint8 response
       train       2 fine-tuning steps at 576x1024x14 (BASELINE config 4's per-GPU work)"""
     import copy
 
@@ -492,7 +496,7 @@ def extras(args, cfg, unet, device, req, elapsed):
 
     out = {}
     T, h, w = cfg.num_frames, args.height // 8, args.width // 8
-    budget = 240.0     # seconds of bench wall clock after which no further leg starts
+    budget = 270.0     # seconds of bench wall clock after which no further leg starts
 
     def timed_rollout(den, r, n):
         den.denoise(r["image_latents"], r["image_embeddings"], r["noise"], r["actions"], num_steps=2)    # warm (capture) pass
@@ -531,6 +535,12 @@ def extras(args, cfg, unet, device, req, elapsed):
                     torch.cuda.empty_cache()
             except Exception as e:   # noqa: BLE001
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
+    try:      # one whole request through the worker (CLIP + VAE encode, loop, VAE decode, PIL, uint8), with a vae_decode row
+        if left() > 40:
+            out["end_to_end"] = end_to_end(SVDDenoiser(unet, use_graph=True), unet, device, 1, args)
+            torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        out["end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         if left() > 45:
             a2 = copy.copy(args)
@@ -573,8 +583,27 @@ def end_to_end(den, unet, device, B, args):
     out = worker(req)
     dt = time.perf_counter() - t0
     assert out["pred_frames"].shape == (B, 14, 3, 480, 480)
+    # the phases either side of the loop, HIP events on the current stream (row f1 / f4 of SURVEY 8: temporal VAE decoder
+    # autoencoder_kl_temporal_decoder.py:87-161; CLIP + VAE encoder pipeline:183-252)
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return r, e0.elapsed_time(e1) * 1e-3
+    x = rs.standard_normal((B, 3, args.height, args.width)).astype(np.float32)
+    nz = rs.standard_normal(x.shape).astype(np.float32)
+    _, t_enc = timed(lambda: fe.encode(x, nz, 0.02))
+    lat = torch.randn(B, 14, 4, args.height // 8, args.width // 8, device=device)
+    _, t_dec = timed(lambda: fe.decode_uint8(lat))
+    dec_tf = 97.2e12 * B * (args.height * args.width) / (576.0 * 1024.0)    # 97.2 TFLOP per 576x1024x14 clip (temporal decoder MACs x 2)
     return {"seconds_per_request": round(dt, 3), "frames_per_s": round(B * 14 / dt, 3), "candidates": B,
-            "includes": "CLIP + VAE encode, denoise loop, VAE decode, PIL resize, uint8 response (random-init weights)"}
+            "includes": "CLIP + VAE encode, denoise loop, VAE decode, PIL resize, uint8 response (random-init weights)",
+            "vae_decode": {"seconds": round(t_dec, 4), "tflops": round(dec_tf / t_dec / 1e12, 1), "algorithmic_TFLOP": round(dec_tf / 1e12, 1),
+                           "frac_of_mfma_peak": round(dec_tf / t_dec / 2.5e15, 3), "what": "latents on the device -> uint8 frames on the device"},
+            "clip_vae_encode": {"seconds": round(t_enc, 4)}}
 
 
 def pmc_traffic(mode: int):

@@ -24,7 +24,7 @@ import wiw_amd  # noqa: F401  (registers the package under an importable name)
 from wiw_amd import frontend as FE
 from wiw_amd.config import UNetConfig
 from wiw_amd.pipeline import SVDDenoiser
-from wiw_amd.server.worker import SVDWorker, build_arg_parser, serve_tcp, worker_main
+from wiw_amd.server.worker import SVDWorker, build_arg_parser, serve_tcp, validate_args, worker_main
 from wiw_amd.unet import UNetHIP
 from wiw_amd.vae import HIPFrontend, VAEHIP
 from wiw_amd.weights import load_safetensors, random_state_dict
@@ -81,6 +81,8 @@ def arg_parser():
 
 def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) -> SVDWorker:
     """cfg / vae_cfg / clip: overrides for tests (reduced-width checkpoints); the served geometry by default."""
+    if cfg is None:
+        validate_args(args)
     cfg = cfg or UNetConfig(num_frames=args.num_frames, action_input_channel=args.action_input_channel, task_type=args.task_type)
     vae_cfg = vae_cfg or {}
     if args.random_weights:

@@ -374,3 +374,39 @@ def test_full_size_rollout_fp16_is_finite_and_batch_independent(hip):
     assert torch.isfinite(both).all()
     assert torch.equal(both[0], alone[0])
     assert torch.equal(den.denoise(il[:1], ie[:1], nz[:1], acts[:1], num_steps=2).float().cpu(), alone)
+
+
+def test_large_activations_do_not_saturate_fp16(hip):
+    """trained SVD weights have activation outliers a Gaussian-init network does not.  Inputs scaled so that
+    a 16-bit INTERMEDIATE would overflow (65 504) while inputs and outputs stay representable: the fp32 accumulators /
+    statistics / softmax of the kernels must carry them."""
+    # (a) GEMM: |A.W^T| reaches ~1e5 inside the accumulator, alpha brings the stored result back to O(1e3)
+    M, N, K = 512, 320, 2880
+    a, w = h16(rnd(M, K, seed=1, scale=300.0)), h16(rnd(N, K, seed=2))
+    acc = a @ w.t()
+    assert float(acc.abs().max()) > 65504.0
+    out = torch.empty(M, N, dtype=H16, device=DEV)
+    hip.gemm(dev16(a), dev16(w), out, M=M, N=N, K=K, C1=K, alpha=0.01)
+    check(out, 0.01 * acc, what="gemm, accumulator beyond the fp16 range")
+    # (b) GroupNorm of a unit sitting at 2e4 with std 400: sum of squares 1e15 and mean^2 / var = 2 500 — fp32 statistics
+    frames, S, C = 2, 2304, 320
+    x = h16(20000.0 + rnd(frames * S, C, seed=3, scale=400.0))
+    g, b = rnd(C, seed=4), rnd(C, seed=5)
+    y = hip.groupnorm(dev16(x), C, None, 0, frames * S, S, dev_f(g), dev_f(b), 1e-6, False)
+    ref = F.group_norm(x.reshape(frames, S, C).permute(0, 2, 1).double(), 32, g.double(), b.double(), 1e-6).permute(0, 2, 1).reshape(frames * S, C)
+    check(y, ref.float(), max_tol=2e-2, rms_tol=6e-3, what="groupnorm, |mean| / std = 50 at 2e4")
+    # (c) spatial attention with logits of several hundred (exp2 domain): one-hot rows, late keys beating early ones by 2^100+ —
+    # the raise path with fp16 P operands
+    frames, S, heads = 1, 512, 2
+    Cc = heads * 64
+    ps = math.log2(math.e) / 8.0
+    q, k, v = rnd(frames * S, Cc, seed=6, scale=6.0), rnd(frames * S, Cc, seed=7, scale=6.0), rnd(frames * S, Cc, seed=8)
+    qs, k, v = h16(q * ps), h16(k), h16(v)
+    o = torch.empty(frames * S, Cc, dtype=H16, device=DEV)
+    hip.attn_spatial_ps(dev16(torch.cat([qs, k], dim=1)), 2 * Cc, Cc, dev16(v.t().contiguous()), frames * S, o, Cc, frames, S, heads)
+
+    def hd(t):
+        return t.reshape(frames, S, heads, 64).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(hd(qs / ps).double(), hd(k).double(), hd(v).double()).transpose(1, 2).reshape(frames * S, Cc)
+    check(o, ref.float(), max_tol=6e-3, rms_tol=2e-3, what="attn_spatial_ps, logits of several hundred")

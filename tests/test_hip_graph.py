@@ -65,3 +65,39 @@ def test_eager_steps_interleave_with_replays():
     unet.hip.gemm_profile = None
     assert torch.equal(out, ref)
     assert den.host_launch["graph"][1] == 2 and den.host_launch["eager"][1] == 2 and len(prof) > 0
+
+
+def test_capture_is_refused_loudly_when_the_pool_would_not_fit(caplog):
+    """a capture pins ~6 GB per candidate at 576x1024; the denoiser estimates the pool against the free HBM, refuses
+    the SHAPE (not graphs for good) with a logged warning, runs it eagerly with the same bytes, and retries after an eviction."""
+    import logging
+
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 5), DEV)
+    den = SVDDenoiser(unet, use_graph=True)
+    il, ie, noise, acts = _inputs(cfg, 1, 4, 16, 32, 0)
+    ref = SVDDenoiser(unet, use_graph=False).denoise(il, ie, noise, acts, num_steps=2)
+    den.GRAPH_MEM_FRACTION = 0.0                      # nothing fits
+    with caplog.at_level(logging.WARNING, logger="wiw_amd.graph"):
+        out = den.denoise(il, ie, noise, acts, num_steps=2)
+    assert torch.equal(out, ref) and den.host_launch["eager"][1] == 2 and not den._graphs
+    assert "MemoryError" in den.graph_error and any("EAGERLY" in r.message for r in caplog.records)
+    st = den.graph_status()
+    assert st["enabled"] and st["captured"] == [] and len(st["refused"]) == 1
+    den.GRAPH_MEM_FRACTION = 0.8                      # a different shape still captures; the refused one stays refused ...
+    il2, ie2, noise2, acts2 = _inputs(cfg, 2, 4, 16, 32, 1)
+    den.denoise(il2, ie2, noise2, acts2, num_steps=2)
+    assert list(den._graphs) == [(2, 16, 32)] and (1, 16, 32) in den._graph_refused
+    den.MAX_GRAPHS = 1                                # ... until an eviction gives memory back
+    il3, ie3, noise3, acts3 = _inputs(cfg, 3, 4, 16, 32, 2)
+    den.denoise(il3, ie3, noise3, acts3, num_steps=2)
+    assert not den._graph_refused
+    out = den.denoise(il, ie, noise, acts, num_steps=2)
+    assert torch.equal(out, ref) and list(den._graphs) == [(1, 16, 32)]
+    assert unet.hip.gn_counters_clean()               # every GroupNorm statistics launch (eager, warm-up, captured) left zeros

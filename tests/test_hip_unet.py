@@ -165,3 +165,15 @@ def test_unet_with_folded_layernorms(tiny, golden):
     print(f"[parity] unet tiny, folded LayerNorms: max_rel={mx:.3e} rms_rel={rms:.3e} (reference bf16 run {rms_ref:.3e}); "
           f"vs the unfolded network rms={rel(out, base)[1]:.3e}")
     assert np.isfinite(out).all() and rms <= rms_ref and mx <= 1.25 * mx_ref
+
+
+def test_more_than_one_conditioning_embedding_is_refused(tiny):
+    """The cross-attention is the closed form for ONE key; (B, P > 1, D) embeddings of a --num_past_obs > 1 checkpoint must
+    raise, not be flattened into a mis-shaped vector (pipeline_stable_video_diffusion.py:501-504)."""
+    cfg, sd, unet = tiny(0)
+    ie = torch.zeros(1, 2, cfg.cross_attention_dim)
+    with pytest.raises(NotImplementedError, match="num_past_obs"):
+        unet.prepare_request(ie, np.zeros((1, cfg.num_frames, cfg.action_input_channel), np.float32))
+    sample = torch.zeros(2, cfg.num_frames, 8, 16, 32)
+    with pytest.raises(NotImplementedError, match="single-key"):
+        unet(sample, 1.0, torch.zeros(2, 2, cfg.cross_attention_dim), torch.zeros(2, 3), torch.zeros(1, cfg.num_frames, cfg.action_input_channel))

@@ -15,11 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def fake_denoise(il, ie, noise, actions, num_steps=2, **kw):
-    a = torch.as_tensor(np.asarray(actions), dtype=torch.float32)[:, :, None, None, None]
+    a = torch.as_tensor(np.asarray(actions), dtype=torch.float64)
+    if a.dim() == 3:                       # manipulation rows (B, T, 8): every value matters
+        a = (a * torch.arange(1, 9, dtype=torch.float64)).sum(-1)
+    a = a.to(torch.float32)[:, :, None, None, None]
     return il[:, None] * (1 + a) + 0.5 * noise + ie.mean((1, 2))[:, None, None, None, None] * num_steps
 
 
-def _run(rank, world, port, B, q):
+def _run(rank, world, port, B, q, manip=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,8 +30,11 @@ def _run(rank, world, port, B, q):
         req = [None] * 4
         if rank == 0:
             g = torch.Generator().manual_seed(0)
+            acts = np.arange(B * 3).reshape(B, 3) % 5
+            if manip:     # (B, T, 8) continuous rows keep their shape and their float values through the scatter
+                acts = np.random.RandomState(3).standard_normal((B, 3, 8))
             req = [torch.randn(B, 4, 4, 8, generator=g), torch.randn(B, 1, 16, generator=g),
-                   torch.randn(B, 3, 4, 4, 8, generator=g), np.arange(B * 3).reshape(B, 3) % 5]
+                   torch.randn(B, 3, 4, 4, 8, generator=g), acts]
         out = sharded_denoise(fake_denoise, torch.device("cpu"), *req, num_steps=3)
         if rank == 0:
             ref = fake_denoise(req[0], req[1], req[2], req[3], num_steps=3)
@@ -53,11 +59,11 @@ def test_shard_bounds():
     assert shard_bounds(1, 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
 
 
-def _spawn(B):
+def _spawn(B, manip=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, B, q, manip)) for r in range(2)]
     for p in procs:
         p.start()
     err = q.get(timeout=120)
@@ -71,6 +77,7 @@ def test_sharded_equals_single_rank_even_and_ragged():
     assert _spawn(4) == 0.0   # 2 + 2
     assert _spawn(3) == 0.0   # 2 + 1 (ragged)
     assert _spawn(1) == 0.0   # 1 + 0 (a rank with no candidate)
+    assert _spawn(3, manip=True) == 0.0   # manipulation: (B, T, 8) float actions (were cast to int64 (T,))
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -209,6 +209,38 @@ def test_cli_accepts_the_reference_launcher_arguments():
     assert args.num_frames == 14 and args.action_input_channel == 14
 
 
+def test_unsupported_configurations_are_refused_at_startup():
+    """--num_past_obs > 1 (Sk > 1 cross-attention is not built) and action-embedder widths the task cannot produce fail when
+    the worker is BUILT, not at the first client request."""
+    from wiw_amd.server.worker import validate_args
+
+    ap = build_arg_parser()
+    validate_args(ap.parse_args([]))                                                            # the served default
+    validate_args(ap.parse_args("--task_type manipulation --action_input_channel 10".split()))
+    validate_args(ap.parse_args("--task_type manipulation --action_input_channel 23".split()))
+    validate_args(ap.parse_args("--num_frames 8 --action_input_channel 8".split()))             # BASELINE config 0
+    for bad in ("--num_past_obs 2", "--task_type manipulation", "--task_type manipulation --action_input_channel 14",
+                "--action_input_channel 10", "--num_frames 8"):
+        with pytest.raises(SystemExit):
+            validate_args(ap.parse_args(bad.split()))
+
+
+def test_manipulation_requests_with_degenerate_quaternions_are_refused():
+    """The reference raises inside scipy on a zero-norm / NaN quaternion (utils/svd_utils.py:357-375); the closed-form rotation
+    here would decode NaN frames silently: `check_b_action` refuses before compute is committed."""
+    from wiw_amd.server.plumbing import check_b_action
+
+    a = np.zeros((2, 14, 8))
+    a[..., 6] = 1.0
+    check_b_action(a, 14, "manipulation")
+    bad = a.copy(); bad[1, 3, 3:7] = 0.0
+    with pytest.raises(AssertionError, match="zero-norm"):
+        check_b_action(bad, 14, "manipulation")
+    bad = a.copy(); bad[0, 0, 1] = np.nan
+    with pytest.raises(AssertionError, match="non-finite"):
+        check_b_action(bad, 14, "manipulation")
+
+
 def test_launcher_cli_takes_the_manager_command_line():
     """serve_worker.py is started by the reference manager as `<python> <script> <args...> <w_fd>`
     (worker_manager.py:324-334): the reference launcher's arguments plus the trailing result-pipe fd must parse,

@@ -44,7 +44,7 @@ def main():
         stats = torch.zeros(frames * 64, device=dev)
         ab = torch.randn(frames * 2 * C, device=dev)
         s = torch.cuda.current_stream().cuda_stream
-        cnt = hip._gn_cnt
+        cnt = hip._gn_cnt_pool[0]
         ref = x.float().view(frames, S, 32, C // 32).transpose(1, 2).reshape(frames, 32, -1)
         ref_m, ref_v = ref.mean(-1), ref.var(-1, unbiased=False)
         for clip, rpu, label in ((False, S, "gn_stats        "), (True, 14 * S, "gn_stats (T*S)  ")):

@@ -103,6 +103,9 @@ def save_checkpoint(output_dir: str, global_step: int, master: Optional[Dict[str
     of `train_unet.EMAShadow` (`--use_ema`).  Returns the directory."""
     from safetensors.torch import save_file
 
+    if ema is not None and unet_config is None:    # BEFORE anything is written: a partial checkpoint-N would be resumed from
+        raise ValueError("save_checkpoint: `ema` needs `unet_config` — unet_ema/config.json must be loadable as a model "
+                         "directory (EMAModel.from_pretrained reads the architecture from it)")
     path = os.path.join(output_dir, f"checkpoint-{global_step}")
     os.makedirs(os.path.join(path, "unet"), exist_ok=True)
     if rank == 0 and master is not None:
@@ -112,9 +115,6 @@ def save_checkpoint(output_dir: str, global_step: int, master: Optional[Dict[str
                 f.write(json.dumps(unet_config, indent=2, sort_keys=True) + "\n")
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump(dict(meta, global_step=int(global_step)), f, indent=1, sort_keys=True)
-    if ema is not None and unet_config is None:
-        raise ValueError("save_checkpoint: `ema` needs `unet_config` — unet_ema/config.json must be loadable as a model "
-                         "directory (EMAModel.from_pretrained reads the architecture from it)")
     if rank == 0 and ema is not None:
         # `ema_unet.save_pretrained(<dir>/unet_ema)` (train_svd.py:588-589): the averaged weights as a model directory whose
         # config.json carries the EMA state next to the architecture (training_utils.py:390-403 registers it into the config)

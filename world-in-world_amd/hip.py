@@ -227,7 +227,10 @@ class Hip:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
         self._splitk_ws = None
-        self._gn_cnt = torch.zeros(65536, dtype=torch.int32, device=self.device)    # see _gn_buffers
+        # int32 counters of the GroupNorm statistics launches, one row per STREAM that ever launched one (see _gn_buffers);
+        # all rows are allocated and zeroed here: handing one out is legal inside a hipGraph capture
+        self._gn_cnt_pool = torch.zeros(16, 65536, dtype=torch.int32, device=self.device)
+        self._gn_cnt = {}
         # ... and this one for the non-GEMM kernels: (start_event, end_event, family, algorithmic_flops, algorithmic_bytes)
         self.kernel_profile = None
 
@@ -404,9 +407,22 @@ class Hip:
         before the capture starts)."""
         units = rows // rows_per_unit
         n = int(self.lib.wiw_groupnorm_scratch_floats(rows, rows_per_unit, rpb))
-        assert int(self.lib.wiw_groupnorm_counters(rows, rows_per_unit, rpb)) <= self._gn_cnt.numel(), "groupnorm: more parts than counters"
+        # The last-block-done reduction (norm.hip) needs its counters at zero before a launch and leaves them at zero: two
+        # statistics launches must never overlap on ONE counter buffer.  Launches of one stream are ordered, so the buffer is
+        # keyed by stream (the VAE shares this Hip with the UNet; a capture's warm-up runs on a side stream) — ADVICE r4.
+        cnt = self._gn_cnt.get(self._stream())
+        if cnt is None:
+            if len(self._gn_cnt) >= self._gn_cnt_pool.shape[0]:
+                raise RuntimeError("groupnorm: more streams than counter rows (Hip._gn_cnt_pool)")
+            cnt = self._gn_cnt[self._stream()] = self._gn_cnt_pool[len(self._gn_cnt)]
+        assert int(self.lib.wiw_groupnorm_counters(rows, rows_per_unit, rpb)) <= cnt.numel(), "groupnorm: more parts than counters"
         buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
-        return buf[: units * 64], buf[units * 64:], self._gn_cnt
+        return buf[: units * 64], buf[units * 64:], cnt
+
+    def gn_counters_clean(self) -> bool:
+        """Debug check (tests): every statistics launch left its counters at zero."""
+        torch.cuda.synchronize(self.device)
+        return int(self._gn_cnt_pool.abs().max()) == 0
 
     def groupnorm(self, X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out=None, clip=False, raw16=None):
         """statistics (deterministic, no atomics) -> fused finalize + apply; returns the normalised (and SiLU'd) bf16

@@ -84,7 +84,8 @@ def sharded_denoise(denoise_fn: Callable[..., torch.Tensor], device: torch.devic
     meta = torch.zeros(8, dtype=torch.int64, device=device)
     if rank == 0:
         B, T, _, h, w = noise.shape
-        meta[:6] = torch.tensor([B, T, h, w, image_embeddings.shape[-1], image_embeddings.shape[-2]])
+        meta[:7] = torch.tensor([B, T, h, w, image_embeddings.shape[-1], image_embeddings.shape[-2],
+                                 1 if np.asarray(actions).ndim == 3 else 0])
     dist.broadcast(meta, src=0)
     B, T, h, w, D, L = (int(v) for v in meta[:6].tolist())
     bounds = shard_bounds(B, world)
@@ -94,8 +95,12 @@ def sharded_denoise(denoise_fn: Callable[..., torch.Tensor], device: torch.devic
     il = _scatter_slices(image_latents, (4, h, w), torch.float32, device, bounds, width)[:n]
     ie = _scatter_slices(image_embeddings, (L, D), torch.float32, device, bounds, width)[:n]
     nz = _scatter_slices(noise, (T, 4, h, w), torch.float32, device, bounds, width)[:n]
-    ac = _scatter_slices(None if actions is None else torch.as_tensor(np.asarray(actions), dtype=torch.int64), (T,),
-                         torch.int64, device, bounds, width)[:n]
+    # actions keep their own trailing shape and dtype: (B, T) int64 navigation ids, (B, T, 8) float manipulation rows — rank 0
+    # announces which (the rank of the array selects the encoding, eval_inference.py:324-331)
+    manip = bool(int(meta[6]))
+    a_shape, a_dtype = ((T, 8), torch.float64) if manip else ((T,), torch.int64)
+    ac = _scatter_slices(None if actions is None else torch.as_tensor(np.asarray(actions), dtype=a_dtype), a_shape,
+                         a_dtype, device, bounds, width)[:n]
     if n > 0:
         mine = denoise_fn(il, ie, nz, ac.cpu().numpy(), **kw).to(torch.float32).contiguous()
     else:

@@ -188,9 +188,58 @@ class SVDDenoiser:
         self.use_graph = bool(os.environ.get("WIW_GRAPH")) if use_graph is None else bool(use_graph)
         self._graphs = {}           # (B, h, w) -> GraphedForward; at most MAX_GRAPHS shapes stay captured (their pools hold a
         self.MAX_GRAPHS = 2         # forward's intermediates: ~6 GB per candidate at 576x1024)
-        self.graph_error = None     # why capture was given up (the loop then runs eagerly)
+        self.graph_error = None     # the LAST reason a shape was not captured (that shape then runs eagerly; others still capture)
+        self._graph_refused = {}    # (B, h, w) -> reason; forgotten when a captured shape is evicted (memory came back)
+        self.GRAPH_MEM_FRACTION = 0.8   # of the free HBM a capture's pool may take (estimate below)
         # host time spent ENQUEUEING UNet forwards (no synchronisation inside): [seconds, forwards] per mode
         self.host_launch = {"eager": [0.0, 0], "graph": [0.0, 0]}
+
+    # ---- hipGraph cache (capture is default-on in the server; a pool of ~6 GB per candidate must not be taken blindly)
+    def graph_pool_estimate(self, B: int, h: int, w: int) -> float:
+        """Bytes a captured forward pins for (B candidates, h x w latent): ~6.2 GB per candidate at 72x128 with 16-bit
+        activations (measured, serve_worker --help), x 1.6 with the fp32 residual stream; linear in B h w."""
+        per = 6.2e9 * (1.6 if getattr(self.unet, "res32", False) else 1.0)
+        return per * B * (h * w) / (72.0 * 128.0)
+
+    def graph_status(self) -> dict:
+        """For the server's status line / logs: what is captured, what was refused and why."""
+        return {"enabled": self.use_graph, "captured": [list(k) for k in self._graphs], "refused": {str(k): v for k, v in self._graph_refused.items()},
+                "last_error": self.graph_error, "host_launch": {k: list(v) for k, v in self.host_launch.items()}}
+
+    def _graph_for(self, B: int, h: int, w: int, cond):
+        import logging
+
+        key = (B, h, w)
+        gf = self._graphs.pop(key, None)
+        if gf is not None:
+            self._graphs[key] = gf     # re-insert: dict order = recency, eviction below is least-recently-used
+            return gf
+        if key in self._graph_refused:
+            return None
+        log = logging.getLogger("wiw_amd.graph")
+        prof = (self.hip.gemm_profile, self.hip.kernel_profile)      # (bench.py may have armed per-launch events for
+        self.hip.gemm_profile = self.hip.kernel_profile = None       # the first step: not inside a capture)
+        try:
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
+                self._graph_refused.clear()          # memory came back: refused shapes get another try
+                torch.cuda.empty_cache()
+            need = self.graph_pool_estimate(B, h, w)
+            free = float(torch.cuda.mem_get_info(self.device)[0]) if self.device.type == "cuda" else float("inf")
+            if need > self.GRAPH_MEM_FRACTION * free:
+                raise MemoryError(f"a captured forward for {B} candidate(s) at {h}x{w} would pin ~{need / 2**30:.1f} GiB, "
+                                  f"{free / 2**30:.1f} GiB are free")
+            gf = self._graphs[key] = GraphedForward(self.unet, cond, h, w)
+            log.info("captured the UNet forward for %d candidate(s) at %dx%d (~%.1f GiB pool)", B, h, w, need / 2**30)
+        except Exception as e:       # capture is an optimisation: the eager loop is the same computation — but say so, loudly
+            self.graph_error = f"{type(e).__name__}: {e}"
+            self._graph_refused[key] = self.graph_error
+            log.warning("hipGraph capture refused for %d candidate(s) at %dx%d, this shape runs EAGERLY (~12 ms more host work per "
+                        "forward): %s", B, h, w, self.graph_error)
+            gf = None
+        finally:
+            self.hip.gemm_profile, self.hip.kernel_profile = prof
+        return gf
 
     @torch.no_grad()
     def denoise(self, image_latents: torch.Tensor, image_embeddings: torch.Tensor, noise: torch.Tensor,
@@ -225,26 +274,10 @@ class SVDDenoiser:
         img = image_latents.to(self.device, torch.float32).contiguous()
         cond = self.unet.prepare_request(image_embeddings, act_ids, noise_aug_strength)
         hw = h * w
-        gf = None
-        if self.use_graph and self.graph_error is None:
-            gf = self._graphs.pop((B, h, w), None)
-            if gf is not None:
-                self._graphs[(B, h, w)] = gf     # re-insert: dict order = recency, eviction below is least-recently-used
-            if gf is None:
-                prof = (self.hip.gemm_profile, self.hip.kernel_profile)      # (bench.py may have armed per-launch events for
-                self.hip.gemm_profile = self.hip.kernel_profile = None       # the first step: not inside a capture)
-                try:
-                    while len(self._graphs) >= self.MAX_GRAPHS:
-                        self._graphs.pop(next(iter(self._graphs)))
-                    gf = self._graphs[(B, h, w)] = GraphedForward(self.unet, cond, h, w)
-                except Exception as e:       # capture is an optimisation: the eager loop below is the same computation
-                    self.graph_error = f"{type(e).__name__}: {e}"
-                    gf = None
-                finally:
-                    self.hip.gemm_profile, self.hip.kernel_profile = prof
-            if gf is not None:
-                gf.load(cond)
-                cond = gf.cond
+        gf = self._graph_for(B, h, w, cond) if self.use_graph else None
+        if gf is not None:
+            gf.load(cond)
+            cond = gf.cond
         x_in = gf.x_in if gf is not None else torch.empty((2 * B * T * hw, CIN_PAD), dtype=self.unet.dtype, device=self.device)
         for i in range(num_steps):
             s, sn = float(sig[i]), float(sig[i + 1])

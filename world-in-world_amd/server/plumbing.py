@@ -47,6 +47,11 @@ def check_b_action(b_action, num_frames: int, task_type: str = "navigation") -> 
     if task_type == "manipulation":
         assert b_action.ndim == 3 and b_action.shape[1:] == (num_frames, 8), \
             f"manipulation b_action must be (b, {num_frames}, 8), got {b_action.shape}"
+        # the reference raises inside scipy's Rotation.from_quat on these (utils/svd_utils.py:357-375); here the rotation matrix is
+        # closed-form and would carry NaNs into the action embedding: refuse before compute is committed
+        a = b_action.astype(np.float64)
+        assert np.isfinite(a).all(), "manipulation b_action holds non-finite values"
+        assert (np.linalg.norm(a[..., 3:7], axis=-1) > 0).all(), "manipulation b_action holds a zero-norm quaternion"
     else:
         assert b_action.ndim == 2 and b_action.shape[1] == num_frames, \
             f"navigation b_action must be (b, {num_frames}), got {b_action.shape}"

@@ -336,3 +336,21 @@ def build_arg_parser() -> argparse.ArgumentParser:
                     help="> 0: batch requests of different clients into one GPU call of up to this many candidates")
     ap.add_argument("--coalesce_wait_ms", type=float, default=20.0, help="how long the oldest pending request may wait for company")
     return ap
+
+
+def validate_args(args) -> None:
+    """Configurations this build does not serve are refused at START-UP, not at the first client request (on every rank of
+    a sharded server): --num_past_obs > 1 (Sk > 1 cross-attention is not built, unet._require_single_key); an action
+    embedder width the task cannot produce (navigation: one channel per frame, get_action_ids micro_cond; manipulation: 10 =
+    [norm_xyz | r6 | norm_grip] or num_frames + 9, its positional form — utils/svd_utils.py:418-457, 499-567)."""
+    if args.num_past_obs != 1:
+        raise SystemExit(f"--num_past_obs {args.num_past_obs}: this build serves checkpoints conditioned on ONE past observation "
+                         f"(single-key cross-attention in closed form); Sk > 1 is not built")
+    if args.task_type == "manipulation":
+        ok = (10, args.num_frames + 9)
+        if args.action_input_channel not in ok:
+            raise SystemExit(f"--task_type manipulation needs --action_input_channel {ok[0]} or {ok[1]} (num_frames + 9), "
+                             f"got {args.action_input_channel}")
+    elif args.action_input_channel != args.num_frames:
+        raise SystemExit(f"--task_type navigation embeds one action channel per frame: --action_input_channel must equal "
+                         f"--num_frames ({args.num_frames}), got {args.action_input_channel}")

@@ -133,6 +133,18 @@ class RequestCond:
     pos_emb_blend: Dict[str, torch.Tensor]  # -am/(1-am) * pos_emb (AlphaBlender correction, see _transformer)
 
 
+def _require_single_key(ehs: torch.Tensor) -> None:
+    """The cross-attention of this build is the CLOSED FORM for one key (softmax over a single key is 1: the output is
+    to_out(to_v(embedding)), attention.py:545-551, 740-743 with the served conditioning of one CLIP embedding per
+    candidate).  A checkpoint trained with --num_past_obs > 1 hands (B, P > 1, 1024) embeddings
+    (pipeline_stable_video_diffusion.py:501-504; train_svd.py:359, 889-894): that needs the general Sk > 1 attention, which is
+    not built — refuse instead of flattening P embeddings into one mis-shaped vector."""
+    if ehs.dim() != 3 or ehs.shape[1] != 1:
+        raise NotImplementedError(f"encoder_hidden_states {tuple(ehs.shape)}: this build serves ONE conditioning embedding per "
+                                  f"candidate (B, 1, D) — the single-key cross-attention in closed form; --num_past_obs > 1 "
+                                  f"checkpoints (Sk > 1) are not supported")
+
+
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
                  hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None,
@@ -202,7 +214,7 @@ class UNetHIP:
             w[p + ".weight"] = self._t(sd, p + ".weight").contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
 
-        def conv3(p, cin_pad=0):
+        def conv3(p, cin_pad=0, halo=True):
             x = self._t(sd, p + ".weight").permute(0, 2, 3, 1)  # OIHW -> OHWI
             if cin_pad and x.shape[-1] < cin_pad:
                 x = torch.cat([x, x.new_zeros(*x.shape[:-1], cin_pad - x.shape[-1])], dim=-1)
@@ -211,7 +223,7 @@ class UNetHIP:
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
             # a second copy in the K order of the halo-staged kernel (N % 320 == 0: every ResnetBlock2D convolution of the
             # served widths): `_conv3` picks it when the request's geometry fits (hip.conv_halo_ok), else the copy above
-            if self.halo and x.shape[0] % 320 == 0 and x.shape[1] % (9 * 64) == 0:
+            if halo and self.halo and x.shape[0] % 320 == 0 and x.shape[1] % (9 * 64) == 0:
                 w[p + ".weight_h"] = conv_k_halo32(x).to(bf).contiguous()
 
         def convt(p):
@@ -323,7 +335,7 @@ class UNetHIP:
                 if i < n - 1:
                     self.tr_names.append(f"down_blocks.{i}.attentions.{j}")
             if i < n - 1:
-                conv3(f"down_blocks.{i}.downsamplers.0.conv")
+                conv3(f"down_blocks.{i}.downsamplers.0.conv", halo=False)   # stride 2: never reaches `_conv3` (no second copy)
         self.res_names += ["mid_block.resnets.0", "mid_block.resnets.1"]
         self.tr_names.append("mid_block.attentions.0")
         for i in range(n):
@@ -446,6 +458,7 @@ class UNetHIP:
         Bc = 2 * B if cfg_batch else B
         T = cfg.num_frames
         bf = self.dtype
+        _require_single_key(image_embeddings)
         ie = image_embeddings.reshape(B, -1).to(self.device, torch.float32)
         ehs = torch.cat([torch.zeros_like(ie), ie]) if cfg_batch else ie
         ehs = ehs.to(bf).contiguous()
@@ -720,6 +733,7 @@ class UNetHIP:
         Bc, T, Cin, h, w_ = sample.shape
         B = added_action_ids.shape[0]
         assert Bc % B == 0 and T == self.cfg.num_frames
+        _require_single_key(encoder_hidden_states)
         ehs = encoder_hidden_states.reshape(Bc, -1).to(self.device, torch.float32)
         cond = self.prepare_request(ehs[Bc - B:].reshape(B, 1, -1), added_action_ids.cpu().numpy(),
                                     float(added_time_ids[0, -1]), cfg_batch=(Bc == 2 * B))
