@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 13  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 14  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -47,7 +47,8 @@ extern "C" {
                                  wiw_cast_f32_to_16, wiw_calib_mfma;
                              12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
                                  statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream;
-                             13: wiw_attn_spatial_ps_bf16 (32x32x16 spatial attention on a pre-scaled Q) */
+                             13: wiw_attn_spatial_ps_bf16 (32x32x16 spatial attention on a pre-scaled Q);
+                             14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling) */
 
 int wiw_abi_version(void);
 
@@ -258,6 +259,18 @@ int wiw_ffn_geglu_f32stream(void* stream, const void* X, int ldx, const void* W1
                        const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
                        float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
                        int C_in, int hidden, int ln, float ln_eps, int f32);
+/* ABI 14: the same operator, same arguments and f32 mask, on v_mfma_f32_32x32x16 with every tensor of a 128-row tile in
+ * registers (csrc/ffn32.hip: one wave per SIMD, the exact-erf GEGLU of hidden chunk c - 1 issued between the MFMAs of chunk c;
+ * no LDS staging in the epilogue: ONE rounding of alpha * (h . W2^T + b2 + rowvec) + beta1 res1 + beta2 res2 whatever the
+ * output type).  Operand packing differs (`unet.pack_ffn32`):
+ *   W1 : [2560][320] in chunks of 64 rows = [32 value | 32 gate] rows of hidden units 32c .. 32c+31, TILED with the 16-row
+ *        chunk swizzle (position p of row R holds 16-byte chunk p ^ ((R >> 1) & 7); the default tiling uses p ^ (R & 7))
+ *   b1 : fp32 [2560] packed the same way, its VALUE half pre-multiplied by 0.5
+ *   W2 : [320][1280] TILED with the 16-row swizzle */
+int wiw_ffn32_geglu(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                    const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
+                    float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
+                    int C_in, int hidden, int ln, float ln_eps, int f32);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) in NHWC, split into statistics + fused normalise/affine/SiLU.

@@ -35,37 +35,46 @@ class TiledW:
     instruction copies one contiguous KiB: 63 B/clk/CU instead of 25 for eight row segments K*2 bytes apart
     (tools/ubench/lds_fill.hip).  Quacks like the [N, K] tensor it replaces (`shape`, `data_ptr`)."""
 
-    def __init__(self, w: torch.Tensor):
+    def __init__(self, w: torch.Tensor, sw16: bool = False):
+        """sw16: the chunk swizzle of the 32x32x16-MFMA kernels (csrc/ffn32.hip): position p of row R holds chunk
+        p ^ ((R >> 1) & 7) — 16 rows distinct mod 16 then cover all LDS banks once per ds_read_b128 (the default swizzle,
+        p ^ (R & 7), serves the 16x16x32 fragment reads of gemm.hip)."""
         assert w.dim() == 2 and w.dtype in DTYPE_CODES and w.shape[1] % 64 == 0, "TiledW: 16-bit [N, K] with K % 64 == 0"
         self.shape = tuple(w.shape)
-        self.data = tile_weight(w)
+        self.sw16 = bool(sw16)
+        self.data = tile_weight(w, sw16=sw16)
 
     def data_ptr(self):
         return self.data.data_ptr()
 
     def untiled(self) -> torch.Tensor:
-        return untile_weight(self.data, *self.shape)
+        return untile_weight(self.data, *self.shape, sw16=self.sw16)
 
 
-def tile_weight(w: torch.Tensor) -> torch.Tensor:
+def _tile_swizzle(Np: int, device, sw16: bool) -> torch.Tensor:
+    """[nb][r][p] -> the chunk stored at position p of row 8 nb + r."""
+    R = torch.arange(Np, device=device).reshape(Np // 8, 8)
+    sw = ((R >> 1) & 7) if sw16 else (R & 7)
+    return torch.arange(8, device=device)[None, None, :] ^ sw[:, :, None]
+
+
+def tile_weight(w: torch.Tensor, sw16: bool = False) -> torch.Tensor:
     """[N, K] bf16 -> flat tiled tensor (layout: class TiledW)."""
     N, K = w.shape
     Np = -(-N // 8) * 8
     if Np != N:
         w = torch.cat([w, w.new_zeros(Np - N, K)])
     x = w.reshape(Np // 8, 8, K // 64, 8, 8).permute(0, 2, 1, 3, 4)           # [nb][kt][r][chunk][e]
-    r = torch.arange(8, device=w.device)
-    idx = (r[None, :] ^ r[:, None])                                          # [r][p] -> chunk stored at position p
-    x = torch.gather(x, 3, idx[None, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
+    idx = _tile_swizzle(Np, w.device, sw16)                                   # [nb][r][p]
+    x = torch.gather(x, 3, idx[:, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
     return x.contiguous().reshape(-1)
 
 
-def untile_weight(t: torch.Tensor, N: int, K: int) -> torch.Tensor:
+def untile_weight(t: torch.Tensor, N: int, K: int, sw16: bool = False) -> torch.Tensor:
     Np = -(-N // 8) * 8
     x = t.reshape(Np // 8, K // 64, 8, 8, 8)
-    r = torch.arange(8, device=t.device)
-    idx = (r[None, :] ^ r[:, None])                                          # the swizzle is an involution per row
-    x = torch.gather(x, 3, idx[None, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
+    idx = _tile_swizzle(Np, t.device, sw16)                                   # the swizzle is an involution per row
+    x = torch.gather(x, 3, idx[:, None, :, :, None].expand(x.shape[0], x.shape[1], 8, 8, 8))
     return x.permute(0, 2, 1, 3, 4).reshape(Np, K)[:N].contiguous()
 
 
@@ -107,6 +116,9 @@ EXPORTS = {
     "wiw_ffn_geglu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "wiw_ffn32_geglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                  C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "wiw_ffn_geglu_f32stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
@@ -207,7 +219,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 13:
+        if self.lib.wiw_abi_version() != 14:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -372,6 +384,21 @@ class Hip:
                                                  _p(out), ldo, M, FFN_C, FFN_HIDDEN, 1 if ln else 0, ln_eps),
                      "wiw_ffn_geglu_bf16")
         self._timed("ffn_fused", flops, nbytes, launch)
+        return out
+
+    def ffn32_geglu(self, X, W1, b1, W2, b2, out, M, *, ldx=FFN_C, rowvec=None, rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0,
+                    beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0, ldo=FFN_C, ln=False, ln_eps=1e-5):
+        """The same operator on the 32x32x16-MFMA kernel (csrc/ffn32.hip, round 5).  Operands from `unet.pack_ffn32`: W1 / W2 are
+        TiledW(sw16=True), W1 / b1 packed in chunks of [32 value | 32 gate] rows, the value half of b1 pre-multiplied by 0.5."""
+        flops = 2.0 * M * (2 * FFN_HIDDEN * FFN_C + FFN_C * FFN_HIDDEN)
+        nbytes = 2.0 * M * FFN_C * (2 + (res1 is not None) + (res2 is not None)) + 2.0 * 3 * FFN_HIDDEN * FFN_C
+        f32 = ((out.dtype == torch.float32) * 1 + (res1 is not None and res1.dtype == torch.float32) * 2
+               + (res2 is not None and res2.dtype == torch.float32) * 4)
+        assert getattr(W1, "sw16", False) and getattr(W2, "sw16", False), "ffn32_geglu: weights must be TiledW(sw16=True) (unet.pack_ffn32)"
+        self._timed("ffn_fused", flops, nbytes, lambda: self._ck(
+            self.lib.wiw_ffn32_geglu(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec), rowvec_ld, rows_per_vec,
+                                     _p(res1), ldr1, beta1, _p(res2), ldr2, beta2, alpha, _p(out), ldo, M, FFN_C, FFN_HIDDEN,
+                                     1 if ln else 0, ln_eps, f32), "wiw_ffn32_geglu"))
         return out
 
     def attn_small(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, seqs, S, Sp, heads, head_dim, scale):

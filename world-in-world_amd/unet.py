@@ -91,6 +91,18 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, tile: int = GEGLU_TILE):
     return wp.contiguous(), bp.contiguous(), n_half
 
 
+def pack_ffn32(w0: torch.Tensor, b0: torch.Tensor, w2: torch.Tensor, dtype: torch.dtype):
+    """Operands of `wiw_ffn32_geglu` (csrc/ffn32.hip) from the GEGLU projection [2560, 320] / [2560] (value rows then gate rows,
+    activations.py:122) and net.2's weight [320, 1280], all fp32: W1 in chunks of [32 value | 32 gate] rows, b1 likewise with
+    its VALUE half pre-multiplied by 0.5 (the kernel evaluates (0.5 v + 0.5 b_v) (|g| erf|g| + g)); both matrices in the tiled
+    layout with the 16-row chunk swizzle.  -> (TiledW W1, b1 fp32, TiledW W2)."""
+    w1p, b1p, n_half = pack_geglu(w0, b0, 32)
+    b1p = b1p.clone().reshape(-1, 2, 32)
+    b1p[:, 0] *= 0.5
+    return (TiledW(w1p.to(dtype).contiguous(), sw16=True), b1p.reshape(-1).float().contiguous(),
+            TiledW(w2.to(dtype).contiguous(), sw16=True))
+
+
 def pack_temporal_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                       tiled: bool = True, dtype: torch.dtype = torch.bfloat16):
     """Operands of `wiw_temporal_attn_block_bf16` (temporal.hip): rows of head h = [q_h | k_h | v_h] with the LayerNorm
