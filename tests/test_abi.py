@@ -82,3 +82,6 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.wiw_ffn_geglu_bf16(None, 8, 320, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 320, 128,
                                   320, 1280, 0, 1e-5) == -1
     assert b"16-byte aligned" in lib.wiw_last_error()
+    assert lib.wiw_ffn32_geglu(None, 16, 320, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 320, 128, 320, 1280,
+                               0, 1e-5, 9) == -1
+    assert b"3-bit mask" in lib.wiw_last_error()

@@ -259,3 +259,120 @@ def test_ffn_fp32_residual_stream(hip, M, rpv):
     hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out32, M, res1=r1h.to(DEV), res2=r2h.float().to(DEV), **kw)
     d = (o_st.float() - out32).abs().max() / out32.abs().max()
     assert float(d) <= 1.2e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# wiw_ffn32_geglu (csrc/ffn32.hip, ABI 14): the same operator on 32x32x16 MFMAs, everything in registers.  Same oracle, same
+# gates.  (Opt-in in the UNet — WIW_FFN32=1 — because it is not faster than ffn.hip; it is kept correct.)
+# ----------------------------------------------------------------------------------------------------------------------
+def make_weights32(dtype, seed=0, gamma=None, beta=None):
+    from wiw_amd.unet import pack_ffn32
+
+    w0 = rnd(2 * HID, C, seed=seed + 1) / math.sqrt(C)
+    b0 = rnd(2 * HID, seed=seed + 2) * 0.3
+    w2 = rnd(C, HID, seed=seed + 3) / math.sqrt(HID)
+    b2 = rnd(C, seed=seed + 4) * 0.3
+    if gamma is not None:
+        w0f, b0f = w0 * gamma[None, :], w0 @ beta + b0
+    else:
+        w0f, b0f = w0, b0
+    W1s, b1s, W2s = pack_ffn32(w0f.to(DEV), b0f.to(DEV), w2.to(DEV), dtype)
+    return dict(w0=w0f.to(dtype).float(), b0=b0f, w2=w2.to(dtype).float(), b2=b2, W1=W1s, b1=b1s, W2=W2s, b2d=b2.to(DEV).contiguous())
+
+
+def test_sw16_tiling_round_trips():
+    from wiw_amd.hip import TiledW
+
+    w = rnd(64 * 3, 320, seed=3).to(torch.bfloat16).to(DEV)
+    for sw16 in (False, True):
+        assert torch.equal(TiledW(w, sw16=sw16).untiled(), w)
+    assert not torch.equal(TiledW(w, sw16=True).data, TiledW(w).data)
+
+
+@pytest.mark.parametrize("M", [1, 100, 128, 1000, 256 * 128 + 77, 3 * 256 * 128 + 5])
+def test_ffn32_plain(hip, M):
+    dt = torch.bfloat16
+    wt = make_weights32(dt)
+    x = rnd(M, C, seed=10).to(dt)
+    out = torch.full((M, C), float("nan"), dtype=dt, device=DEV)
+    hip.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M)
+    check(out, oracle(x, wt, dt), dt, f"ffn32 plain M={M}")
+
+
+def test_ffn32_identity_rows_catch_transposes(hip):
+    dt = torch.bfloat16
+    wt = make_weights32(dt, seed=50)
+    x = torch.eye(C, C).to(dt)
+    out = torch.empty(C, C, dtype=dt, device=DEV)
+    hip.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, C)
+    check(out, oracle(x, wt, dt), dt, "ffn32 one-hot rows")
+
+
+@pytest.mark.parametrize("M,rpv", [(700, 100), (3 * 9216 // 8, 9216 // 8), (130, 7)])
+def test_ffn32_epilogues(hip, M, rpv):
+    """Residual + per-frame vector; AlphaBlender with two residuals; strided, no b2."""
+    dt = torch.bfloat16
+    wt = make_weights32(dt, seed=20)
+    x, r1, r2 = rnd(M, C, seed=11).to(dt), rnd(M, C, seed=12).to(dt), rnd(M, C, seed=16).to(dt)
+    rv = rnd(-(-M // rpv), C, seed=13)
+    out = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, rowvec=rv.to(DEV), rowvec_ld=C, rows_per_vec=rpv,
+                    res1=r1.to(DEV), ldr1=C, beta1=1.0)
+    check(out, oracle(x, wt, dt, rowvec=rv, rows_per_vec=rpv, res1=r1, beta1=1.0), dt, f"ffn32 res1+rowvec M={M} rpv={rpv}")
+    am = 0.37
+    hip.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, rowvec=rv.to(DEV), rowvec_ld=C, rows_per_vec=rpv,
+                    res1=r1.to(DEV), ldr1=C, beta1=1.0 - am, res2=r2.to(DEV), ldr2=C, beta2=am, alpha=1.0 - am)
+    check(out, oracle(x, wt, dt, rowvec=rv, rows_per_vec=rpv, res1=r1, beta1=1.0 - am, res2=r2, beta2=am, alpha=1.0 - am), dt,
+          f"ffn32 AlphaBlender M={M}")
+    ldx, ldo = 512, 384
+    xs = rnd(M, ldx, seed=21).to(dt)
+    outs = torch.zeros(M, ldo, dtype=dt, device=DEV)
+    hip.ffn32_geglu(xs.to(DEV), wt["W1"], wt["b1"], wt["W2"], None, outs, M, ldx=ldx, ldo=ldo)
+    check(outs[:, :C], oracle(xs[:, :C], wt, dt, bias2=False), dt, "ffn32 strided, no b2")
+    assert float(outs[:, C:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M", [64, 1500, 2 * 256 * 128 + 300])
+def test_ffn32_fused_layernorm(hip, M):
+    dt = torch.bfloat16
+    gamma, beta = 1.0 + 0.2 * rnd(C, seed=40), 0.1 * rnd(C, seed=41)
+    wt = make_weights32(dt, seed=42, gamma=gamma, beta=beta)
+    x = (rnd(M, C, seed=18) * 3.0 + 1.5 + rnd(M, 1, seed=19) * 4.0).to(dt)
+    out = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, ln=True, res1=x.to(DEV), ldr1=C, beta1=1.0)
+    check(out, oracle(x, wt, dt, ln=True, res1=x, beta1=1.0), dt, f"ffn32 fused LayerNorm M={M}")
+
+
+def test_ffn32_bit_exact_row_independent_and_fp32_stream(hip):
+    dt = torch.bfloat16
+    wt = make_weights32(dt, seed=70)
+    M = 300 * 128 + 19
+    x = rnd(M, C, seed=22).to(dt).to(DEV)
+    r1 = rnd(M, C, seed=23).to(dt).to(DEV)
+    o1, o2 = torch.empty(M, C, dtype=dt, device=DEV), torch.empty(M, C, dtype=dt, device=DEV)
+    for o in (o1, o2):
+        hip.ffn32_geglu(x, wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o, M, res1=r1, ldr1=C, beta1=1.0)
+    assert torch.equal(o1, o2)
+    lo, n = 128 * 257 + 5, 200
+    o3 = torch.empty(n, C, dtype=dt, device=DEV)
+    hip.ffn32_geglu(x[lo:lo + n].contiguous(), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o3, n, res1=r1[lo:lo + n].contiguous(), ldr1=C, beta1=1.0)
+    assert torch.equal(o1[lo:lo + n], o3)
+    # fp32 residual stream: fp32 res1 and output; the 16-bit output of the same call is the ONE rounding of the fp32 result
+    r32 = rnd(M, C, seed=24) * 3.0
+    o32 = torch.full((M, C), float("nan"), dtype=torch.float32, device=DEV)
+    hip.ffn32_geglu(x, wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o32, M, res1=r32.to(DEV), ldr1=C, beta1=1.0)
+    check(o32, oracle(x.cpu(), wt, dt, res1=r32, beta1=1.0), dt, "ffn32 fp32 stream")
+    o16 = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn32_geglu(x, wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o16, M, res1=r32.to(DEV), ldr1=C, beta1=1.0)
+    assert torch.equal(o16.cpu(), o32.cpu().to(dt))
+
+
+def test_ffn32_fp16_build():
+    dt = torch.float16
+    hip16 = _hip(dt)
+    wt = make_weights32(dt, seed=90)
+    M = 3000
+    x, r1 = rnd(M, C, seed=26).to(dt), rnd(M, C, seed=27).to(dt)
+    out = torch.empty(M, C, dtype=dt, device=DEV)
+    hip16.ffn32_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, res1=r1.to(DEV), ldr1=C, beta1=1.0)
+    check(out, oracle(x, wt, dt, res1=r1, beta1=1.0), dt, "ffn32 fp16 build")

@@ -46,7 +46,28 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-WIW_DEV void glds16(const char* g, char* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
+// LDS-DMA, 16 bytes per lane, in the SADDR form: wave-uniform 64-bit block address in SGPRs + one 32-bit lane offset — a piece
+// costs no VGPR of its own (the builtin takes a per-lane 64-bit pointer; hipcc hoisted ten of them out of the chunk loop and
+// spilled them).  M0 carries the LDS address and is saved / restored inside the statement (cdna guide 5.7); s_nop 4: an SGPR
+// operand written just before by VALU (readfirstlane) must not be read by the VMEM instruction too early.
+WIW_DEV void glds16s(uint64_t sb, unsigned voff, uint32_t lds) {    // both wave-uniform by construction (SALU values)
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds) : "memory");
+}
+WIW_DEV void glds16(const char* sbase, unsigned voff, char* l) {
+#ifdef FF_DMA_BUILTIN
+    __builtin_amdgcn_global_load_lds((gptr_t)(sbase + voff), (lptr_t)l, 16, 0, 0);
+    return;
+#endif
+    const uint32_t lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lptr_t)l);
+    // (the builtin returns a SIGNED int: without the casts a low half with bit 31 set sign-extends over the high half)
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)sbase >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)sbase);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds) : "memory");
+}
 
 #ifdef WIW_F16
 #define FF_MFMA32(a, b, c) \
@@ -108,23 +129,16 @@ __global__ __launch_bounds__(256, 1) void ffn32_kernel(const Ffn32Args p) {
     if ((int)blockIdx.x >= ntiles) return;
 
     // ---- LDS-DMA sources (this lane's 16 bytes of every 1-KiB block)
-    const char* w1src = p.W1 + lane * 16;
-    const char* w2src = p.W2 + lane * 16;
+    // (uniform block address + a 32-bit lane offset: the saddr form of global_load_lds — one VGPR for every piece, not a 64-bit
+    // pointer per piece: hipcc hoisted ten of those out of the loop and spilled them)
+    const unsigned lane16 = lane * 16;
     auto dma_w1 = [&](int cw, int slot) {   // chunk cw (40 contiguous KiB of the tiled matrix) -> [kt][row][128 B] of the slot
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int b = wave + 4 * k;          // block b = 5 * (row block of 8) + kt
-            glds16(w1src + ((int64_t)cw * 40 + b) * 1024, smem + W1_OFF + slot * W1_SLOT + (b % 5) * 8192 + (b / 5) * 1024);
+            glds16(p.W1 + ((int64_t)cw * 40 + b) * 1024, lane16, smem + W1_OFF + slot * W1_SLOT + (b % 5) * 8192 + (b / 5) * 1024);
         }
     };
-    auto dma_w2 = [&](int t) {              // unit tile t (K tile t of the [320][1280] matrix): row blocks 0..39
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            const int nbk = wave + 4 * k;
-            glds16(w2src + ((int64_t)nbk * (HID / 64) + t) * 1024, smem + W2_OFF + nbk * 1024);
-        }
-    };
-
     // ---- LDS read addresses of this lane (A-operand fragments: row of a 32-row block, 16-byte chunk 2 (ks & 3) + hi)
     const int keyi = 16 * (li >> 4) + 8 * ((li >> 2) & 1) + 4 * ((li >> 3) & 1) + (li & 3);
     const int aV = keyi * 128 + ((hi ^ ((keyi >> 1) & 7)) << 4);
@@ -149,211 +163,205 @@ __global__ __launch_bounds__(256, 1) void ffn32_kernel(const Ffn32Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 
-    // GEGLU of one half block (registers 8 h .. 8 h + 7 of V / G = key step h), stage st of 20, four instructions each
-    f32x2_t gq[4], gax[4], gt[4], ge[4], gp[4];     // live values of the half block in flight
-    // FF_PIN4: an empty asm that reads and writes the four pairs of a stage — every pair then lives in an aligned 64-bit
-    // register pair (the packed VOP3P forms need that; without it instruction selection falls back to scalar v_fma_f32) and
-    // nothing of the next stage is computed before it
-#define FF_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
-    auto geglu_stage = [&](auto par_tag, auto half_tag, auto st_tag) {
-        constexpr int PAR = decltype(par_tag)::value, H = decltype(half_tag)::value, ST = decltype(st_tag)::value;
+    // GEGLU of one chunk = 68 UNITS of two value pairs each (hipcc unpacks v_pk_*_f32 in the shadow of an MFMA — a packed f32 op
+    // beside MFMAs costs as much as its two halves —, so a unit is ~4 VALU issues): half block h (registers 8 h .. 8 h + 7 of
+    // V / G = key step h), row k of 17, pairs 2 sub, 2 sub + 1.  Unit u of a chunk: h = u / 34, k = (u % 34) / 2, sub = u & 1.
+    // The 68 units are spread over the 60 MFMA gaps of an iteration (4.5 issues per gap; a 32x32x16 MFMA hides 4).
+    float gq[8], gax[8], gt[8], ge[8], gp[8];     // live values of the half block in flight
+    // (plain v_fma_f32 / v_mul_f32 with LITERAL constants: the packed forms would need every constant as a 64-bit register pair —
+    // two dozen registers this kernel does not have — and hipcc splits them beside MFMAs anyway)
+    auto geglu_unit = [&](auto par_tag, auto u_tag) {
+        constexpr int PAR = decltype(par_tag)::value, U = decltype(u_tag)::value;
+        constexpr int H = U / 34, K = (U % 34) / 2, E0 = 4 * (U & 1);
         f32x16& Vv = vgV[PAR];
         f32x16& Gg = vgG[PAR];
-        const f32x2_t one = {1.0f, 1.0f};
-        if constexpr (ST == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gq[e] = f32x2_t{Gg[8 * H + 2 * e], Gg[8 * H + 2 * e + 1]} + f32x2_t{bgq[(8 * H + 2 * e) >> 2][(2 * e) & 3], bgq[(8 * H + 2 * e) >> 2][(2 * e + 1) & 3]};
-            FF_PIN4(gq);
-        } else if constexpr (ST == 1 || ST == 2) {
-            constexpr int o = (ST - 1) * 2;
-#pragma unroll
-            for (int e = o; e < o + 2; ++e) gax[e] = f32x2_t{__builtin_fabsf(gq[e].x), __builtin_fabsf(gq[e].y)};
-        } else if constexpr (ST == 3) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gt[e] = __builtin_elementwise_fma(f32x2_t{0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f}, gax[e], one);
-            FF_PIN4(gt);
-        } else if constexpr (ST == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ge[e] = gax[e] * (-1.4426950408889634f * 0.5f);
-            FF_PIN4(ge);
-        } else if constexpr (ST == 5) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ge[e] = ge[e] * gax[e];
-            FF_PIN4(ge);
-        } else if constexpr (ST == 6 || ST == 7) {
-            constexpr int o = (ST - 6) * 2;
-#pragma unroll
-            for (int e = o; e < o + 2; ++e) gt[e] = f32x2_t{__builtin_amdgcn_rcpf(gt[e].x), __builtin_amdgcn_rcpf(gt[e].y)};
-        } else if constexpr (ST == 8 || ST == 9) {
-            constexpr int o = (ST - 8) * 2;
-#pragma unroll
-            for (int e = o; e < o + 2; ++e) ge[e] = f32x2_t{__builtin_amdgcn_exp2f(ge[e].x), __builtin_amdgcn_exp2f(ge[e].y)};
-        } else if constexpr (ST == 10) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, gt[e], f32x2_t{-1.453152027f, -1.453152027f});
-            FF_PIN4(gp);
-        } else if constexpr (ST == 11) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = __builtin_elementwise_fma(gp[e], gt[e], f32x2_t{1.421413741f, 1.421413741f});
-            FF_PIN4(gp);
-        } else if constexpr (ST == 12) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = __builtin_elementwise_fma(gp[e], gt[e], f32x2_t{-0.284496736f, -0.284496736f});
-            FF_PIN4(gp);
-        } else if constexpr (ST == 13) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = __builtin_elementwise_fma(gp[e], gt[e], f32x2_t{0.254829592f, 0.254829592f});
-            FF_PIN4(gp);
-        } else if constexpr (ST == 14) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = -gp[e] * gt[e];
-            FF_PIN4(gp);
-        } else if constexpr (ST == 15) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gp[e] = __builtin_elementwise_fma(gp[e], ge[e], one);          // erf|g|
-            FF_PIN4(gp);
-        } else if constexpr (ST == 16) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gq[e] = __builtin_elementwise_fma(gax[e], gp[e], gq[e]);       // |g| erf|g| + g = 2 gelu(g)
-            FF_PIN4(gq);
-        } else if constexpr (ST == 17) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                gt[e] = __builtin_elementwise_fma(f32x2_t{Vv[8 * H + 2 * e], Vv[8 * H + 2 * e + 1]}, f32x2_t{0.5f, 0.5f}, f32x2_t{bvq[(8 * H + 2 * e) >> 2][(2 * e) & 3], bvq[(8 * H + 2 * e) >> 2][(2 * e + 1) & 3]});
-            FF_PIN4(gt);
-        } else if constexpr (ST == 18) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gt[e] = gt[e] * gq[e];
-            FF_PIN4(gt);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hb[H].u[e] = pack2bf(gt[e].x, gt[e].y);
+        for (int e = E0; e < E0 + 4; ++e) {
+            const int r = 8 * H + e;     // accumulator register of this value
+            if constexpr (K == 0) gq[e] = Gg[r] + bgq[r >> 2][r & 3];
+            else if constexpr (K == 1) gax[e] = __builtin_fabsf(gq[e]);
+            else if constexpr (K == 2) gt[e] = __builtin_fmaf(0.3275911f * 0.70710678118654752f, gax[e], 1.0f);
+            else if constexpr (K == 3) ge[e] = gax[e] * (-1.4426950408889634f * 0.5f);
+            else if constexpr (K == 4) ge[e] = ge[e] * gax[e];
+            else if constexpr (K == 5) gt[e] = __builtin_amdgcn_rcpf(gt[e]);
+            else if constexpr (K == 6) ge[e] = __builtin_amdgcn_exp2f(ge[e]);
+            else if constexpr (K == 7) gp[e] = __builtin_fmaf(1.061405429f, gt[e], -1.453152027f);
+            else if constexpr (K == 8) gp[e] = __builtin_fmaf(gp[e], gt[e], 1.421413741f);
+            else if constexpr (K == 9) gp[e] = __builtin_fmaf(gp[e], gt[e], -0.284496736f);
+            else if constexpr (K == 10) gp[e] = __builtin_fmaf(gp[e], gt[e], 0.254829592f);
+            else if constexpr (K == 11) gp[e] = -gp[e] * gt[e];
+            else if constexpr (K == 12) gp[e] = __builtin_fmaf(gp[e], ge[e], 1.0f);          // erf|g|
+            else if constexpr (K == 13) gq[e] = __builtin_fmaf(gax[e], gp[e], gq[e]);        // |g| erf|g| + g = 2 gelu(g)
+            else if constexpr (K == 14) gt[e] = __builtin_fmaf(Vv[r], 0.5f, bvq[r >> 2][r & 3]);   // 0.5 (v + b_v)
+            else if constexpr (K == 15) gt[e] = gt[e] * gq[e];
+        }
+        if constexpr (K == 16) {
+            hb[H].u[E0 / 2] = pack2bf(gt[E0], gt[E0 + 1]);
+            hb[H].u[E0 / 2 + 1] = pack2bf(gt[E0 + 2], gt[E0 + 3]);
+        }
+    };
+    // the units of MFMA gap g of an iteration: half block 0 in gaps 0..24, half block 1 in gaps 25..49 (phase 2 needs H of key
+    // step 0 from gap 40 on and of key step 1 from gap 50 on) — 1.36 units = 5.4 VALU issues per gap
+    auto geglu_gap = [&](auto par_tag, auto g_tag) {
+        constexpr int g = decltype(g_tag)::value;
+        if constexpr (g < 50) {
+            constexpr int h = g / 25, gg = g % 25;
+            constexpr int u0 = 34 * h + gg * 34 / 25, u1 = 34 * h + (gg + 1) * 34 / 25;
+            if constexpr (u1 > u0) geglu_unit(par_tag, std::integral_constant<int, u0>{});
+            if constexpr (u1 > u0 + 1) geglu_unit(par_tag, std::integral_constant<int, u0 + 1>{});
         }
     };
 
-    // One iteration: S1 = phase 1 of chunk i (parity PAR = i & 1) with the GEGLU of chunk i - 1 in its gaps; S2 = phase 2 of
-    // chunk i - 1.  HAS1 / HAS2: the first iteration of a tile has no S2 / GEGLU, the 41st no S1.
-    auto iteration = [&](auto par_tag, auto has1_tag, auto has2_tag, int i, int next_cw) {   // next_cw: W1 chunk to fetch now (-1: none)
+    // One iteration i of a tile (41 per tile):
+    //   S1 (HAS1): phase 1 of chunk i — 20 k-steps, V and G accumulators of parity PAR = i & 1 alternating (40 gaps)
+    //   S2 (HAS2): phase 2 of chunk i - 1 — 20 MFMAs over the ten Y accumulators (20 gaps)
+    //   GEGLU (HASG = HAS2) of chunk i - 1 in gaps 0..49.
+    // LDS-DMA pieces ride in the gaps too: W1 chunk `next_cw` (10 per wave, slots 0..9 of S1), the W2 tile `w2_tile` (slots 10..19;
+    // unit tile t serves phase 2 of chunks 2 t, 2 t + 1 = iterations 2 t + 1, 2 t + 2 and is fetched in iteration 2 t + 1, which
+    // therefore has a second barrier between S1 and S2).  ONE other barrier, after gap 57: everybody is through
+    // phase 1 of chunk i (its W1 slot may be refilled from the next iteration's first gap on), W1(i + 1) has landed (my pieces:
+    // vmcnt(0)), my last W2 fragment reads have returned — then the first fragment reads of the next iteration's phase 1.
+    auto iteration = [&](auto par_tag, auto has1_tag, auto hasg_tag, auto has2_tag, auto ns_tag, int i, int next_cw, int w2_tile, bool next_has1) {
         constexpr int PAR = decltype(par_tag)::value;
-        constexpr bool HAS1 = decltype(has1_tag)::value != 0, HAS2 = decltype(has2_tag)::value != 0;
+        constexpr bool HAS1 = decltype(has1_tag)::value != 0, HASG = decltype(hasg_tag)::value != 0, HAS2 = decltype(has2_tag)::value != 0;
         constexpr int SLOT = PAR;                 // W1 chunk i sits in slot i & 1
-        constexpr int Q = 1 - PAR;                // chunk i - 1: parity of its accumulators, and its half of the W2 tile
-        // ---- top: my DMA pieces of W1(i) have landed, my LDS reads of the previous iteration are done; everybody is through
-        // S2(i-1): the other W1 slot and (odd i) the W2 tile may be refilled
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (!(FF_ABLATE & 8)) __syncthreads();
-        if (next_cw >= 0 && !(FF_ABLATE & 2)) dma_w1(next_cw, next_cw & 1);   // (its slot was last read by phase 1 of chunk i - 1)
-        if (PAR == 1 && !(FF_ABLATE & 2)) dma_w2((i - 1) >> 1);               // unit tile t serves phase 2 of chunks 2 t, 2 t + 1 = S2 of iterations 2 t + 1, 2 t + 2
-        if (HAS1) {
-            FF_DSR(fV[0], w1a[SLOT][0], 0);
-            FF_DSR(fG[0], w1a[SLOT][0], 4096);
-            FF_DSR(fV[1], w1a[SLOT][1], 0);
-            FF_DSR(fG[1], w1a[SLOT][1], 4096);
-        }
+        constexpr int NS = decltype(ns_tag)::value;   // slot of the chunk whose phase 1 runs next (chunk 0 of the next tile: 0)
+        using Qt = std::integral_constant<int, 1 - PAR>;   // chunk i - 1: parity of its accumulators; its half of the W2 tile
+        // wave-uniform bases of this iteration's DMA pieces, made opaque: hipcc otherwise computes every piece's 64-bit address
+        // for every unrolled iteration up front and spills 200 SGPRs into VGPR lanes (1 800 v_readlane / v_writelane)
+        uint64_t w1n = (uint64_t)(uintptr_t)p.W1 + (uint64_t)((next_cw >= 0 ? next_cw : 0) * 40) * 1024;
+        uint64_t w2n = (uint64_t)(uintptr_t)p.W2 + (uint64_t)(w2_tile >= 0 ? w2_tile : 0) * 1024;
+        uint32_t w1dst = (uint32_t)(uintptr_t)(lptr_t)(smem + W1_OFF) + (next_cw & 1) * W1_SLOT;
+        asm volatile("" : "+s"(w1n), "+s"(w2n), "+s"(w1dst));
+        auto dma_piece = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            if (FF_ABLATE & 2) return;
+            if (s < 10 && next_cw >= 0) {
+                const int b = wave + 4 * s;
+                glds16s(w1n + (uint64_t)b * 1024, lane16, w1dst + (b % 5) * 8192 + (b / 5) * 1024);
+            }
+            if (s >= 10 && w2_tile >= 0) {
+                const int nbk = wave + 4 * (s - 10);
+                glds16s(w2n + (uint64_t)nbk * (HID / 64) * 1024, lane16, (uint32_t)(uintptr_t)(lptr_t)(smem + W2_OFF) + nbk * 1024);
+            }
+        };
+        const bool refill = w2_tile >= 0;      // (wave-uniform, the same for every wave of the block)
         // ---- S1
         if constexpr (HAS1) {
             auto slot = [&](auto s_tag) {
                 constexpr int s = decltype(s_tag)::value;
-                constexpr int kt = s >> 2;
                 if constexpr (s + 2 < KS) {
                     constexpr int s2 = s + 2;
                     FF_DSR(fV[s2 % 3], w1a[SLOT][s2 & 3], (s2 >> 2) * 8192);
                     FF_DSR(fG[s2 % 3], w1a[SLOT][s2 & 3], (s2 >> 2) * 8192 + 4096);
                 }
-                if constexpr (PAR == 0 && HAS2 && s == 18) {   // phase-2 prefetch (even iterations: the W2 tile is already there)
-                    FF_DSR(fW[0], w2a[2 * Q + 0], 0);
-                    FF_DSR(fW[1], w2a[2 * Q + 0], 4096);
-                }
-                if constexpr (PAR == 0 && HAS2 && s == 19) FF_DSR(fW[2], w2a[2 * Q + 0], 2 * 4096);
-                (void)kt;
-                if constexpr (s + 2 < KS || (PAR == 0 && HAS2 && s == 18)) FF_WAIT2(4, fV[s % 3], fG[s % 3]);
-                else if constexpr (PAR == 0 && HAS2 && s == 19) FF_WAIT2(3, fV[s % 3], fG[s % 3]);
+                dma_piece(s_tag);
+                if constexpr (s + 2 < KS) FF_WAIT2(4, fV[s % 3], fG[s % 3]);
                 else if constexpr (s == 18) FF_WAIT2(2, fV[s % 3], fG[s % 3]);
                 else FF_WAIT2(0, fV[s % 3], fG[s % 3]);
                 if constexpr (s == 0) vgV[PAR] = FF_MFMA32(fV[0], xf[0], zero);
                 else vgV[PAR] = FF_MFMA32(fV[s % 3], xf[s], vgV[PAR]);
-                if constexpr (HAS2 && !(FF_ABLATE & 1)) geglu_stage(std::integral_constant<int, Q>{}, std::integral_constant<int, (s >= 10)>{}, std::integral_constant<int, 2 * (s % 10)>{});
+                if constexpr (HASG && !(FF_ABLATE & 1)) geglu_gap(Qt{}, std::integral_constant<int, 2 * s>{});
                 FF_GAP
                 if constexpr (s == 0) vgG[PAR] = FF_MFMA32(fG[0], xf[0], zero);
                 else vgG[PAR] = FF_MFMA32(fG[s % 3], xf[s], vgG[PAR]);
-                if constexpr (HAS2 && !(FF_ABLATE & 1)) geglu_stage(std::integral_constant<int, Q>{}, std::integral_constant<int, (s >= 10)>{}, std::integral_constant<int, 2 * (s % 10) + 1>{});
+                if constexpr (HASG && !(FF_ABLATE & 1)) geglu_gap(Qt{}, std::integral_constant<int, 2 * s + 1>{});
                 FF_GAP
             };
-            slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{}); slot(std::integral_constant<int, 2>{});
-            slot(std::integral_constant<int, 3>{}); slot(std::integral_constant<int, 4>{}); slot(std::integral_constant<int, 5>{});
-            slot(std::integral_constant<int, 6>{}); slot(std::integral_constant<int, 7>{}); slot(std::integral_constant<int, 8>{});
-            slot(std::integral_constant<int, 9>{}); slot(std::integral_constant<int, 10>{}); slot(std::integral_constant<int, 11>{});
-            slot(std::integral_constant<int, 12>{}); slot(std::integral_constant<int, 13>{}); slot(std::integral_constant<int, 14>{});
-            slot(std::integral_constant<int, 15>{}); slot(std::integral_constant<int, 16>{}); slot(std::integral_constant<int, 17>{});
-            slot(std::integral_constant<int, 18>{}); slot(std::integral_constant<int, 19>{});
-        } else if constexpr (HAS2) {   // the 41st iteration: the GEGLU of the last chunk without MFMAs to hide behind
-            auto st = [&](auto h_tag, auto s_tag) { geglu_stage(std::integral_constant<int, Q>{}, h_tag, s_tag); };
-#define FF_ALLST(h)                                                                                                                  \
-    st(h, std::integral_constant<int, 0>{}); st(h, std::integral_constant<int, 1>{}); st(h, std::integral_constant<int, 2>{});       \
-    st(h, std::integral_constant<int, 3>{}); st(h, std::integral_constant<int, 4>{}); st(h, std::integral_constant<int, 5>{});       \
-    st(h, std::integral_constant<int, 6>{}); st(h, std::integral_constant<int, 7>{}); st(h, std::integral_constant<int, 8>{});       \
-    st(h, std::integral_constant<int, 9>{}); st(h, std::integral_constant<int, 10>{}); st(h, std::integral_constant<int, 11>{});     \
-    st(h, std::integral_constant<int, 12>{}); st(h, std::integral_constant<int, 13>{}); st(h, std::integral_constant<int, 14>{});    \
-    st(h, std::integral_constant<int, 15>{}); st(h, std::integral_constant<int, 16>{}); st(h, std::integral_constant<int, 17>{});    \
-    st(h, std::integral_constant<int, 18>{}); st(h, std::integral_constant<int, 19>{});
-            FF_ALLST(P0{})
-            FF_ALLST(P1{})
-#undef FF_ALLST
+#define FF_S20(f)                                                                                                                 \
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});                \
+    f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});                \
+    f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{}); f(std::integral_constant<int, 8>{});                \
+    f(std::integral_constant<int, 9>{}); f(std::integral_constant<int, 10>{}); f(std::integral_constant<int, 11>{});              \
+    f(std::integral_constant<int, 12>{}); f(std::integral_constant<int, 13>{}); f(std::integral_constant<int, 14>{});             \
+    f(std::integral_constant<int, 15>{}); f(std::integral_constant<int, 16>{}); f(std::integral_constant<int, 17>{});             \
+    f(std::integral_constant<int, 18>{}); f(std::integral_constant<int, 19>{});
+            FF_S20(slot)
+        } else {   // the last two iterations of a tile: no phase 1 to hide behind
+            auto nslot = [&](auto s_tag) {
+                constexpr int s = decltype(s_tag)::value;
+                dma_piece(s_tag);
+                if constexpr (HASG && !(FF_ABLATE & 1)) {
+                    geglu_gap(Qt{}, std::integral_constant<int, 2 * s>{});
+                    geglu_gap(Qt{}, std::integral_constant<int, 2 * s + 1>{});
+                }
+            };
+            FF_S20(nslot)
         }
-        // ---- S2: phase 2 of chunk i - 1 (its half Q of the W2 tile), bias reads for the GEGLU of chunk i
-        if constexpr (HAS2) {
-            if constexpr (PAR == 1 || !HAS1) {   // odd iterations: the W2 tile was refilled at the top — make it visible first
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(FF_ABLATE & 8)) __syncthreads();
-                FF_DSR(fW[0], w2a[2 * Q + 0], 0);
-                FF_DSR(fW[1], w2a[2 * Q + 0], 4096);
-                FF_DSR(fW[2], w2a[2 * Q + 0], 2 * 4096);
+        // ---- an iteration that refilled the W2 tile: visible to everybody before phase 2 reads it
+        if (refill) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(FF_ABLATE & 8)) __syncthreads();
+        }
+        // ---- S2
+        {
+            if constexpr (HAS2) {
+                FF_DSR(fW[0], w2a[2 * (1 - PAR) + 0], 0);
+                FF_DSR(fW[1], w2a[2 * (1 - PAR) + 0], 4096);
+                FF_DSR(fW[2], w2a[2 * (1 - PAR) + 0], 2 * 4096);
             }
-            const int ba = b1a + i * 256;
-            if constexpr (HAS1) {   // the bias of chunk i in accumulator register order (4 x 16 B value half, 4 x 16 B gate half)
-                FF_DSR(bvq[0], ba, 0);   FF_DSR(bvq[1], ba, 16);
-                FF_DSR(bvq[2], ba, 64);  FF_DSR(bvq[3], ba, 80);
-                FF_DSR(bgq[0], ba, 128); FF_DSR(bgq[1], ba, 144);
-                FF_DSR(bgq[2], ba, 192); FF_DSR(bgq[3], ba, 208);
-            }
+            const int ba = b1a + i * 256;    // the bias of chunk i for the GEGLU of the next iteration: fetched in gap 50 (this
+                                             // iteration's GEGLU reads its bias until gap ~47)
             auto p2 = [&](auto j_tag) {
                 constexpr int j = decltype(j_tag)::value;
                 constexpr int ks = j / 10, ob = j % 10;
-                if constexpr (j + 3 < 20) {
-                    constexpr int j3 = j + 3;
-                    FF_DSR(fW[j3 % 4], w2a[2 * Q + j3 / 10], (j3 % 10) * 4096);
+                (void)&fV; (void)&fG; (void)&w1a; (void)&bvq; (void)&bgq; (void)next_has1; (void)ba;   // (named here: clang does not capture what only a discarded `if constexpr` branch uses)
+                if constexpr (j == 10 && HAS1) {
+                    FF_DSR(bvq[0], ba, 0);   FF_DSR(bvq[1], ba, 16);
+                    FF_DSR(bvq[2], ba, 64);  FF_DSR(bvq[3], ba, 80);
+                    FF_DSR(bgq[0], ba, 128); FF_DSR(bgq[1], ba, 144);
+                    FF_DSR(bgq[2], ba, 192); FF_DSR(bgq[3], ba, 208);
                 }
-                if constexpr (j < 3 && HAS1) FF_WAIT1(11, fW[j % 4]);
-                else if constexpr (j < 3) FF_WAIT1(3, fW[j % 4]);
-                else if constexpr (j + 3 < 20) FF_WAIT1(3, fW[j % 4]);
-                else if constexpr (j == 17) FF_WAIT1(2, fW[j % 4]);
-                else if constexpr (j == 18) FF_WAIT1(1, fW[j % 4]);
-                else FF_WAIT1(0, fW[j % 4]);
-                Y[ob] = FF_MFMA32(fW[j % 4], hb[ks].v, Y[ob]);
+                if constexpr (HAS2) {
+                    if constexpr (j + 3 < 20) {
+                        constexpr int j3 = j + 3;
+                        FF_DSR(fW[j3 % 4], w2a[2 * (1 - PAR) + j3 / 10], (j3 % 10) * 4096);
+                    }
+                    if constexpr (j >= 10 && j < 13 && HAS1) FF_WAIT1(11, fW[j % 4]);   // (the eight bias reads sit between fW[j] and fW[j + 3])
+                    else if constexpr (j < 17) FF_WAIT1(3, fW[j % 4]);
+                    else if constexpr (j == 17) FF_WAIT1(2, fW[j % 4]);
+                    else FF_WAIT1(4, fW[j % 4]);      // (everything older than the four reads issued behind the barrier has landed)
+                    Y[ob] = FF_MFMA32(fW[j % 4], hb[ks].v, Y[ob]);
+                }
+                if constexpr (HASG && !(FF_ABLATE & 1)) geglu_gap(Qt{}, std::integral_constant<int, 40 + j>{});
                 FF_GAP
+                if constexpr (j == 17) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if constexpr (HAS1) asm volatile("" : "+v"(bvq[0]), "+v"(bvq[1]), "+v"(bvq[2]), "+v"(bvq[3]), "+v"(bgq[0]), "+v"(bgq[1]), "+v"(bgq[2]), "+v"(bgq[3]));
+                    if (!(FF_ABLATE & 8)) __syncthreads();
+                    if (next_has1) {     // first fragment reads of the next iteration's phase 1
+                        FF_DSR(fV[0], w1a[NS][0], 0);
+                        FF_DSR(fG[0], w1a[NS][0], 4096);
+                        FF_DSR(fV[1], w1a[NS][1], 0);
+                        FF_DSR(fG[1], w1a[NS][1], 4096);
+                    } else {             // keep the queue depth the waits of gaps 58 / 59 count on
+                        FF_DSR(fV[0], w1a[0][0], 0); FF_DSR(fG[0], w1a[0][0], 0); FF_DSR(fV[1], w1a[0][0], 0); FF_DSR(fG[1], w1a[0][0], 0);
+                    }
+                }
             };
-            p2(std::integral_constant<int, 0>{}); p2(std::integral_constant<int, 1>{}); p2(std::integral_constant<int, 2>{});
-            p2(std::integral_constant<int, 3>{}); p2(std::integral_constant<int, 4>{}); p2(std::integral_constant<int, 5>{});
-            p2(std::integral_constant<int, 6>{}); p2(std::integral_constant<int, 7>{}); p2(std::integral_constant<int, 8>{});
-            p2(std::integral_constant<int, 9>{}); p2(std::integral_constant<int, 10>{}); p2(std::integral_constant<int, 11>{});
-            p2(std::integral_constant<int, 12>{}); p2(std::integral_constant<int, 13>{}); p2(std::integral_constant<int, 14>{});
-            p2(std::integral_constant<int, 15>{}); p2(std::integral_constant<int, 16>{}); p2(std::integral_constant<int, 17>{});
-            p2(std::integral_constant<int, 18>{}); p2(std::integral_constant<int, 19>{});
-            if constexpr (HAS1) asm volatile("" : "+v"(bvq[0]), "+v"(bvq[1]), "+v"(bvq[2]), "+v"(bvq[3]), "+v"(bgq[0]), "+v"(bgq[1]), "+v"(bgq[2]), "+v"(bgq[3]));
-        } else {   // first iteration of a tile: only the bias of chunk 0 is fetched
-            const int ba = b1a;
-            FF_DSR(bvq[0], ba, 0);   FF_DSR(bvq[1], ba, 16);
-            FF_DSR(bvq[2], ba, 64);  FF_DSR(bvq[3], ba, 80);
-            FF_DSR(bgq[0], ba, 128); FF_DSR(bgq[1], ba, 144);
-            FF_DSR(bgq[2], ba, 192); FF_DSR(bgq[3], ba, 208);
-            FF_WAIT(0);
-            asm volatile("" : "+v"(bvq[0]), "+v"(bvq[1]), "+v"(bvq[2]), "+v"(bvq[3]), "+v"(bgq[0]), "+v"(bgq[1]), "+v"(bgq[2]), "+v"(bgq[3]));
+            FF_S20(p2)
+#undef FF_S20
         }
     };
 
     // ---- kernel prologue: the resident bias, the first W1 chunk
-    for (int k = wave; k < B1_BYTES / 1024; k += 4) glds16((const char*)p.b1 + k * 1024 + lane * 16, smem + B1_OFF + k * 1024);
+    for (int k = wave; k < B1_BYTES / 1024; k += 4) glds16((const char*)p.b1 + k * 1024, lane16, smem + B1_OFF + k * 1024);
     dma_w1(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FF_DSR(fV[0], w1a[0][0], 0);
+    FF_DSR(fG[0], w1a[0][0], 4096);
+    FF_DSR(fV[1], w1a[0][1], 0);
+    FF_DSR(fG[1], w1a[0][1], 4096);
+    {   // the bias of chunk 0
+        FF_DSR(bvq[0], b1a, 0);   FF_DSR(bvq[1], b1a, 16);
+        FF_DSR(bvq[2], b1a, 64);  FF_DSR(bvq[3], b1a, 80);
+        FF_DSR(bgq[0], b1a, 128); FF_DSR(bgq[1], b1a, 144);
+        FF_DSR(bgq[2], b1a, 192); FF_DSR(bgq[3], b1a, 208);
+        FF_WAIT(0);
+        asm volatile("" : "+v"(bvq[0]), "+v"(bvq[1]), "+v"(bvq[2]), "+v"(bvq[3]), "+v"(bgq[0]), "+v"(bgq[1]), "+v"(bgq[2]), "+v"(bgq[3]),
+                     "+v"(fV[0]), "+v"(fG[0]), "+v"(fV[1]), "+v"(fG[1]));
+    }
 
     const int ntl = (ntiles - (int)blockIdx.x + nb - 1) / nb;
     for (int ti = 0; ti < ntl; ++ti) {
@@ -405,13 +413,15 @@ __global__ __launch_bounds__(256, 1) void ffn32_kernel(const Ffn32Args p) {
         for (int ob = 0; ob < 10; ++ob) Y[ob] = zero;
 
         const bool more = ti + 1 < ntl;
-        iteration(P0{}, P1{}, P0{}, 0, 1);
+        // iteration i: phase 1 of chunk i, GEGLU and phase 2 of chunk i - 1.  W1 chunk i + 1 is fetched during S1 of iteration i;
+        // unit tile t of W2 (chunks 2 t, 2 t + 1) during S1 of iteration 2 t + 1, where its first reader runs.
+        iteration(P0{}, P1{}, P0{}, P0{}, P1{}, 0, 1, -1, true);
         for (int i = 1; i + 1 < NCH; i += 2) {
-            iteration(P1{}, P1{}, P1{}, i, i + 1);
-            iteration(P0{}, P1{}, P1{}, i + 1, i + 2);
+            iteration(P1{}, P1{}, P1{}, P1{}, P0{}, i, i + 1, (i - 1) >> 1, true);
+            iteration(P0{}, P1{}, P1{}, P1{}, P1{}, i + 1, i + 2, -1, true);
         }
-        iteration(P1{}, P1{}, P1{}, NCH - 1, -1);
-        iteration(P0{}, P0{}, P1{}, NCH, more ? 0 : -1);      // (chunk 0 of the next tile goes to slot 0, last read by phase 1 of chunk 38)
+        iteration(P1{}, P1{}, P1{}, P1{}, P0{}, NCH - 1, -1, (NCH - 2) >> 1, false);
+        iteration(P0{}, P0{}, P1{}, P1{}, P0{}, NCH, more ? 0 : -1, -1, more);
 
         // ---- epilogue: lane (token, hi) holds channels 32 ob + 8 g + 4 hi + (0..3) in registers 4 g .. 4 g + 3; a swap of the even /
         // odd groups between the two lanes of a token gives the lower lane channels 16 jj .. + 7, the upper 16 jj + 8 .. + 15

@@ -199,6 +199,10 @@ class UNetHIP:
         # 16-bit x, so there the norm stays the f32in LayerNorm pass)
         self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not (self.res32 and os.environ.get("WIW_FF_UNFUSED_RES32"))
         self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN") and not self.res32
+        # round 5: the 32x32x16-MFMA form of the fused FeedForward (csrc/ffn32.hip) — correct and bit-repeatable, but NOT faster
+        # than ffn.hip at M = 258 048 (805 vs 804 us: both sit on the same serial sum of MFMA + GEGLU + weight DMA + LDS time,
+        # profiles/r13b_*): opt-in A/B knob, ffn.hip stays the served kernel
+        self.ffn32 = self.ffn_fused and bool(os.environ.get("WIW_FFN32"))
         self._prepare(state_dict)
 
     # ------------------------------------------------------------------------------------------
@@ -295,10 +299,14 @@ class UNetHIP:
                 # goes into W1 and beta into b1 (the kernel normalises the raw rows in registers)
                 w1, b1, _ = pack_geglu(w0, b0, FFN_CHUNK)
                 w[p + ".ffn.w1"], w[p + ".ffn.b1"] = TiledW(w1.to(bf).contiguous()), b1.contiguous()
+                if self.ffn32:
+                    w[p + ".ffn32"] = pack_ffn32(w0, b0, self._t(sd, p + ".net.2.weight"), bf)
                 if ln is not None and self.ffn_ln:
                     gamma, beta = self._t(sd, ln + ".weight"), self._t(sd, ln + ".bias")
                     w1, b1, _ = pack_geglu(w0 * gamma[None, :], w0 @ beta + b0, FFN_CHUNK)
                     w[p + ".ffn.w1ln"], w[p + ".ffn.b1ln"] = TiledW(w1.to(bf).contiguous()), b1.contiguous()
+                    if self.ffn32:
+                        w[p + ".ffn32ln"] = pack_ffn32(w0 * gamma[None, :], w0 @ beta + b0, self._t(sd, p + ".net.2.weight"), bf)
 
         def transformer(p):
             norm(p + ".norm"); lin(p + ".proj_in"); lin(p + ".proj_out")
@@ -440,6 +448,10 @@ class UNetHIP:
             kw = {k: v for k, v in epi_kw.items() if k in ("rowvec", "rowvec_ld", "rows_per_vec", "res1", "ldr1", "beta1",
                                                            "res2", "ldr2", "beta2", "alpha")}
             assert len(kw) == len(epi_kw), f"unsupported FeedForward epilogue arguments: {set(epi_kw) - set(kw)}"
+            if (p + ".ffn32") in self.w:      # opt-in (WIW_FFN32=1): the 32x32x16 form
+                W1s, b1s, W2s = self.w[p + (".ffn32ln" if ln else ".ffn32")]
+                return self.hip.ffn32_geglu(ln_input if ln else a, W1s, b1s, W2s, self.w[p + ".net.2.bias"], out, M, ln=ln,
+                                            ln_eps=1e-5, **kw)
             return self.hip.ffn_geglu(ln_input if ln else a, self.w[p + (".ffn.w1ln" if ln else ".ffn.w1")],
                                       self.w[p + (".ffn.b1ln" if ln else ".ffn.b1")], self.w[p + ".net.2.weight"],
                                       self.w[p + ".net.2.bias"], out, M, ln=ln, ln_eps=1e-5, **kw)
