@@ -94,6 +94,52 @@ void sweep_t1(const char* name) {
            run_t1<M32, KIND, 5>(), run_t1<M32, KIND, 6>(), run_t1<M32, KIND, 8>(), run_t1<M32, KIND, 10>());
 }
 
+// ---- T4 (round 5, after ffn32): as T1 with the MFMAs on NACC accumulators in turn — dependency distance NACC.  csrc/ffn32.hip runs
+// its up-projection on TWO accumulators (V, G) and measured MFMA, VALU, DMA and LDS time adding up serially.
+template <int NACC, int KIND, int N>
+__global__ __launch_bounds__(256) void t4(float* out, long long* cyc, float seed) {
+    s8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(threadIdx.x + i); b[i] = (short)(threadIdx.x * 3 + i); }
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed + threadIdx.x * 1e-3f + i;
+    f16v acc2[4];
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < 64; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            mfma32(acc2[m % NACC], a, b);
+#pragma unroll
+            for (int f = 0; f < N; ++f) filler<KIND>(x, seed, m * N + f, m * N + f);
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float res = 0.f;
+    for (int i = 0; i < 8; ++i) res += x[i];
+    for (int i = 0; i < 4; ++i) res += acc2[i][0] + acc2[i][15];
+    out[blockIdx.x * 256 + threadIdx.x] = res;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int NACC, int KIND, int N>
+double run_t4() {
+    float* out;
+    long long* cyc;
+    hipMalloc(&out, 256 * 256 * 4);
+    hipMalloc(&cyc, 64);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((t4<NACC, KIND, N>), dim3(256), dim3(256), 0, 0, out, cyc, 1.0001f);
+    long long h = 0;
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+    hipFree(out);
+    hipFree(cyc);
+    return (double)h / 256.0;
+}
+template <int NACC, int KIND>
+void sweep_t4(const char* name) {
+    printf("T4 %-44s cycles per MFMA at N fillers/MFMA  N=0: %5.1f  2: %5.1f  4: %5.1f  6: %5.1f  8: %5.1f\n", name, run_t4<NACC, KIND, 0>(),
+           run_t4<NACC, KIND, 2>(), run_t4<NACC, KIND, 4>(), run_t4<NACC, KIND, 6>(), run_t4<NACC, KIND, 8>());
+}
+
 // ---- T2: role A (waves 0..3) MFMA stream, role B (waves 4..7) v_fma stream, priorities pa / pb
 template <bool M32>
 __global__ __launch_bounds__(512) void t2(float* out, long long* cyc, float seed, int run_a, int run_b, int pa, int pb) {
@@ -256,6 +302,10 @@ int main() {
     sweep_t1<true, 1>("32x32x16 + mix(fma,exp,add,cvt)");
     sweep_t1<false, 0>("16x16x32 + v_fma_f32");
     sweep_t1<false, 1>("16x16x32 + mix(fma,exp,add,cvt)");
+    sweep_t4<1, 0>("32x32x16 on ONE accumulator + v_fma_f32");
+    sweep_t4<2, 0>("32x32x16 on TWO accumulators + v_fma_f32");
+    sweep_t4<2, 1>("32x32x16 on TWO accumulators + mix");
+    sweep_t4<4, 1>("32x32x16 on FOUR accumulators + mix");
     run_t2<false>("A = 16x16x32", 0, 0);
     run_t2<false>("A = 16x16x32", 0, 3);
     run_t2<false>("A = 16x16x32", 3, 0);
