@@ -1,9 +1,11 @@
 #!/bin/bash
+# Per-call GPU job: `gpurun -- 'bash tools/gpu_job.sh TAG'`.  This file is edited for every experiment (its history is in
+# git); the committed form is the round-end check: full GPU suite (-rP: the measured parity values of every passing test),
+# smoke, default bench line -> gpurun_out/TAG/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-echo "# ffn32_kernel (second schedule) ablation builds (-DFF_ABLATE=bits: 1 no GEGLU VALU, 2 no weight DMA in the loop, 4 no LDS fragment reads, 8 no barriers); timing only" > $O/${TAG}_ffn32_ablation.txt
-for v in world-in-world_amd/libwiwsvd.so tools/ablate/libwiw_ffab1.so tools/ablate/libwiw_ffab2.so tools/ablate/libwiw_ffab4.so tools/ablate/libwiw_ffab8.so tools/ablate/libwiw_ffab3.so; do
-  echo "== $v" | tee -a $O/${TAG}_ffn32_ablation.txt
-  WIW_LIB=$v MS=258048 timeout 300 python tools/ffn32_probe.py 2>&1 | grep "ffn ffn32" | tee -a $O/${TAG}_ffn32_ablation.txt
-done
+timeout 2400 python -m pytest tests -q -m gpu -rP > $O/${TAG}_gpu_suite_full.log 2>&1
+grep -n "passed\|failed\|rror" $O/${TAG}_gpu_suite_full.log | tail -6
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo "== bench"; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json; cut -c1-260 $O/${TAG}_bench.json

@@ -1,7 +1,7 @@
 # rocprofv3 kernel-stats (2-step) + PMC (1-step, three separate passes: never combined with tracing domains other than
 # kernel-trace) of bench.py, the default bench line with the per-shape dump, and the B = 8 / end-to-end line -> gpurun_out/TAG/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r14}
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python bench.py --num-inference-steps 2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-graph --no-calibrate > $O/ks.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_ks -name "*results.db" | head -1) $O/${TAG}_kernel_stats_2step.csv
