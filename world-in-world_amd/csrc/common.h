@@ -56,10 +56,23 @@ WIW_DEV uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); 
 WIW_DEV float silu_f(float x) {   // x * sigmoid(x) on the raw v_exp_f32 / v_rcp_f32 (1 ulp each; output is bf16)
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
-// exact-erf GELU (activations.py:109 `F.gelu`), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, i.e.
-// fp32-roundoff class) instead of libm erff's ~40 instructions — the GEGLU epilogue evaluates
-// 20480 of these per 256x160 block tile and VALU issue time there is NOT hidden behind MFMAs.
-WIW_DEV float gelu_erf_f(float x) {
+// erf-GELU (activations.py:109 `F.gelu`, approximate='none'): x * Phi(x).
+// Round 5: Phi(x) = sigmoid(x * P(min(|x|, 6))) with P of degree 4 fitted (minimax on the absolute error of
+// x * Phi(x) over the whole line, /tmp-free recipe in oracle/gelu_fit.py) — |error| <= 5.2e-6 evaluated in fp32 with the raw
+// v_exp_f32 / v_rcp_f32, i.e. 1/50 of half an fp16 ulp at |h| = 1 and 1/400 of bf16's; 10 VALU instructions instead of the
+// 14 of Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), which stays as gelu_erf_as_f: the fine-tuning kernels (train.hip) keep
+// it, and -DWIW_GELU_AS7126=1 builds every epilogue with it (the A/B switch).  The GEGLU epilogues evaluate 20480 of these
+// per 256x160 block tile and their VALU issue time is NOT hidden behind MFMAs.  The coefficients carry -log2(e).
+#ifndef WIW_GELU_AS7126
+#define WIW_GELU_AS7126 0
+#endif
+#define WIW_GELU_C0 (-2.3031814098358154f)
+#define WIW_GELU_C1 (0.0026162799913436174f)
+#define WIW_GELU_C2 (-0.1058432012796402f)
+#define WIW_GELU_C3 (-0.0018446178874000907f)
+#define WIW_GELU_C4 (0.0014851129380986094f)
+#define WIW_GELU_CLAMP 6.0f
+WIW_DEV float gelu_erf_as_f(float x) {
     // 14 VALU instructions: v_rcp_f32 / v_exp_f32 raw (1 ulp is far below the bf16 output rounding),
     // 0.5*x*(1 + sign(x)*erf|x|) rewritten as 0.5*(x + |x|*erf|x|)
     const float ax = fabsf(x);
@@ -74,8 +87,20 @@ WIW_DEV float gelu_erf_f(float x) {
     const float erf_abs = __builtin_fmaf(-poly * t, e, 1.0f);
     return 0.5f * __builtin_fmaf(ax, erf_abs, x);
 }
+WIW_DEV float gelu_erf_f(float x) {
+#if WIW_GELU_AS7126
+    return gelu_erf_as_f(x);
+#else
+    const float a = __builtin_fminf(fabsf(x), WIW_GELU_CLAMP);     // beyond 6: x * sigmoid(3.3 x) is x or 0 to fp32 roundoff
+    float p = __builtin_fmaf(WIW_GELU_C4, a, WIW_GELU_C3);
+    p = __builtin_fmaf(p, a, WIW_GELU_C2);
+    p = __builtin_fmaf(p, a, WIW_GELU_C1);
+    p = __builtin_fmaf(p, a, WIW_GELU_C0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));     // exp2 -> inf for x << 0: rcp(inf) = 0
+#endif
+}
 
-// gelu_erf_f on NP PACKED pairs at once, breadth first, the same arithmetic bit for bit.  One wave issues at most one VALU
+// gelu_erf_f on NP PACKED pairs at once, breadth first, the same arithmetic bit for bit (both forms).  One wave issues at most one VALU
 // instruction per ~5.4 cycles (8.5 when it depends on the previous one) packed or not (tools/ubench/valu_rate.hip), so the
 // cost of a GELU block is its instruction count: v_pk_* halves it and independent work per stage removes the dependency
 // stalls.  wiw_regp is an empty asm statement that reads and writes every pair of a stage — without it instruction
@@ -93,6 +118,43 @@ WIW_DEV void wiw_regp(wiw_f32x2 (&a)[NP]) {
 }
 template <int NP>
 WIW_DEV void gelu_erf_pk(wiw_f32x2 (&x)[NP]) {
+#if !WIW_GELU_AS7126
+    wiw_f32x2 a[NP], p[NP];
+    const auto fma2s = [](wiw_f32x2 a_, wiw_f32x2 b_, wiw_f32x2 c_) { return __builtin_elementwise_fma(a_, b_, c_); };
+    const auto bcs = [](float c) { return wiw_f32x2{c, c}; };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        a[i] = wiw_f32x2{__builtin_fminf(fabsf(x[i].x), WIW_GELU_CLAMP), __builtin_fminf(fabsf(x[i].y), WIW_GELU_CLAMP)};
+        p[i] = fma2s(bcs(WIW_GELU_C4), a[i], bcs(WIW_GELU_C3));
+    }
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = fma2s(p[i], a[i], bcs(WIW_GELU_C2));
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = fma2s(p[i], a[i], bcs(WIW_GELU_C1));
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = fma2s(p[i], a[i], bcs(WIW_GELU_C0));
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = x[i] * p[i];
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = wiw_f32x2{__builtin_amdgcn_exp2f(p[i].x), __builtin_amdgcn_exp2f(p[i].y)};
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = p[i] + bcs(1.0f);
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = wiw_f32x2{__builtin_amdgcn_rcpf(p[i].x), __builtin_amdgcn_rcpf(p[i].y)};
+    wiw_regp(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) x[i] = x[i] * p[i];
+    wiw_regp(x);
+    return;
+#endif
+
     wiw_f32x2 ax[NP], z[NP], t[NP], e[NP], poly[NP];
     const auto fma2 = [](wiw_f32x2 a, wiw_f32x2 b, wiw_f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
     const auto bc = [](float c) { return wiw_f32x2{c, c}; };

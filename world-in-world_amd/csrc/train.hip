@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint16_t* __restri
         unpack8(*(const uint4*)(dH + r * Ch + c), dh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float ge = gelu_erf_f(g[e]);                                 // g * Phi(g)
+            const float ge = gelu_erf_as_f(g[e]);                                 // g * Phi(g)
             const float phi = 0.3989422804014327f * __expf(-0.5f * g[e] * g[e]);
             const float Phi = fabsf(g[e]) > 1e-6f ? ge / g[e] : 0.5f;
             dv[e] = dh[e] * ge;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint16_t* __restri
         unpack8(*(const uint4*)(P + r * 2 * Ch + c), v);
         unpack8(*(const uint4*)(P + r * 2 * Ch + Ch + c), g);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_as_f(g[e]);
         *(uint4*)(Hh + r * Ch + c) = pack8(v);
     }
 }
