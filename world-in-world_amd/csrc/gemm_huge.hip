@@ -30,6 +30,20 @@
 #ifndef WIW_ABLATE
 #define WIW_ABLATE 0
 #endif
+#ifndef WIW_HUGE_PIPE
+#define WIW_HUGE_PIPE 1   // 1: the free-running K loop of round 5 for every instantiation without a halo-staged A operand (below: PIPE)
+#endif
+#ifndef WIW_PIPE_DMA
+#define WIW_PIPE_DMA 0    // PIPE: when the K tiles are fetched (see pipe_step): 0 = K tile kt + 1 during the first k-step of tile kt;
+                          // 1 = K tile kt + 2 behind tile kt's barrier, its last two parts in the next tile; 2 = all five parts behind the barrier (measured: 0 is
+                          // 3-7 % faster than the eight-slot loop, 1 and 2 no faster than it — a burst of DMA issue right behind the barrier
+                          // is the worst place for it, profiles/r16f_pipe_ab.txt)
+#endif
+#if WIW_F16
+#define WIW_MFMA_ASM "v_mfma_f32_16x16x32_f16"
+#else
+#define WIW_MFMA_ASM "v_mfma_f32_16x16x32_bf16"
+#endif
 
 #include <mutex>
 #include <type_traits>
@@ -119,6 +133,16 @@ template <int MODE, bool GE, bool SK, int HALO_ = 0, bool F32E = false, bool A1 
 __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, const int stagger) {
     static_assert(!F32E || (!GE && !SK), "the fp32-stream epilogue: plain launches only");
     constexpr bool HALO = HALO_ != 0, HSEG = HALO_ == 2;
+    // PIPE (round 5): the K loop without slots.  tools/ubench/mfma_dma.hip: a wave that interleaves its own ds_read_b128 with
+    // its own MFMAs loses nothing (8 waves per CU, 14 fragment reads per 40 MFMAs: matrix pipe 0.94-1.00 busy), one s_barrier
+    // per K tile costs 2-3 %, and the 9 LDS-DMA pieces per wave and K tile cost their issue time (64 cycles each) wherever
+    // they are put — 0.80 busy for the whole loop against the 0.58-0.60 of the eight-slot schedule above, whose read slots
+    // (9 / 5 KiB per wave) and seven pacing barriers per K tile are what the slots cost.  Every wave runs the same stream:
+    // per 32-deep k-step  for j in 0..9 { wait W[j]; 4 MFMA (A[0..3] x W[j]); read W[j + 3] }  with the W fragments in a ring
+    // of four and each A fragment of the next k-step read right behind its last MFMA; ONE barrier per K tile (iteration 7 of its
+    // second k-step: every wave has issued its last read of the tile, every wave's share of the next tile has landed), the
+    // DMA of tile kt + 2 may start right behind it.
+    constexpr bool PIPE = WIW_HUGE_PIPE != 0 && !HALO;
     static_assert(!HALO || ((MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_UP) && !GE && !SK) , "the halo-staged A operand is a plain 3x3 convolution");
     static_assert(!HSEG || MODE == WIW_A_CONV3X3, "the shortcut segment belongs to the stride-1 convolution");
     // UPH: nearest x2 upsample + 3x3 (WIW_A_CONV3X3_UP).  The staged image is the LOW-resolution input: tap (dy, dx) of output
@@ -540,6 +564,134 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
         //     barrier 8kt-1, i.e. finished slot 8(kt-1)+6 — the last read of that stage;
         //   * tile kt+1 is first read in the leading group's slot 8(kt+1) = after the lagging group's barrier 8kt+7,
         //     so every wave confirms its DMA share before its local barrier 8kt+7 (end of slot 6).
+        if constexpr (PIPE) {
+            // ---- the free-running K loop (see PIPE above).  Fragment registers: A of the running / the next k-step (pa[kk & 1]),
+            // W in a ring of four (fragment w of k-step kk lives in slot (2 kk + w) & 3: 20 fragments per K tile, so the phase
+            // repeats every tile); reads run three fragments ahead of the MFMAs.  Every ds_read and every MFMA is a volatile asm
+            // statement: the order below IS the instruction order, and the counted waits say which reads may still be in flight.
+#define HP_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define HP_MMA(c, w_, a_) asm volatile(WIW_MFMA_ASM " %0, %1, %2, %0" : "+v"(c) : "v"(w_), "v"(a_))
+#define HP_WAIT(n, r) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(n))
+            // The MFMAs below are asm statements: hipcc does not pad hazards for them.  The only VALU writes they can meet are the
+            // zeros of the accumulators, which the compiler materialises as late as it can — found as ONE stale register of ONE
+            // accumulator (a v_mov_b64 of zeros directly in front of its first MFMA, profiles/r16_pipe_kloop.txt).  These two
+            // statements take all 160 registers as operands: the zeros exist before them, the s_nop is the padding.
+#define HP_A10(m) "+v"(acc[m][0]), "+v"(acc[m][1]), "+v"(acc[m][2]), "+v"(acc[m][3]), "+v"(acc[m][4]), "+v"(acc[m][5]), "+v"(acc[m][6]), "+v"(acc[m][7]), "+v"(acc[m][8]), "+v"(acc[m][9])
+            asm volatile("s_nop 7" : HP_A10(0), HP_A10(1));
+            asm volatile("s_nop 7" : HP_A10(2), HP_A10(3));
+#undef HP_A10
+            slot_barrier();        // K tile 0 (confirmed above by every wave) is visible; every wave has left the previous epilogue's staging area
+            bf16x8 pa[4], pb[4];
+            unsigned ra[2], rb[2];     // this lane's fragment addresses in the stage of the running tile, k-step 0 / 1
+            int nd;                    // byte distance to the other stage
+            {
+                const unsigned ro0 = (unsigned)(frow * 128 + ((fq ^ (lane & 7)) << 4)), ro1 = ro0 ^ 64u;
+                const unsigned sa = (unsigned)(uintptr_t)(smem + st_c * HSTAGE) + (unsigned)(wm * 8192);
+                const unsigned sb = (unsigned)(uintptr_t)(smem + st_c * WSTAGE + WOFF) + (unsigned)(wn * 20480);
+                ra[0] = sa + ro0; ra[1] = sa + ro1; rb[0] = sb + ro0; rb[1] = sb + ro1;
+                nd = st_c ? -HSTAGE : HSTAGE;
+            }
+            // prologue, in the order the steady state leaves its reads: W[0] W[1] A[0..3] W[2]
+            HP_DSR(pb[0], rb[0], 0); HP_DSR(pb[1], rb[0], 2048);
+            HP_DSR(pa[0], ra[0], 0); HP_DSR(pa[1], ra[0], 2048); HP_DSR(pa[2], ra[0], 4096); HP_DSR(pa[3], ra[0], 6144);
+            HP_DSR(pb[2], rb[0], 4096);
+            // one k-step, KK its parity.  Program order of the reads:  iteration j < 7: W[j + 3];  iteration 7: W'[0] (behind the
+            // tile's barrier when the next k-step is the next tile's);  iterations 8 and 9, merged (4 x { MFMA(8, mi); MFMA(9, mi);
+            // A'[mi] }): W'[1] behind the first MFMA, W'[2] at the end — ONE set of A registers, each reloaded right behind its last
+            // two MFMAs.  The last K tile of an output tile runs the same code (ONE copy of the loop body: with a second flavour for
+            // it hipcc kept the accumulators of one flavour in scratch): its reads ahead fetch stale bytes of the other stage that
+            // nothing uses, its barrier is one barrier more.
+            // DMA: K tile kt + 2 goes into the stage of tile kt right behind tile kt's barrier (parts in iterations 7, 8/9 of the
+            // second k-step and 0, 1 of the next tile's first: a whole K tile of latency cover); K tile 1 of an output tile in the
+            // first k-step of tile 0 (the previous epilogue fetched K tile 0 only: the other stage was its staging area)
+            auto pipe_step = [&](auto kk_tag, const bool dma1, const bool dma2, const bool dma2_tail, const int si) {
+                constexpr int KK = decltype(kk_tag)::value;
+                const unsigned ra_n = KK == 0 ? ra[1] : ra[0] + (unsigned)nd;      // the next k-step's fragment addresses
+                const unsigned rb_n = KK == 0 ? rb[1] : rb[0] + (unsigned)nd;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bf16x8& w_now = pb[(2 * KK + j) & 3];
+                    // in flight behind what iteration j needs — j = 0: A[mi] is followed by A[mi + 1 ..], W[2] (and W[3], read
+                    // behind the first MFMA); j >= 1: the two W fragments read since
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w_now), "+v"(pa[0]));
+                    else HP_WAIT(2, w_now);
+                    if (KK == 1 && j == 7) {
+                        // the tile's barrier: my share of K tile kt + 1 has landed, my last read of this tile is done
+                        // (lgkmcnt(0) inside slot_barrier) — behind it every wave may read the other stage and DMA into this one
+                        wait_vmcnt<0>();
+                        slot_barrier();
+                    }
+                    HP_MMA(acc[0][j], w_now, pa[0]);
+                    {      // W[j + 3], or W'[0] of the next k-step
+                        bf16x8& w_new = pb[(2 * KK + j + 3) & 3];
+                        if (j < 7) HP_DSR(w_new, rb[KK], (j + 3) * 2048);
+                        else HP_DSR(w_new, rb_n, 0);
+                    }
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pa[1]));
+                    HP_MMA(acc[1][j], w_now, pa[1]);
+                    if (KK == 0 && (j & 1) == 0 && dma1) {      // tile 0: the 9 DMA instructions of K tile 1, in five parts (the fifth below)
+                        if (j == 0) issue_part(si, IC<0>{}, IC<0>{});
+                        else if (j == 2) issue_part(si, IC<1>{}, IC<0>{});
+                        else if (j == 4) issue_part(si, IC<2>{}, IC<0>{});
+                        else issue_part(si, IC<3>{}, IC<0>{});
+                    }
+                    if (KK == 0 && dma2_tail) {                 // the last two parts of the K tile whose fetch began behind the previous tile's barrier
+                        if (j == 0) issue_part(si, IC<3>{}, IC<0>{});
+                        else if (j == 1) issue_part(si, IC<4>{}, IC<0>{});
+                    }
+                    if (KK == 1 && j == 7 && dma2) issue_part(si, IC<0>{}, IC<0>{});
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(pa[2]));
+                    HP_MMA(acc[2][j], w_now, pa[2]);
+                    if (j == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(pa[3]));
+                    HP_MMA(acc[3][j], w_now, pa[3]);
+                }
+                {   // iterations 8 and 9
+                    bf16x8& w8 = pb[(2 * KK + 8) & 3];
+                    bf16x8& w9 = pb[(2 * KK + 9) & 3];
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w8), "+v"(w9));      // W'[0] may be in flight
+                    HP_MMA(acc[0][8], w8, pa[0]);
+                    HP_DSR(pb[(2 * KK + 11) & 3], rb_n, 2048);                       // W'[1] into W[7]'s registers
+                    HP_MMA(acc[0][9], w9, pa[0]);
+                    HP_DSR(pa[0], ra_n, 0);
+                    if (KK == 0 && dma1) issue_part(si, IC<4>{}, IC<0>{});
+                    if (KK == 1 && dma2) issue_part(si, IC<1>{}, IC<0>{});
+                    HP_MMA(acc[1][8], w8, pa[1]);
+                    HP_MMA(acc[1][9], w9, pa[1]);
+                    HP_DSR(pa[1], ra_n, 2048);
+                    HP_MMA(acc[2][8], w8, pa[2]);
+                    HP_MMA(acc[2][9], w9, pa[2]);
+                    HP_DSR(pa[2], ra_n, 4096);
+                    if (KK == 1 && dma2) issue_part(si, IC<2>{}, IC<0>{});
+                    HP_MMA(acc[3][8], w8, pa[3]);
+                    if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<3>{}, IC<0>{});
+                    HP_MMA(acc[3][9], w9, pa[3]);
+                    if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<4>{}, IC<0>{});
+                    HP_DSR(pa[3], ra_n, 6144);
+                    HP_DSR(pb[(2 * KK + 12) & 3], rb_n, 4096);                       // W'[2] into W[8]'s registers
+                }
+            };
+            for (int kt = 0; kt < nk; ++kt) {
+                // step 0 of tile kt: K tile 1 (kt = 0), or the tail of K tile kt + 1, into the other stage; step 1: the head of
+                // K tile kt + 2 into THIS stage behind the barrier
+#if WIW_PIPE_DMA == 0
+                pipe_step(IC<0>{}, kt + 1 < nk, false, false, st_c ^ 1);
+                pipe_step(IC<1>{}, false, false, false, st_c);
+#elif WIW_PIPE_DMA == 1
+                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, kt >= 1 && kt + 1 < nk, st_c ^ 1);
+                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c);
+#else
+                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, false, st_c ^ 1);
+                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c);
+#endif
+                ra[0] += (unsigned)nd; ra[1] += (unsigned)nd; rb[0] += (unsigned)nd; rb[1] += (unsigned)nd;
+                nd = -nd;
+                st_c ^= 1;
+            }
+            slot_barrier();        // every wave has finished reading the ring: the epilogue may stage into it
+#undef HP_DSR
+#undef HP_MMA
+#undef HP_WAIT
+        } else {
         if (lag) slot_barrier();
         // one K tile.  cseg / fseg (HALO_ == 2 only): this tile / the tile fetched during it belongs to the shortcut segment —
         // compile-time, and the three kinds of tile run in three loops below: with run-time tests in ONE loop hipcc peeled
@@ -606,6 +758,7 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             for (++kt; kt < nk; ++kt) k_tile(kt, IC<1>{}, IC<1>{});
         }
         if (!lag) slot_barrier();   // leading group: the lagging group has finished reading the ring
+        }   // !PIPE
 
         // ---- epilogue, part 1: bias + first pass operands, then the next tile's first K tile, then the 4 passes
         constexpr int ITEMS_P = 6, ITEMS_G = 3;
