@@ -31,7 +31,7 @@
 #define WIW_ABLATE 0
 #endif
 #ifndef WIW_HUGE_PIPE
-#define WIW_HUGE_PIPE 1   // 1: the free-running K loop of round 5 for every instantiation without a halo-staged A operand (below: PIPE)
+#define WIW_HUGE_PIPE 2   // 1: the free-running K loop of round 5 for every instantiation without a halo-staged A operand (below: PIPE); 2: also the halo-staged 3x3 convolutions
 #endif
 #ifndef WIW_PIPE_DMA
 #define WIW_PIPE_DMA 0    // PIPE: when the K tiles are fetched (see pipe_step): 0 = K tile kt + 1 during the first k-step of tile kt;
@@ -142,7 +142,9 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
     // of four and each A fragment of the next k-step read right behind its last MFMA; ONE barrier per K tile (iteration 7 of its
     // second k-step: every wave has issued its last read of the tile, every wave's share of the next tile has landed), the
     // DMA of tile kt + 2 may start right behind it.
-    constexpr bool PIPE = WIW_HUGE_PIPE != 0 && !HALO;
+    // HALO (round 5, second step): the same loop with the A fragments read from the halo buffers at the tap's offset; the
+    // instantiation with the fused shortcut segment (HALO_ == 2: three kinds of K tile) keeps the slots.
+    constexpr bool PIPE = WIW_HUGE_PIPE != 0 && HALO_ != 2 && (!HALO || WIW_HUGE_PIPE >= 2);
     static_assert(!HALO || ((MODE == WIW_A_CONV3X3 || MODE == WIW_A_CONV3X3_UP) && !GE && !SK) , "the halo-staged A operand is a plain 3x3 convolution");
     static_assert(!HSEG || MODE == WIW_A_CONV3X3, "the shortcut segment belongs to the stride-1 convolution");
     // UPH: nearest x2 upsample + 3x3 (WIW_A_CONV3X3_UP).  The staged image is the LOW-resolution input: tap (dy, dx) of output
@@ -582,18 +584,49 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 #undef HP_A10
             slot_barrier();        // K tile 0 (confirmed above by every wave) is visible; every wave has left the previous epilogue's staging area
             bf16x8 pa[4], pb[4];
-            unsigned ra[2], rb[2];     // this lane's fragment addresses in the stage of the running tile, k-step 0 / 1
+            unsigned ra[2], rb[2];     // this lane's fragment addresses in the stage of the running tile, k-step 0 / 1 (HALO: ra unused)
             int nd;                    // byte distance to the other stage
             {
                 const unsigned ro0 = (unsigned)(frow * 128 + ((fq ^ (lane & 7)) << 4)), ro1 = ro0 ^ 64u;
                 const unsigned sa = (unsigned)(uintptr_t)(smem + st_c * HSTAGE) + (unsigned)(wm * 8192);
                 const unsigned sb = (unsigned)(uintptr_t)(smem + st_c * WSTAGE + WOFF) + (unsigned)(wn * 20480);
                 ra[0] = sa + ro0; ra[1] = sa + ro1; rb[0] = sb + ro0; rb[1] = sb + ro1;
-                nd = st_c ? -HSTAGE : HSTAGE;
+                nd = st_c ? -WSTAGE : WSTAGE;
             }
+            // HALO: the A fragments of k-step s are tap s % 9 of 32-channel block s / 9, read from halo buffer (s / 9) & 1 at the
+            // tap's pixel offset (read_a_halo above).  (p_tap, p_blk) = the k-step whose fragments are read NEXT.
+            int p_tap = 0, p_blk = 0;
+            unsigned hS64[4] = {0u, 0u, 0u, 0u};
+            if constexpr (HALO && !UPH) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) hS64[mi] = (unsigned)(h_S[mi] * 64);
+            }
+            auto halo_a = [&]() -> unsigned {      // this lane's address of fragment mi = 0 of k-step (p_tap, p_blk); advances the cursor
+                const int dy = p_tap / 3 - 1, dx = p_tap - (p_tap / 3) * 3 - 1;
+                unsigned a;
+                if constexpr (UPH) {
+                    const int fx = (frow + dx) >> 1;
+                    const int lp = fx * 64 + ((fq ^ (((1 + fx) >> 1) & 3)) << 4);
+                    a = (unsigned)(uintptr_t)(halo0 + (p_blk & 1) * HALO_BUF) + (unsigned)(((((h_S[1] + dy) >> 1) + 1) * h_P + h_S[0]) * 64 + lp);
+                } else {
+                    const int lp = frow * 64 + ((fq ^ (((1 + dx + frow) >> 1) & 3)) << 4);
+                    a = (unsigned)(uintptr_t)(halo0 + (p_blk & 1) * HALO_BUF) + (unsigned)((dy * h_P + dx) * 64 + lp);
+                }
+                if (++p_tap == 9) { p_tap = 0; ++p_blk; }
+                return a;
+            };
             // prologue, in the order the steady state leaves its reads: W[0] W[1] A[0..3] W[2]
             HP_DSR(pb[0], rb[0], 0); HP_DSR(pb[1], rb[0], 2048);
-            HP_DSR(pa[0], ra[0], 0); HP_DSR(pa[1], ra[0], 2048); HP_DSR(pa[2], ra[0], 4096); HP_DSR(pa[3], ra[0], 6144);
+            if constexpr (!HALO) {
+                HP_DSR(pa[0], ra[0], 0); HP_DSR(pa[1], ra[0], 2048); HP_DSR(pa[2], ra[0], 4096); HP_DSR(pa[3], ra[0], 6144);
+            } else if constexpr (UPH) {
+                const unsigned a0 = halo_a();
+                HP_DSR(pa[0], a0, 0); HP_DSR(pa[1], a0, 512); HP_DSR(pa[2], a0, 1024); HP_DSR(pa[3], a0, 1536);
+            } else {
+                const unsigned a0 = halo_a();
+                const unsigned a00 = a0 + hS64[0], a01 = a0 + hS64[1], a02 = a0 + hS64[2], a03 = a0 + hS64[3];
+                HP_DSR(pa[0], a00, 0); HP_DSR(pa[1], a01, 0); HP_DSR(pa[2], a02, 0); HP_DSR(pa[3], a03, 0);
+            }
             HP_DSR(pb[2], rb[0], 4096);
             // one k-step, KK its parity.  Program order of the reads:  iteration j < 7: W[j + 3];  iteration 7: W'[0] (behind the
             // tile's barrier when the next k-step is the next tile's);  iterations 8 and 9, merged (4 x { MFMA(8, mi); MFMA(9, mi);
@@ -604,9 +637,9 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             // DMA: K tile kt + 2 goes into the stage of tile kt right behind tile kt's barrier (parts in iterations 7, 8/9 of the
             // second k-step and 0, 1 of the next tile's first: a whole K tile of latency cover); K tile 1 of an output tile in the
             // first k-step of tile 0 (the previous epilogue fetched K tile 0 only: the other stage was its staging area)
-            auto pipe_step = [&](auto kk_tag, const bool dma1, const bool dma2, const bool dma2_tail, const int si) {
+            auto pipe_step = [&](auto kk_tag, const bool dma1, const bool dma2, const bool dma2_tail, const int si, const bool hdo, const int m0t, const int y0t) {
                 constexpr int KK = decltype(kk_tag)::value;
-                const unsigned ra_n = KK == 0 ? ra[1] : ra[0] + (unsigned)nd;      // the next k-step's fragment addresses
+                const unsigned ra_n = HALO ? 0u : (KK == 0 ? ra[1] : ra[0] + (unsigned)nd);      // the next k-step's fragment addresses
                 const unsigned rb_n = KK == 0 ? rb[1] : rb[0] + (unsigned)nd;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -629,11 +662,23 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                     }
                     if (j == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pa[1]));
                     HP_MMA(acc[1][j], w_now, pa[1]);
-                    if (KK == 0 && (j & 1) == 0 && dma1) {      // tile 0: the 9 DMA instructions of K tile 1, in five parts (the fifth below)
+                    if (!HALO && KK == 0 && (j & 1) == 0 && dma1) {      // the 9 DMA instructions of K tile kt + 1, in five parts (the fifth below)
                         if (j == 0) issue_part(si, IC<0>{}, IC<0>{});
                         else if (j == 2) issue_part(si, IC<1>{}, IC<0>{});
                         else if (j == 4) issue_part(si, IC<2>{}, IC<0>{});
                         else issue_part(si, IC<3>{}, IC<0>{});
+                    }
+                    if constexpr (HALO) {      // 5 W instructions of K tile kt + 1 (2 | 2 | 1) and, when a halo block may be fetched, its <= 5
+                        if (KK == 0 && dma1) {
+                            if (j == 0) issue_part(si, IC<2>{}, IC<0>{});
+                            else if (j == 2) issue_part(si, IC<3>{}, IC<0>{});
+                            else if (j == 4) issue_part(si, IC<4>{}, IC<0>{});
+                        }
+                        if (KK == 0 && hdo) {
+                            if (j == 5) issue_halo(m0t, y0t, h_next, IC<0>{});
+                            else if (j == 6) issue_halo(m0t, y0t, h_next, IC<1>{});
+                            else if (j == 7) issue_halo(m0t, y0t, h_next, IC<2>{});
+                        }
                     }
                     if (KK == 0 && dma2_tail) {                 // the last two parts of the K tile whose fetch began behind the previous tile's barrier
                         if (j == 0) issue_part(si, IC<3>{}, IC<0>{});
@@ -649,40 +694,51 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                     bf16x8& w8 = pb[(2 * KK + 8) & 3];
                     bf16x8& w9 = pb[(2 * KK + 9) & 3];
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w8), "+v"(w9));      // W'[0] may be in flight
+                    unsigned an0 = ra_n, an1 = ra_n, an2 = ra_n, an3 = ra_n;      // HALO: the four fragment addresses of the next k-step
+                    if constexpr (HALO) {
+                        const unsigned a0 = halo_a();
+                        if constexpr (UPH) { an0 = an1 = an2 = an3 = a0; }
+                        else { an0 = a0 + hS64[0]; an1 = a0 + hS64[1]; an2 = a0 + hS64[2]; an3 = a0 + hS64[3]; }
+                    }
+                    constexpr int AO1 = HALO ? (UPH ? 512 : 0) : 2048, AO2 = 2 * AO1, AO3 = 3 * AO1;
                     HP_MMA(acc[0][8], w8, pa[0]);
                     HP_DSR(pb[(2 * KK + 11) & 3], rb_n, 2048);                       // W'[1] into W[7]'s registers
                     HP_MMA(acc[0][9], w9, pa[0]);
-                    HP_DSR(pa[0], ra_n, 0);
-                    if (KK == 0 && dma1) issue_part(si, IC<4>{}, IC<0>{});
+                    HP_DSR(pa[0], an0, 0);
+                    if (!HALO && KK == 0 && dma1) issue_part(si, IC<4>{}, IC<0>{});
+                    if (HALO && KK == 0 && hdo) issue_halo(m0t, y0t, h_next, IC<3>{});
                     if (KK == 1 && dma2) issue_part(si, IC<1>{}, IC<0>{});
                     HP_MMA(acc[1][8], w8, pa[1]);
                     HP_MMA(acc[1][9], w9, pa[1]);
-                    HP_DSR(pa[1], ra_n, 2048);
+                    HP_DSR(pa[1], an1, AO1);
                     HP_MMA(acc[2][8], w8, pa[2]);
                     HP_MMA(acc[2][9], w9, pa[2]);
-                    HP_DSR(pa[2], ra_n, 4096);
+                    HP_DSR(pa[2], an2, AO2);
+                    if (HALO && KK == 0 && hdo) issue_halo(m0t, y0t, h_next, IC<4>{});
                     if (KK == 1 && dma2) issue_part(si, IC<2>{}, IC<0>{});
                     HP_MMA(acc[3][8], w8, pa[3]);
                     if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<3>{}, IC<0>{});
                     HP_MMA(acc[3][9], w9, pa[3]);
                     if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<4>{}, IC<0>{});
-                    HP_DSR(pa[3], ra_n, 6144);
+                    HP_DSR(pa[3], an3, AO3);
                     HP_DSR(pb[(2 * KK + 12) & 3], rb_n, 4096);                       // W'[2] into W[8]'s registers
                 }
             };
             for (int kt = 0; kt < nk; ++kt) {
                 // step 0 of tile kt: K tile 1 (kt = 0), or the tail of K tile kt + 1, into the other stage; step 1: the head of
                 // K tile kt + 2 into THIS stage behind the barrier
+                const bool hdo = HALO && h_next < h_nblk && kt == h_tile;
 #if WIW_PIPE_DMA == 0
-                pipe_step(IC<0>{}, kt + 1 < nk, false, false, st_c ^ 1);
-                pipe_step(IC<1>{}, false, false, false, st_c);
+                pipe_step(IC<0>{}, kt + 1 < nk, false, false, st_c ^ 1, hdo, m0, y0);
+                pipe_step(IC<1>{}, false, false, false, st_c, false, m0, y0);
 #elif WIW_PIPE_DMA == 1
-                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, kt >= 1 && kt + 1 < nk, st_c ^ 1);
-                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c);
+                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, kt >= 1 && kt + 1 < nk, st_c ^ 1, hdo, m0, y0);
+                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c, false, m0, y0);
 #else
-                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, false, st_c ^ 1);
-                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c);
+                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, false, st_c ^ 1, hdo, m0, y0);
+                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c, false, m0, y0);
 #endif
+                if (HALO && hdo) { ++h_next; h_tile = (9 * h_next - 10) / 2 + 1; }
                 ra[0] += (unsigned)nd; ra[1] += (unsigned)nd; rb[0] += (unsigned)nd; rb[1] += (unsigned)nd;
                 nd = -nd;
                 st_c ^= 1;
