@@ -119,6 +119,52 @@ def cpu_baseline(sd_cpu, cfg, threads, device=None, dtype=None):
     return res
 
 
+class PowerSampler:
+    """Shader clock and package power of GPU 0 from rocm-smi (a few samples per second, a thread of this process) over the
+    timed region.  Why it is in the line: the denoising loop runs against the board's power management — every MFMA-heavy
+    kernel of this repo holds ~1.3 kW at 1.7-2.2 GHz of the 2.4 GHz the peak figures assume (profiles/r16k_power_by_kernel.txt)
+    — so frames/s on a box follows its clock.  None when rocm-smi is not there."""
+
+    def __init__(self):
+        self.samples, self._stop, self._th = [], False, None
+
+    @staticmethod
+    def read():
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True, timeout=10).stdout
+            r = [x for x in out.splitlines() if x.startswith("card")][0]
+            clocks = [int(x) for x in re.findall(r"\((\d+)Mhz\)", r)]
+            return max(clocks[2:4]), float(r.split(",")[-1])
+        except Exception:
+            return None
+
+    def start(self):
+        import threading
+
+        def loop():
+            while not self._stop:
+                smp = self.read()
+                if smp is None:
+                    return
+                self.samples.append(smp)
+
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=15)
+        sm = self.samples[1:] if len(self.samples) > 2 else self.samples      # the first call may predate the first launch
+        if not sm:
+            return None
+        return {"sclk_MHz_mean": round(sum(x[0] for x in sm) / len(sm)), "sclk_MHz_min": min(x[0] for x in sm),
+                "watts_mean": round(sum(x[1] for x in sm) / len(sm)), "watts_max": round(max(x[1] for x in sm)), "samples": len(sm),
+                "source": "rocm-smi --showclocks --showpower during the timed region (GPU 0); nominal peak clock 2400 MHz, board limit 1400 W"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +190,7 @@ def main():
                          "kernel statistics); `box` and `roofline.frac_of_box_peak` are then absent")
     ap.add_argument("--tiny", action="store_true", help="reduced-width model (plumbing check only; INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (clock, watts) during the timed region")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every UNet forward launch by launch (default: replay a captured hipGraph on the Euler steps "
@@ -267,11 +314,15 @@ def main():
     ev["on"] = not args.no_kernel_events
     den.host_launch = {"eager": [0.0, 0], "graph": [0.0, 0]}
     barrier()
+    pws = PowerSampler() if rank == 0 and not args.no_power else None
+    if pws is not None:
+        pws.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = rollout()
     barrier()
     dt = time.perf_counter() - t0
+    power = pws.stop() if pws is not None else None
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -302,6 +353,8 @@ def main():
             res["box"] = {"mfma_peak_measured": box["mfma_tflops"], "mfma_peak_unit": "TFLOP/s", "hbm_copy_GBps": box["copy_GBps"],
                           "cus": box["cus"], "what": "a ~50 ms launch of back-to-back MFMAs on register operands (8 waves per CU) and "
                           "a 1 GiB device copy (read + write bytes), measured on this box before the timed region"}
+        if power is not None:
+            res["power"] = power
         hl = den.host_launch
         res["host_launch"] = {
             "hip_graph": (not args.no_graph) and den.graph_error is None,

@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 14  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 15  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -48,7 +48,8 @@ extern "C" {
                              12: wiw_groupnorm_stats / _f32in take `counters`: the second reduction stage runs inside the
                                  statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream;
                              13: wiw_attn_spatial_ps_bf16 (32x32x16 spatial attention on a pre-scaled Q);
-                             14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling) */
+                             14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling)
+                                15: wiw_groupnorm_onepass / wiw_groupnorm_onepass_ok (one-pass GroupNorm of the inner levels) */
 
 int wiw_abi_version(void);
 
@@ -314,6 +315,16 @@ int wiw_groupnorm_stats_f32in(void* stream, const float* X1, int C1, const float
 int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, int C1, const float* X2, int C2, int64_t rows,
                                     int rows_per_unit, const float* stats, const float* gamma, const float* beta, float eps,
                                     int silu, void* out, void* raw16);
+
+/* ABI 15 (round 5): GroupNorm(32) (+SiLU) of the two inner levels in ONE pass — a block keeps 160 consecutive channels of
+ * one frame in registers (read once; exact two-pass statistics in fp32; normalise; store): the same operator as
+ * wiw_groupnorm_stats + wiw_groupnorm_apply_stats (dp/models/resnet.py:262-300 `norm1` / `norm2`, transformer_temporal.py:
+ * 250 `self.norm`), for rows_per_unit (= H * W of a frame) in {144, 576}, 40 or 80 channels per group, C1 and C2 multiples
+ * of 160, 16-bit tensors.  wiw_groupnorm_onepass_ok(C1, C2, rows, rows_per_unit) != 0 says a launch fits; anything else is
+ * refused (WIW_EINVAL), never re-routed.  Deterministic, no scratch buffers. */
+int wiw_groupnorm_onepass_ok(int C1, int C2, int64_t rows, int rows_per_unit);
+int wiw_groupnorm_onepass(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows, int rows_per_unit,
+                          const float* gamma, const float* beta, float eps, int silu, void* out);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim with an optional fused pre-add of a per-row-group vector:

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path, variant, code):
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported by {os.path.basename(path)}"
     lib.wiw_abi_version.restype = ctypes.c_int
     lib.wiw_dtype.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 14 and lib.wiw_dtype() == code
+    assert lib.wiw_abi_version() == 15 and lib.wiw_dtype() == code
 
 
 def test_gemm_args_struct_layout():
@@ -85,3 +85,17 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.wiw_ffn32_geglu(None, 16, 320, 16, 16, 16, None, None, 0, 1, None, 0, 0.0, None, 0, 0.0, 1.0, 16, 320, 128, 320, 1280,
                                0, 1e-5, 9) == -1
     assert b"3-bit mask" in lib.wiw_last_error()
+
+
+def test_groupnorm_onepass_geometry_rule_on_the_host(lib_path):
+    """ABI 15: wiw_groupnorm_onepass_ok is a host function — the shapes of the served network's two inner levels (18 x 32 and
+    9 x 16 latents, 1280 channels or a 1280 + 1280 concat) fit the one-pass kernel, every other GroupNorm of the network does not."""
+    lib = ctypes.CDLL(lib_path)
+    ok = lib.wiw_groupnorm_onepass_ok
+    ok.restype, ok.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int]
+    frames = 28
+    assert ok(1280, 0, frames * 576, 576) == 1 and ok(1280, 0, frames * 144, 144) == 1
+    assert ok(1280, 1280, frames * 576, 576) == 1 and ok(1280, 1280, frames * 144, 144) == 1
+    for c1, c2, hw in ((320, 0, 9216), (640, 0, 2304), (640, 320, 9216), (1280, 640, 576), (640, 0, 576), (1280, 0, 2304)):
+        assert ok(c1, c2, frames * hw, hw) == 0, (c1, c2, hw)
+    assert ok(1280, 0, 577, 576) == 0 and ok(1280, 0, 0, 576) == 0

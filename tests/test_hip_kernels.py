@@ -320,6 +320,42 @@ def test_groupnorm(hip, n, c1, c2, h, w, unit_frames):
         check(from_nhwc(out4, n, h, w), ref, what=f"groupnorm (4 entry points) C={c1}+{c2} silu={silu}")
 
 
+@pytest.mark.parametrize("n,c1,c2,h,w", [(6, 1280, 0, 18, 32), (6, 1280, 0, 9, 16), (4, 1280, 1280, 9, 16), (3, 1280, 1280, 18, 32)])
+def test_groupnorm_onepass(hip, n, c1, c2, h, w):
+    """ABI 15: GroupNorm(32) (+SiLU) of the two inner levels in ONE pass (a frame's 160-channel slab in registers).  Against
+    torch's fp32 group_norm, against the two-launch path (statistics + apply) on the same tensors, bit-identical over repeats;
+    the dispatcher takes it exactly where wiw_groupnorm_onepass_ok says so."""
+    C = c1 + c2
+    x = bf(rnd(n, C, h, w, seed=11) * 2 + rnd(1, C, 1, 1, seed=12) * 3)        # per-channel offsets: |mean| >> std in some groups
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    t = nhwc(x)
+    x1 = dev_bf(t[:, :c1])
+    x2 = dev_bf(t[:, c1:]) if c2 else None
+    rows = n * h * w
+    assert hip.lib.wiw_groupnorm_onepass_ok(c1, c2, rows, h * w) == 1
+    for silu in (True, False):
+        ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+        ref = F.silu(ref) if silu else ref
+        out = hip.groupnorm(x1, c1, x2, c2, rows, h * w, dev_f(gamma), dev_f(beta), 1e-5, silu)
+        check(from_nhwc(out, n, h, w), ref, what=f"one-pass groupnorm C={c1}+{c2} {h}x{w} silu={silu}")
+        again = hip.groupnorm(x1, c1, x2, c2, rows, h * w, dev_f(gamma), dev_f(beta), 1e-5, silu)
+        assert torch.equal(out, again)
+        hip.gn_two_kernels = True
+        try:
+            two = hip.groupnorm(x1, c1, x2, c2, rows, h * w, dev_f(gamma), dev_f(beta), 1e-5, silu)
+        finally:
+            hip.gn_two_kernels = False
+        d = (out.float() - two.float()).abs().max().item()
+        print(f"[gn one pass] C={c1}+{c2} {h}x{w} silu={silu}: max |one pass - two launches| = {d:.3e}")
+        assert d <= 0.05          # one 16-bit ulp at the largest magnitudes: the statistics differ in the last fp32 bits only
+    # shapes the kernel does not take: refused by the C entry point, routed to the two launches by the dispatcher
+    for (a, b, r, u) in ((320, 0, 6 * 576, 576), (1280, 640, 6 * 576, 576), (1280, 0, 6 * 2304, 2304), (640, 0, 576, 576)):
+        assert hip.lib.wiw_groupnorm_onepass_ok(a, b, r, u) == 0
+    bad = hip.lib.wiw_groupnorm_onepass(torch.cuda.current_stream().cuda_stream, x1.data_ptr(), 320, None, 0, rows, h * w,
+                                        dev_f(gamma).data_ptr(), dev_f(beta).data_ptr(), 1e-5, 0, x1.data_ptr())
+    assert bad != 0 and b"one-pass" in hip.lib.wiw_last_error()
+
+
 def test_groupnorm_is_deterministic(hip):
     """No atomics in the statistics: the same call gives the same BYTES every time (and so does the whole pipeline)."""
     n, C, h, w = 6, 320, 24, 32

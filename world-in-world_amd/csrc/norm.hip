@@ -416,6 +416,86 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// GroupNorm(32) (+SiLU) in ONE pass for the small levels (round 5): a (frame, group) unit of the two inner levels is 576 x 40
+// or 144 x 40 values — a block keeps 160 consecutive channels of ONE frame (4 groups of 40, or 2 of 80 on a 2560-channel
+// concat) in its registers: read once, exact two-pass mean / variance in fp32 (no cancellation: the data is resident),
+// normalise, SiLU, store.  The two-kernel path reads those tensors twice and at these sizes both of its launches are
+// latency-bound (41 MB: 17 + 14 us at 18 x 32, ~10 + 8 us at 9 x 16), and unlike the MFMA kernels the HBM-bound ones do not
+// pay the board's power management: what they save arrives.  240 threads = 12 rows x 20 chunks of 8 channels per
+// pass, PASSES = rows / 12 (48 or 12) loads per thread, all in flight before the first use.  Deterministic: fixed reduction
+// order through LDS, no atomics.  16-bit tensors only (the fp32 stream keeps the two-kernel path).
+// ---------------------------------------------------------------------------------------------
+constexpr int GN1_ROWS = 12, GN1_CHUNKS = 20, GN1_THREADS = GN1_ROWS * GN1_CHUNKS, GN1_CB = GN1_CHUNKS * 8;
+template <int PASSES>
+__global__ __launch_bounds__(GN1_THREADS) void gn_onepass_kernel(const uint16_t* __restrict__ X1, int C1, const uint16_t* __restrict__ X2, int C2,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 int silu, uint16_t* __restrict__ out) {
+    __shared__ float red[GN1_ROWS][GN1_CHUNKS];
+    __shared__ float colsum[GN1_CHUNKS];
+    const int tid = threadIdx.x, cv = tid % GN1_CHUNKS, rl = tid / GN1_CHUNKS;
+    const int C = C1 + C2, cpgv = (C / GROUPS) >> 3;          // chunks per group: 5 (C = 1280) or 10 (2560)
+    const int c0 = blockIdx.x * GN1_CB;                       // first channel of this block: inside ONE source (C1 % 160 == 0)
+    const int64_t row0 = (int64_t)blockIdx.y * (PASSES * GN1_ROWS);
+    const uint16_t* src;
+    int ld, coff;
+    if (c0 < C1) { src = X1; ld = C1; coff = c0; } else { src = X2; ld = C2; coff = c0 - C1; }
+    uint4 raw[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) raw[i] = *(const uint4*)(src + (row0 + i * GN1_ROWS + rl) * ld + coff + cv * 8);
+    const float4 g0 = *(const float4*)(gamma + c0 + cv * 8), g1 = *(const float4*)(gamma + c0 + cv * 8 + 4);
+    const float4 b0 = *(const float4*)(beta + c0 + cv * 8), b1 = *(const float4*)(beta + c0 + cv * 8 + 4);
+    const float inv_n = 1.0f / (float)(PASSES * GN1_ROWS * cpgv * 8);
+    const int gfirst = (cv / cpgv) * cpgv;                   // first chunk of this thread's group inside the block
+    // sum of `v` over the thread's group (all rows of the frame): rows through LDS in row order, then the group's chunks in order
+    auto group_sum = [&](float v) -> float {
+        red[rl][cv] = v;
+        __syncthreads();
+        if (rl == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < GN1_ROWS; ++r) t += red[r][cv];
+            colsum[cv] = t;
+        }
+        __syncthreads();
+        float g = 0.f;
+        for (int k = 0; k < cpgv; ++k) g += colsum[gfirst + k];
+        __syncthreads();
+        return g;
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        float f[8];
+        unpack8(raw[i], f);
+        s += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    }
+    const float mean = group_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        float f[8];
+        unpack8(raw[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q = __builtin_fmaf(d, d, q); }
+    }
+    const float rstd = rsqrtf(group_sum(q) * inv_n + eps);
+    const float a[8] = {rstd * g0.x, rstd * g0.y, rstd * g0.z, rstd * g0.w, rstd * g1.x, rstd * g1.y, rstd * g1.z, rstd * g1.w};
+    const float b[8] = {b0.x - mean * a[0], b0.y - mean * a[1], b0.z - mean * a[2], b0.w - mean * a[3],
+                        b1.x - mean * a[4], b1.y - mean * a[5], b1.z - mean * a[6], b1.w - mean * a[7]};
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        float f[8];
+        unpack8(raw[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f[e] = __builtin_fmaf(f[e], a[e], b[e]);
+            if (silu) f[e] = silu_f(f[e]);
+        }
+        *(uint4*)(out + (row0 + i * GN1_ROWS + rl) * C + c0 + cv * 8) = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (C <= 2048 -> <= 4 chunks of 8 per lane),
 // exact two-pass mean / variance with 64-lane butterfly reductions.
 // ---------------------------------------------------------------------------------------------
@@ -663,6 +743,30 @@ extern "C" int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, in
                                                int rows_per_unit, const float* stats, const float* gamma, const float* beta,
                                                float eps, int silu, void* out, void* raw16) {
     return gn_apply_stats_launch<true>(stream, X1, C1, X2, C2, rows, rows_per_unit, stats, gamma, beta, eps, silu, out, raw16);
+}
+
+// One-pass GroupNorm(32)(+SiLU) of the small levels (ABI 15): rows_per_unit in {144, 576}, 40 or 80 channels per group,
+// C1 (and C2) multiples of 160, 16-bit tensors.  wiw_groupnorm_onepass_ok says whether a launch fits.
+extern "C" int wiw_groupnorm_onepass_ok(int C1, int C2, int64_t rows, int rows_per_unit) {
+    const int C = C1 + C2;
+    if (rows_per_unit != 144 && rows_per_unit != 576) return 0;
+    if (rows <= 0 || rows % rows_per_unit) return 0;
+    if (C % GROUPS || ((C / GROUPS) != 40 && (C / GROUPS) != 80)) return 0;
+    if (C1 % GN1_CB || C2 % GN1_CB || C > GN_MAXC) return 0;
+    return 1;
+}
+extern "C" int wiw_groupnorm_onepass(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows, int rows_per_unit,
+                                     const float* gamma, const float* beta, float eps, int silu, void* out) {
+    WIW_REQUIRE(wiw_groupnorm_onepass_ok(C1, C2, rows, rows_per_unit), "groupnorm_onepass: shape outside the one-pass kernel (wiw_groupnorm_onepass_ok)");
+    WIW_REQUIRE(X1 && gamma && beta && out && (C2 == 0 || X2), "groupnorm_onepass: null pointer");
+    const dim3 grid((unsigned)((C1 + C2) / GN1_CB), (unsigned)(rows / rows_per_unit));
+    if (rows_per_unit == 576)
+        hipLaunchKernelGGL(gn_onepass_kernel<48>, grid, dim3(GN1_THREADS), 0, (hipStream_t)stream, (const uint16_t*)X1, C1, (const uint16_t*)X2, C2,
+                           gamma, beta, eps, silu, (uint16_t*)out);
+    else
+        hipLaunchKernelGGL(gn_onepass_kernel<12>, grid, dim3(GN1_THREADS), 0, (hipStream_t)stream, (const uint16_t*)X1, C1, (const uint16_t*)X2, C2,
+                           gamma, beta, eps, silu, (uint16_t*)out);
+    return wiw_check_launch("wiw_groupnorm_onepass");
 }
 
 extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int C, const float* gamma,

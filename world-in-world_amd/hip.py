@@ -142,6 +142,9 @@ EXPORTS = {
                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "wiw_groupnorm_counters": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "wiw_conv_halo_ok": (C.c_int, [C.c_void_p]),
+    "wiw_groupnorm_onepass_ok": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int]),
+    "wiw_groupnorm_onepass": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_float, C.c_int, C.c_void_p]),
     "wiw_groupnorm_apply_stats_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "wiw_layernorm_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
@@ -219,7 +222,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 14:
+        if self.lib.wiw_abi_version() != 15:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -239,6 +242,7 @@ class Hip:
         # entries are (start_event, end_event, algorithmic_flops, mode, (M, N, K, epilogue))
         self.gemm_profile = None
         self._splitk_ws = None
+        self.gn_two_kernels = bool(os.environ.get("WIW_GN_TWO_KERNELS"))     # A/B knob: statistics + apply launches at every level
         # int32 counters of the GroupNorm statistics launches, one row per STREAM that ever launched one (see _gn_buffers);
         # all rows are allocated and zeroed here: handing one out is legal inside a hipGraph capture
         self._gn_cnt_pool = torch.zeros(16, 65536, dtype=torch.int32, device=self.device)
@@ -462,6 +466,15 @@ class Hip:
         if os.environ.get("WIW_GN_UNFUSED") and not f32in:   # A/B knob for profiling
             return self.groupnorm_unfused(X1, C1, X2, C2, rows, rows_per_unit, gamma, beta, eps, silu, out, clip)
         Ct = C1 + C2
+        if (not f32in and not clip and not self.gn_two_kernels
+                and self.lib.wiw_groupnorm_onepass_ok(C1, C2, rows, rows_per_unit)):      # ABI 15: the two inner levels in ONE pass
+            if out is None:
+                out = torch.empty((rows, Ct), dtype=self.dtype, device=self.device)
+            s = self._stream()
+            self._timed("groupnorm", 0.0, 4.0 * rows * Ct, lambda: self._ck(self.lib.wiw_groupnorm_onepass(
+                s, _p(X1), C1, _p(X2), C2, rows, rows_per_unit, _p(gamma), _p(beta), eps, 1 if silu else 0, out.data_ptr()),
+                "wiw_groupnorm_onepass"))
+            return out
         rpb = self.gn_rows_per_block(rows_per_unit, clip)
         stats, scratch, cnt = self._gn_buffers(rows, rows_per_unit, rpb)
         if out is None:
