@@ -1,14 +1,14 @@
 # rocprofv3 kernel-stats (2-step) + PMC (1-step, three separate passes: never combined with tracing domains other than
 # kernel-trace) of bench.py, the default bench line with the per-shape dump, and the B = 8 / end-to-end line -> gpurun_out/TAG/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r14}
+TAG=${1:-r18}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python bench.py --num-inference-steps 2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-graph --no-calibrate > $O/ks.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o ks -- python bench.py --num-inference-steps 2 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-events --no-graph --no-calibrate --no-power > $O/ks.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_ks -name "*results.db" | head -1) $O/${TAG}_kernel_stats_2step.csv
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc$i -o p$i -- python bench.py --num-inference-steps 1 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-graph --no-calibrate > $O/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc$i -o p$i -- python bench.py --num-inference-steps 1 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-events --no-graph --no-calibrate --no-power > $O/pmc$i.log 2>&1
 done
 python tools/pmc_summary.py $O/${TAG}_pmc_1step.csv $(find /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 -name "*results.db")
 # the temporal block alone (MFMA pipe of temporal_block_resident_kernel (C = 320) / temporal_block_kernel at the level shapes; PMC in its own pass)
