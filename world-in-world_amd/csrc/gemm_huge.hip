@@ -33,12 +33,6 @@
 #ifndef WIW_HUGE_PIPE
 #define WIW_HUGE_PIPE 2   // 1: the free-running K loop of round 5 for every instantiation without a halo-staged A operand (below: PIPE); 2: also the halo-staged 3x3 convolutions
 #endif
-#ifndef WIW_PIPE_DMA
-#define WIW_PIPE_DMA 0    // PIPE: when the K tiles are fetched (see pipe_step): 0 = K tile kt + 1 during the first k-step of tile kt;
-                          // 1 = K tile kt + 2 behind tile kt's barrier, its last two parts in the next tile; 2 = all five parts behind the barrier (measured: 0 is
-                          // 3-7 % faster than the eight-slot loop, 1 and 2 no faster than it — a burst of DMA issue right behind the barrier
-                          // is the worst place for it, profiles/r16f_pipe_ab.txt)
-#endif
 #if WIW_F16
 #define WIW_MFMA_ASM "v_mfma_f32_16x16x32_f16"
 #else
@@ -634,10 +628,10 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
             // two MFMAs.  The last K tile of an output tile runs the same code (ONE copy of the loop body: with a second flavour for
             // it hipcc kept the accumulators of one flavour in scratch): its reads ahead fetch stale bytes of the other stage that
             // nothing uses, its barrier is one barrier more.
-            // DMA: K tile kt + 2 goes into the stage of tile kt right behind tile kt's barrier (parts in iterations 7, 8/9 of the
-            // second k-step and 0, 1 of the next tile's first: a whole K tile of latency cover); K tile 1 of an output tile in the
-            // first k-step of tile 0 (the previous epilogue fetched K tile 0 only: the other stage was its staging area)
-            auto pipe_step = [&](auto kk_tag, const bool dma1, const bool dma2, const bool dma2_tail, const int si, const bool hdo, const int m0t, const int y0t) {
+            // DMA: K tile kt + 1 goes into the other stage during the first k-step of tile kt (five parts, iterations 0 2 4 6 8/9).
+            // Fetching K tile kt + 2 right behind tile kt's barrier instead (a whole K tile of latency cover) measured no faster
+            // than the slot loop: a burst of DMA issue behind the barrier is the worst place for it (profiles/r16f_pipe_ab.txt).
+            auto pipe_step = [&](auto kk_tag, const bool dma1, const int si, const bool hdo, const int m0t, const int y0t) {
                 constexpr int KK = decltype(kk_tag)::value;
                 const unsigned ra_n = HALO ? 0u : (KK == 0 ? ra[1] : ra[0] + (unsigned)nd);      // the next k-step's fragment addresses
                 const unsigned rb_n = KK == 0 ? rb[1] : rb[0] + (unsigned)nd;
@@ -680,11 +674,6 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                             else if (j == 7) issue_halo(m0t, y0t, h_next, IC<2>{});
                         }
                     }
-                    if (KK == 0 && dma2_tail) {                 // the last two parts of the K tile whose fetch began behind the previous tile's barrier
-                        if (j == 0) issue_part(si, IC<3>{}, IC<0>{});
-                        else if (j == 1) issue_part(si, IC<4>{}, IC<0>{});
-                    }
-                    if (KK == 1 && j == 7 && dma2) issue_part(si, IC<0>{}, IC<0>{});
                     if (j == 0) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(pa[2]));
                     HP_MMA(acc[2][j], w_now, pa[2]);
                     if (j == 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(pa[3]));
@@ -707,7 +696,6 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                     HP_DSR(pa[0], an0, 0);
                     if (!HALO && KK == 0 && dma1) issue_part(si, IC<4>{}, IC<0>{});
                     if (HALO && KK == 0 && hdo) issue_halo(m0t, y0t, h_next, IC<3>{});
-                    if (KK == 1 && dma2) issue_part(si, IC<1>{}, IC<0>{});
                     HP_MMA(acc[1][8], w8, pa[1]);
                     HP_MMA(acc[1][9], w9, pa[1]);
                     HP_DSR(pa[1], an1, AO1);
@@ -715,11 +703,8 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                     HP_MMA(acc[2][9], w9, pa[2]);
                     HP_DSR(pa[2], an2, AO2);
                     if (HALO && KK == 0 && hdo) issue_halo(m0t, y0t, h_next, IC<4>{});
-                    if (KK == 1 && dma2) issue_part(si, IC<2>{}, IC<0>{});
                     HP_MMA(acc[3][8], w8, pa[3]);
-                    if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<3>{}, IC<0>{});
                     HP_MMA(acc[3][9], w9, pa[3]);
-                    if (WIW_PIPE_DMA == 2 && KK == 1 && dma2) issue_part(si, IC<4>{}, IC<0>{});
                     HP_DSR(pa[3], an3, AO3);
                     HP_DSR(pb[(2 * KK + 12) & 3], rb_n, 4096);                       // W'[2] into W[8]'s registers
                 }
@@ -728,16 +713,8 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 // step 0 of tile kt: K tile 1 (kt = 0), or the tail of K tile kt + 1, into the other stage; step 1: the head of
                 // K tile kt + 2 into THIS stage behind the barrier
                 const bool hdo = HALO && h_next < h_nblk && kt == h_tile;
-#if WIW_PIPE_DMA == 0
-                pipe_step(IC<0>{}, kt + 1 < nk, false, false, st_c ^ 1, hdo, m0, y0);
-                pipe_step(IC<1>{}, false, false, false, st_c, false, m0, y0);
-#elif WIW_PIPE_DMA == 1
-                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, kt >= 1 && kt + 1 < nk, st_c ^ 1, hdo, m0, y0);
-                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c, false, m0, y0);
-#else
-                pipe_step(IC<0>{}, kt == 0 && nk > 1, false, false, st_c ^ 1, hdo, m0, y0);
-                pipe_step(IC<1>{}, false, kt + 2 < nk, false, st_c, false, m0, y0);
-#endif
+                pipe_step(IC<0>{}, kt + 1 < nk, st_c ^ 1, hdo, m0, y0);
+                pipe_step(IC<1>{}, false, st_c, false, m0, y0);
                 if (HALO && hdo) { ++h_next; h_tile = (9 * h_next - 10) / 2 + 1; }
                 ra[0] += (unsigned)nd; ra[1] += (unsigned)nd; rb[0] += (unsigned)nd; rb[1] += (unsigned)nd;
                 nd = -nd;
