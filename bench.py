@@ -125,6 +125,8 @@ class PowerSampler:
     kernel of this repo holds ~1.3 kW at 1.7-2.2 GHz of the 2.4 GHz the peak figures assume (profiles/r16k_power_by_kernel.txt)
     — so frames/s on a box follows its clock.  None when rocm-smi is not there."""
 
+    PERIOD_S = 0.4
+
     def __init__(self):
         self.samples, self._stop, self._th = [], False, None
 
@@ -144,11 +146,13 @@ class PowerSampler:
         import threading
 
         def loop():
+            import time as _t
             while not self._stop:
                 smp = self.read()
                 if smp is None:
                     return
                 self.samples.append(smp)
+                _t.sleep(self.PERIOD_S)        # no back-to-back forks of rocm-smi beside the timed launches
 
         self._th = threading.Thread(target=loop, daemon=True)
         self._th.start()
@@ -162,6 +166,7 @@ class PowerSampler:
             return None
         return {"sclk_MHz_mean": round(sum(x[0] for x in sm) / len(sm)), "sclk_MHz_min": min(x[0] for x in sm),
                 "watts_mean": round(sum(x[1] for x in sm) / len(sm)), "watts_max": round(max(x[1] for x in sm)), "samples": len(sm),
+                "sampling": f"on (rank 0 only): one rocm-smi fork every {self.PERIOD_S} s + its own run time, from a thread of this process",
                 "source": "rocm-smi --showclocks --showpower during the timed region (GPU 0); nominal peak clock 2400 MHz, board limit 1400 W"}
 
 

@@ -567,6 +567,91 @@ def _gen_pipeline_served(ns, fname, cfg, H, W, steps, seed, keep):
          trajectory_steps=np.array(keep), **cond, **out)
 
 
+def gen_pipeline_northstar(ns):
+    """`StableVideoDiffusionPipeline.__call__` (pipeline_stable_video_diffusion.py:383-638) for the FULL 25 steps at the
+    BENCHMARKED size (BASELINE config 1: 576x1024x14, latent 72x128, B = 1 with CFG), served-width UNet (weights seed 4),
+    output_type='latent', fp32.  25 reference forwards at (2,14,8,72,128): ~2 h on 8 cores, run in the
+    background of the build container.  Tiny random VAE / CLIP supply the conditioning, captured at the UNet boundary.
+    Stored: conditioning (image latents, CLIP embedding), the reference's latents after steps 5/10/15/20 and the final ones, fp32.  NOT stored:
+    the latent noise (2 MB) — the test redraws it (numpy's frozen legacy RandomState, same draw order) and float64 checksums pin it.
+    Every step's latents also go to $WIW_NORTHSTAR_SCRATCH (default /tmp/wiw_ns_partial) so an interrupted run leaves a prefix."""
+    import time
+
+    from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
+    from PIL import Image
+    from transformers import CLIPImageProcessor, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    pl = ns.pipeline_module
+    cfg = UNetConfig()
+    H, W, steps, seed = 576, 1024, 25, 35
+    keep = (5, 10, 15, 20, 25)
+    scratch = os.environ.get("WIW_NORTHSTAR_SCRATCH", "/tmp/wiw_ns_partial")
+    os.makedirs(scratch, exist_ok=True)
+    torch.manual_seed(0)
+    vae = AutoencoderKLTemporalDecoder(block_out_channels=(32, 64, 64, 64), down_block_types=("DownEncoderBlock2D",) * 4,
+                                       layers_per_block=1, latent_channels=4, force_upcast=True, scaling_factor=0.18215).eval()
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1,
+                                                          num_attention_heads=2, image_size=224, patch_size=32,
+                                                          projection_dim=cfg.cross_attention_dim)).eval()
+    T = cfg.num_frames
+    rs = np.random.RandomState(seed)
+    img = Image.fromarray(rs.randint(0, 256, size=(H, W, 3), dtype=np.uint8))
+    acts = np.array([([4] + [1, 2, 1, 3] * 4)[:T]], dtype=np.int64)   # SURVEY 8d: [4] + cycle([1, 2, 1, 3])
+    img_noise = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+    lat_noise = rs.standard_normal((1, T, 4, H // 8, W // 8)).astype(np.float32)
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    unet = ref_unet(ns, cfg, seed=4)
+    pipe = StableVideoDiffusionPipeline(vae=vae, image_encoder=clip, unet=unet, scheduler=make_scheduler(ns),
+                                        feature_extractor=CLIPImageProcessor())
+    pipe.set_progress_bar_config(disable=True)
+    queue = [img_noise, lat_noise]
+    orig = pl.randn_tensor
+    pl.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.from_numpy(queue.pop(0).copy()).to(dtype)
+    cap, traj = {}, {}
+    o_vae, o_img = pipe._encode_vae_image, pipe._encode_image
+    t0 = time.time()
+
+    def enc_vae(*a, **k):
+        r = o_vae(*a, **k)
+        cap["il"] = r.detach().clone()
+        return r
+
+    def enc_img(*a, **k):
+        r = o_img(*a, **k)
+        cap["ie"] = r.detach().clone()
+        return r
+
+    def on_step(pipe_, i, t, kw):
+        x = kw["latents"].detach().clone()
+        if (i + 1) in keep:
+            traj[i + 1] = x
+        if i == 0:
+            np.save(os.path.join(scratch, "image_latents.npy"), cap["il"][1:].numpy())
+            np.save(os.path.join(scratch, "image_embeddings.npy"), cap["ie"][1:].numpy())
+        np.save(os.path.join(scratch, f"step_{i + 1:02d}.npy"), x.numpy())
+        print(f"  pipeline_northstar: step {i + 1}/{steps}  {time.time() - t0:.0f} s  rms {float(x.double().pow(2).mean().sqrt()):.5f}", flush=True)
+        return kw
+
+    pipe._encode_vae_image, pipe._encode_image = enc_vae, enc_img
+    try:
+        with torch.no_grad():
+            lat = pipe([img], height=H, width=W, num_frames=T, fps=7, motion_bucket_id=127, noise_aug_strength=0.02,
+                       num_inference_steps=steps, added_action_ids=aid, output_type="latent",
+                       callback_on_step_end=on_step, callback_on_step_end_tensor_inputs=["latents"]).frames
+    finally:
+        pl.randn_tensor = orig
+    assert not queue
+    assert float(cap["il"][0].abs().max()) == 0.0 and float(cap["ie"][0].abs().max()) == 0.0
+    assert torch.equal(lat, traj[steps])
+    keep = keep[:-1]            # the final latents are `latents_out`
+    save("pipeline_northstar_72x128.npz", weight_seed=np.array(4), input_seed=np.array(seed), num_steps=np.array(steps),
+         num_frames=np.array(T), latent_hw=np.array([H // 8, W // 8]), actions=acts,
+         noise_checksum=np.array(lat_noise.astype(np.float64).sum()), noise_abs_checksum=np.array(np.abs(lat_noise.astype(np.float64)).sum()),
+         image_latents=cap["il"][1:].numpy(), image_embeddings=cap["ie"][1:].numpy(), trajectory_steps=np.array(keep),
+         trajectory=np.stack([traj[k][0].numpy() for k in keep]), latents_out=lat.numpy(),
+         seconds=np.array(time.time() - t0))
+
+
 def gen_frontend(ns):
     """VAE encode (mode) / temporal decode and the CLIP antialias resize of the reference, tiny random VAE."""
     from diffusers import AutoencoderKLTemporalDecoder
@@ -602,10 +687,10 @@ def main():
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
                 pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
                 pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0, manip=gen_manip,
-                unet_northstar=gen_unet_northstar)
-    only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything
+                unet_northstar=gen_unet_northstar, pipeline_northstar=gen_pipeline_northstar)
+    only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything but the 2-hour one
     for name, fn in gens.items():
-        if not only or name in only:
+        if name in only or (not only and name != "pipeline_northstar"):
             fn(ns)
 
 

@@ -101,3 +101,58 @@ def test_capture_is_refused_loudly_when_the_pool_would_not_fit(caplog):
     out = den.denoise(il, ie, noise, acts, num_steps=2)
     assert torch.equal(out, ref) and list(den._graphs) == [(1, 16, 32)]
     assert unet.hip.gn_counters_clean()               # every GroupNorm statistics launch (eager, warm-up, captured) left zeros
+
+
+def test_many_shapes_captured_in_sequence_keep_capturing():
+    """GroupNorm counter rows are keyed by stream; every capture used to take a FRESH side stream for its warm-up,
+    so the 15th shape a server saw ran out of rows, was refused (after evicting a live graph) and the server stayed eager.
+    One persistent warm-up stream per Hip: 20 shapes in sequence all capture, three streams ever launch a GroupNorm."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 5), DEV)
+    den = SVDDenoiser(unet, use_graph=True)
+    shapes = [(1 + (i % 3), 16 * (1 + i // 6), 32 * (1 + (i // 3) % 2)) for i in range(20)]
+    assert len(set(shapes)) == 20
+    for i, (B, h, w) in enumerate(shapes):
+        il, ie, noise, acts = _inputs(cfg, B, 4, h, w, i)
+        den.denoise(il, ie, noise, acts, num_steps=1)
+        assert den.graph_error is None, f"shape {i} {B, h, w}: {den.graph_error}"
+        assert (B, h, w) in den._graphs and len(den._graphs) <= den.MAX_GRAPHS
+    assert den.host_launch["eager"][1] == 0 and den.host_launch["graph"][1] == 20
+    assert len(unet.hip._gn_cnt) <= 3, f"GroupNorm launched from {len(unet.hip._gn_cnt)} streams"
+    assert unet.hip.gn_counters_clean()
+
+
+def test_a_shape_that_cannot_fit_costs_no_live_graph_and_its_refusal_expires():
+    """the fit is checked BEFORE the eviction (counting what the eviction would return), and a refusal is not
+    for ever — it expires after REFUSAL_TTL requests of that shape."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.pipeline import SVDDenoiser
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    cfg = UNetConfig.tiny(4)
+    unet = UNetHIP(cfg, random_state_dict(cfg, 5), DEV)
+    den = SVDDenoiser(unet, use_graph=True)
+    den.MAX_GRAPHS = 1
+    a = _inputs(cfg, 1, 4, 16, 32, 0)
+    b = _inputs(cfg, 2, 4, 16, 32, 1)
+    den.denoise(*a, num_steps=1)
+    assert list(den._graphs) == [(1, 16, 32)]
+    est = den.graph_pool_estimate
+    den.graph_pool_estimate = lambda B, h, w: 1e18 if B == 2 else est(B, h, w)     # B = 2 can never fit
+    den.denoise(*b, num_steps=1)
+    assert list(den._graphs) == [(1, 16, 32)], "a shape that cannot fit must not evict a live graph"
+    assert (2, 16, 32) in den._graph_refused
+    den.graph_pool_estimate = est
+    for _ in range(den.REFUSAL_TTL - 1):                                            # still refused: runs eagerly
+        den.denoise(*b, num_steps=1)
+    assert (2, 16, 32) in den._graph_refused or (2, 16, 32) in den._graphs
+    den.denoise(*b, num_steps=1)
+    assert list(den._graphs) == [(2, 16, 32)] and not den._graph_refused

@@ -575,7 +575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
 #define HP_A10(m) "+v"(acc[m][0]), "+v"(acc[m][1]), "+v"(acc[m][2]), "+v"(acc[m][3]), "+v"(acc[m][4]), "+v"(acc[m][5]), "+v"(acc[m][6]), "+v"(acc[m][7]), "+v"(acc[m][8]), "+v"(acc[m][9])
             asm volatile("s_nop 7" : HP_A10(0), HP_A10(1));
             asm volatile("s_nop 7" : HP_A10(2), HP_A10(3));
-#undef HP_A10
             slot_barrier();        // K tile 0 (confirmed above by every wave) is visible; every wave has left the previous epilogue's staging area
             bf16x8 pa[4], pb[4];
             unsigned ra[2], rb[2];     // this lane's fragment addresses in the stage of the running tile, k-step 0 / 1 (HALO: ra unused)
@@ -720,6 +719,11 @@ __global__ __launch_bounds__(512, 2) void gemm_huge_kernel(const WiwGemmArgs p, 
                 nd = -nd;
                 st_c ^= 1;
             }
+            // ... and the same on the way OUT: the epilogue's first VALU read of an accumulator must not depend on what
+            // happens to sit between the last asm MFMA and it (XDL write -> VALU read, the hazard class of attention32's v_max3)
+            asm volatile("s_nop 7\n\ts_nop 7" : HP_A10(0), HP_A10(1));
+            asm volatile("s_nop 7\n\ts_nop 7" : HP_A10(2), HP_A10(3));
+#undef HP_A10
             slot_barrier();        // every wave has finished reading the ring: the epilogue may stage into it
 #undef HP_DSR
 #undef HP_MMA

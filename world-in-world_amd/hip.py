@@ -245,8 +245,10 @@ class Hip:
         self.gn_two_kernels = bool(os.environ.get("WIW_GN_TWO_KERNELS"))     # A/B knob: statistics + apply launches at every level
         # int32 counters of the GroupNorm statistics launches, one row per STREAM that ever launched one (see _gn_buffers);
         # all rows are allocated and zeroed here: handing one out is legal inside a hipGraph capture
-        self._gn_cnt_pool = torch.zeros(16, 65536, dtype=torch.int32, device=self.device)
+        # 40 rows: torch hands out at most 32 pooled streams + the default stream + the graph-capture stream (10 MB)
+        self._gn_cnt_pool = torch.zeros(40, 65536, dtype=torch.int32, device=self.device)
         self._gn_cnt = {}
+        self._warmup_stream = None
         # ... and this one for the non-GEMM kernels: (start_event, end_event, family, algorithmic_flops, algorithmic_bytes)
         self.kernel_profile = None
 
@@ -258,6 +260,13 @@ class Hip:
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def warmup_stream(self):
+        """The ONE side stream graph captures warm up on (pipeline.GraphedForward): stream-keyed state (the GroupNorm counter
+        rows) then sees three streams per process — eager, warm-up, capture — however many shapes are captured."""
+        if self._warmup_stream is None:
+            self._warmup_stream = torch.cuda.Stream(self.device)
+        return self._warmup_stream
 
     def _timed(self, family: str, flops: float, nbytes: float, fn):
         """Run `fn` (one or more launches of one kernel family) between two HIP events when bench.py profiles."""

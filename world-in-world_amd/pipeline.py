@@ -147,7 +147,10 @@ class GraphedForward:
         self.emb = torch.zeros((cond.Bc * cfg.num_frames, cfg.time_embed_dim), dtype=unet.dtype, device=unet.device)
         hip = unet.hip
         assert hip.gemm_profile is None and hip.kernel_profile is None, "per-launch events cannot be recorded inside a capture"
-        side = torch.cuda.Stream(unet.device)
+        # ONE warm-up stream per Hip for every capture of the process: GroupNorm counter rows are keyed by stream
+        # (Hip._gn_buffers), and a fresh torch.cuda.Stream per capture walked torch's 32-stream pool until the rows ran out —
+        # a server seeing many (candidates, h, w) shapes then fell back to the eager loop for good
+        side = hip.warmup_stream()
         side.wait_stream(torch.cuda.current_stream(unet.device))
         with torch.cuda.stream(side):                                       # warm-up: one-time attribute calls, workspaces
             unet.forward(self.x_in, self.emb, cond, h, w)
@@ -189,7 +192,8 @@ class SVDDenoiser:
         self._graphs = {}           # (B, h, w) -> GraphedForward; at most MAX_GRAPHS shapes stay captured (their pools hold a
         self.MAX_GRAPHS = 2         # forward's intermediates: ~6 GB per candidate at 576x1024)
         self.graph_error = None     # the LAST reason a shape was not captured (that shape then runs eagerly; others still capture)
-        self._graph_refused = {}    # (B, h, w) -> reason; forgotten when a captured shape is evicted (memory came back)
+        self._graph_refused = {}    # (B, h, w) -> [reason, requests left before the shape gets another try]; also forgotten
+        self.REFUSAL_TTL = 8        # when a captured shape is evicted (memory came back)
         self.GRAPH_MEM_FRACTION = 0.8   # of the free HBM a capture's pool may take (estimate below)
         # host time spent ENQUEUEING UNet forwards (no synchronisation inside): [seconds, forwards] per mode
         self.host_launch = {"eager": [0.0, 0], "graph": [0.0, 0]}
@@ -203,7 +207,7 @@ class SVDDenoiser:
 
     def graph_status(self) -> dict:
         """For the server's status line / logs: what is captured, what was refused and why."""
-        return {"enabled": self.use_graph, "captured": [list(k) for k in self._graphs], "refused": {str(k): v for k, v in self._graph_refused.items()},
+        return {"enabled": self.use_graph, "captured": [list(k) for k in self._graphs], "refused": {str(k): v[0] for k, v in self._graph_refused.items()},
                 "last_error": self.graph_error, "host_launch": {k: list(v) for k, v in self.host_launch.items()}}
 
     def _graph_for(self, B: int, h: int, w: int, cond):
@@ -214,26 +218,45 @@ class SVDDenoiser:
         if gf is not None:
             self._graphs[key] = gf     # re-insert: dict order = recency, eviction below is least-recently-used
             return gf
-        if key in self._graph_refused:
-            return None
+        ref = self._graph_refused.get(key)
+        if ref is not None:
+            ref[1] -= 1               # a refusal expires: memory may have come back without an eviction
+            if ref[1] > 0:
+                return None
+            del self._graph_refused[key]
         log = logging.getLogger("wiw_amd.graph")
         prof = (self.hip.gemm_profile, self.hip.kernel_profile)      # (bench.py may have armed per-launch events for
         self.hip.gemm_profile = self.hip.kernel_profile = None       # the first step: not inside a capture)
         try:
-            while len(self._graphs) >= self.MAX_GRAPHS:
-                self._graphs.pop(next(iter(self._graphs)))
-                self._graph_refused.clear()          # memory came back: refused shapes get another try
-                torch.cuda.empty_cache()
             need = self.graph_pool_estimate(B, h, w)
-            free = float(torch.cuda.mem_get_info(self.device)[0]) if self.device.type == "cuda" else float("inf")
-            if need > self.GRAPH_MEM_FRACTION * free:
+
+            def free_now() -> float:
+                if self.device.type != "cuda":
+                    return float("inf")
+                torch.cuda.empty_cache()        # blocks torch's allocator only caches (a VAE decode, an eager run) ARE free
+                return float(torch.cuda.mem_get_info(self.device)[0])
+
+            # the fit is checked BEFORE anything is evicted, counting what the evictions would give back: a shape that cannot
+            # fit must not cost a live graph
+            victims = list(self._graphs)[: max(0, len(self._graphs) - self.MAX_GRAPHS + 1)]
+            back = sum(self.graph_pool_estimate(*k) for k in victims)
+            free = free_now()
+            if need > self.GRAPH_MEM_FRACTION * (free + back):
                 raise MemoryError(f"a captured forward for {B} candidate(s) at {h}x{w} would pin ~{need / 2**30:.1f} GiB, "
                                   f"{free / 2**30:.1f} GiB are free")
+            for k in victims:
+                self._graphs.pop(k)
+            if victims:
+                self._graph_refused.clear()          # memory came back: refused shapes get another try
+                free = free_now()
+                if need > self.GRAPH_MEM_FRACTION * free:
+                    raise MemoryError(f"a captured forward for {B} candidate(s) at {h}x{w} would pin ~{need / 2**30:.1f} GiB, "
+                                      f"{free / 2**30:.1f} GiB are free after evicting {len(victims)} graph(s)")
             gf = self._graphs[key] = GraphedForward(self.unet, cond, h, w)
             log.info("captured the UNet forward for %d candidate(s) at %dx%d (~%.1f GiB pool)", B, h, w, need / 2**30)
         except Exception as e:       # capture is an optimisation: the eager loop is the same computation — but say so, loudly
             self.graph_error = f"{type(e).__name__}: {e}"
-            self._graph_refused[key] = self.graph_error
+            self._graph_refused[key] = [self.graph_error, self.REFUSAL_TTL]
             log.warning("hipGraph capture refused for %d candidate(s) at %dx%d, this shape runs EAGERLY (~12 ms more host work per "
                         "forward): %s", B, h, w, self.graph_error)
             gf = None

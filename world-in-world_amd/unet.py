@@ -230,6 +230,23 @@ class UNetHIP:
             w[p + ".weight"] = self._t(sd, p + ".weight").contiguous()
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
 
+        n_lv = len(cfg.block_out_channels)
+        # widest latent this replica is built for (default: the served 1024-px panorama): the halo-staged kernel takes rows of
+        # 32 / 64 / 128 pixels (hip.conv_halo_ok), so a layer whose level can never be that wide gets no second weight copy —
+        # the 1280-channel level and the mid block at the served size: ~0.5 GB of HBM per replica
+        max_w = int(os.environ.get("WIW_MAX_LATENT_WIDTH", "128"))
+
+        def level_of(p):
+            if p.startswith("down_blocks."):
+                return int(p.split(".")[1])
+            if p.startswith("up_blocks."):
+                i = int(p.split(".")[1])
+                return n_lv - 1 - i - (1 if ".upsamplers." in p else 0)     # the upsampler's convolution runs at its OUTPUT size
+            return n_lv - 1 if p.startswith("mid_block.") else 0
+
+        def halo_level(p):
+            return (max_w >> level_of(p)) >= 32
+
         def conv3(p, cin_pad=0, halo=True):
             x = self._t(sd, p + ".weight").permute(0, 2, 3, 1)  # OIHW -> OHWI
             if cin_pad and x.shape[-1] < cin_pad:
@@ -239,7 +256,7 @@ class UNetHIP:
             w[p + ".bias"] = self._t(sd, p + ".bias").contiguous()
             # a second copy in the K order of the halo-staged kernel (N % 320 == 0: every ResnetBlock2D convolution of the
             # served widths): `_conv3` picks it when the request's geometry fits (hip.conv_halo_ok), else the copy above
-            if halo and self.halo and x.shape[0] % 320 == 0 and x.shape[1] % (9 * 64) == 0:
+            if halo and self.halo and halo_level(p) and x.shape[0] % 320 == 0 and x.shape[1] % (9 * 64) == 0:
                 w[p + ".weight_h"] = conv_k_halo32(x).to(bf).contiguous()
 
         def convt(p):
@@ -267,7 +284,8 @@ class UNetHIP:
                 w[s + ".conv2sc.bias"] = (self._t(sd, s + ".conv2.bias") + self._t(sd, s + ".conv_shortcut.bias")).contiguous()
                 del w[s + ".conv2.weight"], w[s + ".conv2.bias"]
                 w.pop(s + ".conv2.weight_h", None)
-                if self.halo and self.halo_sc and x.shape[0] % 320 == 0 and w2.shape[1] % (9 * 64) == 0 and x.shape[1] % 64 == 0:
+                if (self.halo and self.halo_sc and halo_level(s) and x.shape[0] % 320 == 0 and w2.shape[1] % (9 * 64) == 0
+                        and x.shape[1] % 64 == 0):
                     w2h = conv_k_halo32(self._t(sd, s + ".conv2.weight").permute(0, 2, 3, 1).reshape(x.shape[0], -1))
                     w[s + ".conv2sc.weight_h"] = torch.cat([w2h, x], dim=1).to(bf).contiguous()
             norm(t + ".norm1"); convt(t + ".conv1"); norm(t + ".norm2"); convt(t + ".conv2")
@@ -310,6 +328,12 @@ class UNetHIP:
 
         def transformer(p):
             norm(p + ".norm"); lin(p + ".proj_in"); lin(p + ".proj_out")
+            # ATTN_PRESCALE bakes head_dim 64 into the packed to_q rows (and the kernels are built for d = 64): a checkpoint with
+            # another head width must fail here, not run with a silently wrong softmax temperature
+            Cp = self._t(sd, p + ".proj_in.weight").shape[0]
+            lvl = [i for i, c in enumerate(cfg.block_out_channels) if c == Cp]
+            assert lvl and all(Cp == 64 * cfg.num_attention_heads[i] for i in lvl), (
+                f"{p}: {Cp} channels with heads {[cfg.num_attention_heads[i] for i in lvl]}: this build serves head_dim 64 only")
             b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
             norm(b + ".norm1"); norm(b + ".norm3"); norm(t + ".norm_in"); norm(t + ".norm1"); norm(t + ".norm3")
             # to_q rows PRE-SCALED by log2(e) / sqrt(64) in fp32, before their one rounding to 16 bits: the spatial attention
