@@ -21,6 +21,7 @@ launch inside the timed region, on the launch stream) and "cpu_baseline" (the CP
 host cores on a bounded sample, rank 0 / N=1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -189,7 +190,7 @@ def main():
                          "1e-3 of the reference's fp32 evaluation, DESIGN.md 5)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` legs the default single-GPU line appends after its timed region (B = 8 rollout = "
-                         "BASELINE config 2's per-GPU work, fp16 and fp16 + fp32-residual rollouts, a 2-step --train leg)")
+                         "BASELINE config 2's per-GPU work, fp16 and fp16 + fp32-residual rollouts, a --train leg of 2 warm-up + 5 timed steps)")
     ap.add_argument("--no-calibrate", action="store_true",
                     help="skip the box calibration launches (rocprofv3 runs: ~100 ms of calibration kernels would lead the "
                          "kernel statistics); `box` and `roofline.frac_of_box_peak` are then absent")
@@ -512,11 +513,21 @@ def train_bench(args, rank, world, device, dist_on=False):
     for _ in range(args.warmup):
         tr.step(st)
     barrier()
+    torch.cuda.reset_peak_memory_stats(device)
+    pws = PowerSampler() if rank == 0 and not getattr(args, "no_power", False) else None
+    if pws is not None:
+        pws.start()
+    # every step is bracketed (a step is ~0.3 s of GPU work: the barrier costs nothing measurable) so that the line can say
+    # whether a slow figure is one outlier (allocator growth, first touch) or the steady state — VERDICT r5 item 3
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         loss = tr.step(st)
-    barrier()
+        barrier()
+        per_step.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
+    power = pws.stop() if pws is not None else None
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -528,6 +539,8 @@ def train_bench(args, rank, world, device, dist_on=False):
             "metric": "fine-tuning samples/sec (train_svd.py step: fwd + bwd + AdamW)", "value": round(world * args.steps / dt, 4),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_median": round(1e3 * float(np.median(per_step)), 2), "ms_per_step_max": round(1e3 * max(per_step), 2),
+            "ms_per_step_all": [round(1e3 * x, 1) for x in per_step], "power": power,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SVD UNet fine-tuning step {args.train_height}x{args.train_width}x{Tn}, one sample per GPU, "
                                    "random-init weights; un-fused training forward, GEMM-shaped gradients on the inference GEMM "
@@ -549,7 +562,8 @@ def extras(args, cfg, unet, device, req, elapsed):
       fp16_res32  the same with the residual stream in fp32: the configuration gated at <= 1e-3 vs the reference's fp32 output
       end_to_end  ONE whole request through the worker: CLIP + VAE encode, loop, temporal VAE decode (own
                   row with its TFLOP/s), PIL resize, uint8 response
-      train       2 fine-tuning steps at 576x1024x14 (BASELINE config 4's per-GPU work)"""
+      train       2 warm-up + 5 timed fine-tuning steps at 576x1024x14 (BASELINE config 4's per-GPU work), every step bracketed:
+                  mean / median / max, clock and watts"""
     import copy
 
     from wiw_amd.pipeline import SVDDenoiser
@@ -606,9 +620,12 @@ def extras(args, cfg, unet, device, req, elapsed):
     try:
         if left() > 45:
             a2 = copy.copy(args)
-            a2.steps, a2.warmup, a2.no_autotune = 2, 1, True
+            a2.steps, a2.warmup, a2.no_autotune = 5, 2, True
+            gc.collect()
+            torch.cuda.empty_cache()           # four legs have churned the allocator: start the step from a clean cache
             tl = train_bench(a2, 0, 1, device, False)
-            out["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "peak_memory_GiB")}
+            out["train"] = {k: tl[k] for k in ("metric", "value", "unit", "ms_per_step", "ms_per_step_median", "ms_per_step_max",
+                                               "ms_per_step_all", "steps", "warmup", "power", "peak_memory_GiB")}
     except Exception as e:   # noqa: BLE001
         out["train"] = {"error": f"{type(e).__name__}: {e}"}
     out["seconds"] = round(time.perf_counter() - t0, 1)

@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 15  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 16  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -49,7 +49,9 @@ extern "C" {
                                  statistics launch (wiw_groupnorm_counters); WIW_K_HALO32 / wiw_conv_halo_ok; wiw_ffn_geglu_f32stream;
                              13: wiw_attn_spatial_ps_bf16 (32x32x16 spatial attention on a pre-scaled Q);
                              14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling)
-                                15: wiw_groupnorm_onepass / wiw_groupnorm_onepass_ok (one-pass GroupNorm of the inner levels) */
+                                15: wiw_groupnorm_onepass / wiw_groupnorm_onepass_ok (one-pass GroupNorm of the inner levels);
+                             16: wiw_ffn_geglu_f32stream2 (the fused FeedForward's LayerNorm reads the fp32 stream; a second,
+                                 16-bit output) */
 
 int wiw_abi_version(void);
 
@@ -260,6 +262,16 @@ int wiw_ffn_geglu_f32stream(void* stream, const void* X, int ldx, const void* W1
                        const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
                        float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
                        int C_in, int hidden, int ln, float ln_eps, int f32);
+/* ABI 16: the same operator with the fp32 stream on the INPUT side too.  f32 bit 3 = X is fp32 [M][ldx] (ldx in elements):
+ * allowed with ln != 0 only — the in-kernel LayerNorm (attention.py:540-567 / 745-756) takes exact two-pass moments of the fp32
+ * row and packs the normalised 16-bit MFMA operand, so the standalone wiw_layernorm_f32in pass in front of the FeedForward
+ * (read 4 B + write 2 B per element) disappears.  out16 (may be NULL): a second output [M][ldo16] in the library's 16-bit
+ * type = the rounding of `out` — what a 16-bit consumer of the stream (wiw_temporal_attn_block_bf16) reads, written from the
+ * registers that hold the fp32 result instead of by a wiw_cast_f32_to_16 pass. */
+int wiw_ffn_geglu_f32stream2(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                        const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1, int ldr1,
+                        float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out, int ldo, int64_t M,
+                        int C_in, int hidden, int ln, float ln_eps, int f32, void* out16, int ldo16);
 /* ABI 14: the same operator, same arguments and f32 mask, on v_mfma_f32_32x32x16 with every tensor of a 128-row tile in
  * registers (csrc/ffn32.hip: one wave per SIMD, the exact-erf GEGLU of hidden chunk c - 1 issued between the MFMAs of chunk c;
  * no LDS staging in the epilogue: ONE rounding of alpha * (h . W2^T + b2 + rowvec) + beta1 res1 + beta2 res2 whatever the

@@ -261,6 +261,57 @@ def test_ffn_fp32_residual_stream(hip, M, rpv):
     assert float(d) <= 1.2e-2
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [64, 1500, 9 * 128 * 20 + 77, 2 * 256 * 128 + 300])
+def test_ffn_layernorm_reads_the_fp32_stream(dt, M):
+    """`wiw_ffn_geglu_f32stream2` (ABI 16), f32 bit 3: X is the fp32 residual stream, the fused LayerNorm takes its moments
+    from the fp32 row and packs the normalised 16-bit operand — bit-identical to the same kernel fed the f32in LayerNorm
+    pass's job done in torch (normalise in fp32, round once), to which the standalone pass + 16-bit kernel also agree; `out16`
+    is the rounding of `out`.  M values: one tile, several tiles per block, the last tile ragged."""
+    hip = _hip(dt)
+    gamma, beta = 1.0 + 0.2 * rnd(C, seed=40), 0.1 * rnd(C, seed=41)
+    wt = make_weights(dt, seed=42, gamma=gamma, beta=beta)
+    x = rnd(M, C, seed=18) * 3.0 + 1.5 + rnd(M, 1, seed=19) * 4.0          # fp32 rows, mean / std far from 0 / 1
+    a = 0.3
+    hs = rnd(M, C, seed=20)
+    out = torch.full((M, C), float("nan"), dtype=torch.float32, device=DEV)
+    o16 = torch.full((M, C), float("nan"), dtype=dt, device=DEV)
+    kw = dict(res1=x.to(DEV), ldr1=C, beta1=1.0 - a, res2=hs.to(DEV), ldr2=C, beta2=a, alpha=1.0 - a)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, ln=True, out16=o16, **kw)
+    ref = oracle(x, wt, dt, ln=True, res1=x, beta1=1.0 - a, res2=hs, beta2=a, alpha=1.0 - a)
+    check(out, ref, dt, f"ffn LayerNorm on the fp32 stream M={M} {dt}")
+    assert torch.equal(o16.cpu(), out.cpu().to(dt)), "out16 must be the rounding of out"
+    # the normalised operand: the kernel on the PRE-normalised, rounded rows (ln = 0, same folded weights) gives the same bits
+    # wherever torch's layer_norm and the kernel's two-pass moments round alike; everywhere within an ulp of the operand
+    xn = F.layer_norm(x, (C,), None, None, 1e-5).to(dt)
+    out_b = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    hip.ffn_geglu(xn.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out_b, M, **kw)
+    d = float((out - out_b).abs().max() / out_b.abs().max())
+    print(f"[parity] in-kernel fp32 LayerNorm vs torch-normalised operand: max_rel={d:.2e}")
+    assert d <= (4e-3 if dt == torch.bfloat16 else 5e-4)
+    # 16-bit output + twice: bit-repeatable
+    o2 = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], o2, M, ln=True, **kw)
+    assert torch.equal(o2.cpu(), out.cpu().to(dt))
+    out2 = torch.empty_like(out)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out2, M, ln=True, **kw)
+    assert torch.equal(out2, out)
+
+
+def test_ffn_out16_without_fp32_x(hip):
+    """out16 beside a 16-bit X (the ff_in of the fp32-stream mode behind a separate LayerNorm pass)."""
+    dt = torch.bfloat16
+    M = 3000
+    wt = make_weights(dt, seed=21)
+    x = rnd(M, C, seed=11).to(dt)
+    r1 = rnd(M, C, seed=12) * 3.0
+    out = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    o16 = torch.empty(M, C, dtype=dt, device=DEV)
+    hip.ffn_geglu(x.to(DEV), wt["W1"], wt["b1"], wt["W2"], wt["b2d"], out, M, res1=r1.to(DEV), ldr1=C, beta1=1.0, out16=o16)
+    check(out, oracle(x, wt, dt, res1=r1, beta1=1.0), dt, "ffn fp32 out + out16")
+    assert torch.equal(o16.cpu(), out.cpu().to(dt))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # wiw_ffn32_geglu (csrc/ffn32.hip, ABI 14): the same operator on 32x32x16 MFMAs, everything in registers.  Same oracle, same
 # gates.  (Opt-in in the UNet — WIW_FFN32=1 — because it is not faster than ffn.hip; it is kept correct.)

@@ -451,3 +451,59 @@ def test_unet_north_star_size_against_the_reference(name, res32, golden):
     assert rms <= gate, f"{name} res32={res32}: rms {rms:.3e} vs the reference's fp32 output at 72x128 exceeds {gate:.2e}"
     assert rms_w <= gate_w, f"{name} res32={res32}: rms {rms_w:.3e} vs the same-weights reference at 72x128 exceeds {gate_w:.2e}"
     torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------------------------
+# north_star's parity sentence on BASELINE config 1 itself: the reference pipeline's OWN 25-step trajectory at the benchmarked
+# size (tests/golden/pipeline_northstar_72x128.npz, `oracle/make_golden.py pipeline_northstar`: StableVideoDiffusionPipeline
+# .__call__, pipeline_stable_video_diffusion.py:383-638, output_type='latent', 576x1024x14, B = 1 with CFG, fp32; 25 reference
+# forwards = 2 h of the build container's cores).  VERDICT r5 item 2: the 16x32 trajectory says the error is made in steps
+# 15-25 (sigma < 3) — not at the sigma the one-forward 72x128 fixture samples.
+# ----------------------------------------------------------------------------------------------
+def northstar_pipeline_noise(p):
+    """The fixture stores no noise (2 MB): the generator's draws restated in its order (image, image noise, latent noise) on
+    numpy's frozen legacy RandomState; float64 checksums pin the draw."""
+    h, w = (int(v) for v in p["latent_hw"])
+    T = int(p["num_frames"])
+    rs = np.random.RandomState(int(p["input_seed"]))
+    rs.randint(0, 256, size=(8 * h, 8 * w, 3), dtype=np.uint8)
+    rs.standard_normal((1, 3, 8 * h, 8 * w))
+    noise = rs.standard_normal((1, T, 4, h, w)).astype(np.float32)
+    assert abs(float(noise.astype(np.float64).sum()) - float(p["noise_checksum"])) < 1e-6
+    assert abs(float(np.abs(noise.astype(np.float64)).sum()) - float(p["noise_abs_checksum"])) < 1e-6
+    return noise
+
+
+# (rms, max) gates of the relative latent error after 25 steps at 72x128.  fp16 + fp32 stream: north_star's 1e-3 on BOTH norms;
+# the others 1.2 x the round-6 measurement (profiles/r19*_northstar_trajectory.log)
+NORTHSTAR_LOOP_GATES = {
+    ("fp16", True): (1.0e-3, 1.0e-3),
+    ("fp16", False): (1.0e-3, 1.5e-3),
+    ("bf16", False): (8.0e-3, 1.2e-2),
+}
+
+
+@pytest.mark.parametrize("name,res32", list(NORTHSTAR_LOOP_GATES))
+def test_reference_trajectory_25_steps_at_the_benchmarked_size(name, res32, golden):
+    from wiw_amd.pipeline import SVDDenoiser
+
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "pipeline_northstar_72x128.npz")):
+        pytest.skip("tests/golden/pipeline_northstar_72x128.npz not generated yet (oracle/make_golden.py pipeline_northstar, ~2 h)")
+    p = golden("pipeline_northstar_72x128.npz")
+    assert int(p["weight_seed"]) == 4 and int(p["num_steps"]) == 25 and tuple(int(v) for v in p["latent_hw"]) == (72, 128)
+    noise = northstar_pipeline_noise(p)
+    keep = [int(k) for k in p["trajectory_steps"]]
+    traj = {}
+    unet = full_unet(name, res32)
+    lat = SVDDenoiser(unet, use_graph=False).denoise(
+        torch.from_numpy(p["image_latents"]), torch.from_numpy(p["image_embeddings"]), torch.from_numpy(noise), p["actions"],
+        num_steps=25, callback=lambda i, x: traj.__setitem__(i + 1, x.cpu().numpy().copy()) if (i + 1) in keep else None).cpu().numpy()
+    mx, rms = rel(lat, p["latents_out"])
+    per = " ".join(f"{k}:{rel(traj[k], p['trajectory'][i][None])[1]:.2e}/{rel(traj[k], p['trajectory'][i][None])[0]:.2e}" for i, k in enumerate(keep))
+    print(f"[tolerance] 25-step rollout at the BENCHMARKED size 576x1024x14 vs the reference pipeline's own latents, {name}"
+          f"{' + fp32 residual stream' if res32 else ''}: relative latent error rms={rms:.3e} max={mx:.3e} | per step rms/max {per}")
+    assert np.isfinite(lat).all()
+    g_rms, g_max = NORTHSTAR_LOOP_GATES[(name, res32)]
+    assert rms <= g_rms, f"{name} res32={res32}: rms {rms:.3e} > {g_rms:.1e}"
+    assert mx <= g_max, f"{name} res32={res32}: max {mx:.3e} > {g_max:.1e}"
+    torch.cuda.empty_cache()

@@ -273,12 +273,17 @@ struct FfnArgs {
     int M, ldx, ldo, ldr1, ldr2, rowvec_ld, rows_per_vec, ln;
     int f32;                // F32E: bit 0 out, bit 1 res1, bit 2 res2 are fp32 (leading dimensions in ELEMENTS)
     float alpha, beta1, beta2, ln_eps;
+    uint16_t* out16;        // F32E (ABI 16): a second, 16-bit copy of the output rows [M][ldo16], or null
+    int ldo16;
 };
 
 // F32E (round 4, the fp32 residual stream of ABI 11 in this kernel): res1 / res2 / out may be fp32 (p.f32 bits 1 / 2 / 0); the
 // Y accumulators then take bias, per-frame vector and residuals in the FRAGMENT layout (a lane holds 4 consecutive columns of
 // a row: 16-byte fp32 / 8-byte 16-bit accesses) and are rounded once, or not at all — no 16-bit staging in between.
-template <bool F32E>
+// F32X (round 6, ABI 16: f32 bit 3): X itself is the fp32 residual stream and the LayerNorm (ln != 0) reads it — the H-waves
+// stage a row block's 80 fp32 values per lane in registers, take exact two-pass moments and pack the normalised 16-bit MFMA
+// operand; the standalone LayerNorm pass of the fp32-stream mode (read 4 B + write 2 B per element) is gone.
+template <bool F32E, bool F32X = false>
 __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -353,6 +358,47 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 }
             }
         };
+        // F32X: row block mi of a tile as fp32 (lane: row 16*mi + frow, columns 32*ks + 8*fq .. +7 = two 16-byte loads), staged in
+        // xf0 / xf1; block 0 of the NEXT tile is requested before the last GEGLU of a tile (80 registers in flight under it),
+        // block 1 right behind that GEGLU (the accumulators are dead by then), so its latency hides behind block 0's moments
+        float4 xf0[KS][2], xf1[KS][2];
+        auto load_xf = [&](float4 (&xf)[KS][2], int tile, int mi) {
+            int m = tile * BM + wq * 32 + mi * 16 + frow;
+            m = m < p.M ? m : p.M - 1;
+            const float* src = (const float*)p.X + (int64_t)m * p.ldx + fq * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xf[ks][0] = ld_stream((const float4*)(src + ks * 32));
+                xf[ks][1] = ld_stream((const float4*)(src + ks * 32 + 4));
+            }
+        };
+        auto normalize_xf = [&](const float4 (&xf)[KS][2], int mi) {
+            float s = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s += (xf[ks][h].x + xf[ks][h].y) + (xf[ks][h].z + xf[ks][h].w);
+            const float mean = xor32_sum(xor16_sum(s)) * (1.0f / (float)C);
+            float q = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a = xf[ks][h].x - mean, b = xf[ks][h].y - mean, c = xf[ks][h].z - mean, d = xf[ks][h].w - mean;
+                    q = __builtin_fmaf(a, a, __builtin_fmaf(b, b, __builtin_fmaf(c, c, __builtin_fmaf(d, d, q))));
+                }
+            const float rstd = rsqrtf(xor32_sum(xor16_sum(q)) * (1.0f / (float)C) + p.ln_eps);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                union { bf16x8 v; uint32_t u[4]; } x;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    x.u[2 * h] = pack2bf((xf[ks][h].x - mean) * rstd, (xf[ks][h].y - mean) * rstd);
+                    x.u[2 * h + 1] = pack2bf((xf[ks][h].z - mean) * rstd, (xf[ks][h].w - mean) * rstd);
+                }
+                xa[mi][ks] = x.v;
+            }
+        };
         const int sw0 = (fq ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;   // swizzled chunk of k-step 0 / 1
         auto read_w1 = [&](bf16x8* fb, int stage, int sw) {
             const char* s = smem + stage * RING_STAGE_BYTES + frow * 128 + sw;
@@ -381,16 +427,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             __builtin_amdgcn_s_setprio(0);
         };
 
-        load_x(blockIdx.x);
+        if constexpr (F32X) { load_xf(xf0, blockIdx.x, 0); load_xf(xf1, blockIdx.x, 1); }
+        else load_x(blockIdx.x);
         int st = 0;          // ring stage of the next K tile
         int c = 0, ti = 0;   // chunk inside the tile, tile counter of this block
-        for (int cc = 0; cc <= NC; ++cc) {
-            if (cc == NC) {   // drain iteration: the Y-waves finish the last chunk (+ the tile-end barrier, see below)
-#pragma unroll
-                for (int i = 0; i < NKT + 2; ++i) slot_barrier();
-                break;
-            }
-            if (c == 0 && p.ln) normalize_x();
+        // one hidden chunk (H-wave side); LAST: compile-time "chunk NCH - 1 of its tile" (F32X only, see the loads below)
+        auto chunk = [&](const int cc, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -436,7 +479,14 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             FTP(0, 11);
             mma(fbB, xa[0][KS - 1], xa[1][KS - 1]);
             FTP(0, 12);              // last k-step issued
-            if (c == NCH - 1 && ti + 1 < ntl) load_x(blockIdx.x + (ti + 1) * nb);   // X of the next tile: latency under the GEGLU
+            if constexpr (F32X) {   // X of the next tile: latency under the GEGLU
+                // (LAST is compile time and the load unconditional — behind the block's last tile it re-reads row M - 1 — so
+                // that the staging registers are provably dead during the other 19 chunks: with a run-time test hipcc kept
+                // all 160 of them alive around the loop, 500 bytes of scratch per lane)
+                if constexpr (LAST) load_xf(xf0, blockIdx.x + (ti + 1) * nb, 0);
+            } else {
+                if (c == NCH - 1 && ti + 1 < ntl) load_x(blockIdx.x + (ti + 1) * nb);
+            }
             if (FFN_GE_PRIO) __builtin_amdgcn_s_setprio(FFN_GE_PRIO);
             {
                 const char* bs = smem + BIAS_OFF + (cc & 1) * BIAS_BYTES;
@@ -478,12 +528,31 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 }
             }
             if (FFN_GE_PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (F32X && LAST) load_xf(xf1, blockIdx.x + (ti + 1) * nb, 1);
             FTP(0, 13);              // GEGLU done, H written
             // tile-end barrier: in this iteration the Y-waves finished a tile (its last chunk is cc - 1) and stage its
             // epilogue in the W2 buffer, which every Y-wave must have stopped reading first
             if (c == 0 && cc >= 1) slot_barrier();
-            if (++c == NCH) { c = 0; ++ti; }
+        };
+        using L0 = std::integral_constant<bool, false>; using L1 = std::integral_constant<bool, true>;
+        if constexpr (F32X) {
+            int cc = 0;
+            for (ti = 0; ti < ntl; ++ti) {
+                normalize_xf(xf0, 0); normalize_xf(xf1, 1);
+                for (c = 0; c < NCH - 1; ++c, ++cc) chunk(cc, L0{});
+                chunk(cc, L1{});
+                ++cc;
+            }
+        } else {
+            for (int cc = 0; cc < NC; ++cc) {
+                if (c == 0 && p.ln) normalize_x();
+                chunk(cc, L0{});
+                if (++c == NCH) { c = 0; ++ti; }
+            }
         }
+        // drain: the Y-waves finish the last chunk (+ the tile-end barrier, see above)
+#pragma unroll
+        for (int i = 0; i < NKT + 2; ++i) slot_barrier();
 #ifdef WIW_FFN_TRACE
         if (trace_blk) for (int i = 0; i < 64; ++i) g_ftrace[0][i] = *(volatile long long*)(smem + SMEM + i * 8);
 #endif
@@ -724,6 +793,11 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                                             __builtin_nontemporal_store(pack2bf(v[0], v[1]), d);
                                             __builtin_nontemporal_store(pack2bf(v[2], v[3]), d + 1);
                                         }
+                                        if (p.out16) {     // the rounded copy a 16-bit consumer (the fused temporal block) reads
+                                            uint32_t* d = (uint32_t*)(p.out16 + (int64_t)m * p.ldo16 + n);
+                                            __builtin_nontemporal_store(pack2bf(v[0], v[1]), d);
+                                            __builtin_nontemporal_store(pack2bf(v[2], v[3]), d + 1);
+                                        }
                                     }
                                 }
                             }
@@ -758,11 +832,11 @@ extern "C" int wiw_ffn_hwid_read(unsigned* out) {
 #endif
 
 namespace {
-template <bool F32E>
+template <bool F32E, bool F32X = false>
 int ffn_launch(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
                const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
                int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
-               int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps, int f32) {
+               int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps, int f32, void* out16 = nullptr, int ldo16 = 0) {
     WIW_REQUIRE(X && W1 && b1 && W2 && out, "ffn_geglu: null X / W1 / b1 / W2 / out pointer");
     WIW_REQUIRE(C_in == C && hidden == HID, "ffn_geglu: built for C = 320, hidden = 1280 (the UNet's first level); use wiw_gemm_bf16 elsewhere");
     WIW_REQUIRE(M > 0 && M < (1ll << 31) - BM, "ffn_geglu: bad M");
@@ -773,11 +847,14 @@ int ffn_launch(void* stream, const void* X, int ldx, const void* W1, const float
     WIW_REQUIRE((((uintptr_t)X | (uintptr_t)W1 | (uintptr_t)b1 | (uintptr_t)W2 | (uintptr_t)b2 | (uintptr_t)rowvec | (uintptr_t)res1 |
                   (uintptr_t)res2 | (uintptr_t)out) & 15) == 0, "ffn_geglu: pointers must be 16-byte aligned");
     WIW_REQUIRE(!ln || ln_eps > 0.0f, "ffn_geglu: the fused LayerNorm needs ln_eps > 0");
+    WIW_REQUIRE(out16 == nullptr || (F32E && ldo16 % 8 == 0 && ldo16 >= C && ((uintptr_t)out16 & 15) == 0),
+                "ffn_geglu: out16 needs the f32stream entry, ldo16 a multiple of 8 and >= 320, 16-byte alignment");
+    WIW_REQUIRE(!F32X || ln, "ffn_geglu: an fp32 X is read by the fused LayerNorm only (ln != 0)");
     static std::once_flag once;
     static bool attr_ok = false;
     static int num_cu = 256;
     std::call_once(once, [] {
-        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel<F32E>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_LAUNCH) == hipSuccess;
+        attr_ok = hipFuncSetAttribute((const void*)ffn_kernel<F32E, F32X>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_LAUNCH) == hipSuccess;
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -793,9 +870,10 @@ int ffn_launch(void* stream, const void* X, int ldx, const void* W1, const float
     a.M = (int)M; a.ldx = ldx; a.ldo = ldo; a.ldr1 = ldr1; a.ldr2 = ldr2; a.rowvec_ld = rowvec_ld;
     a.rows_per_vec = rows_per_vec > 0 ? rows_per_vec : 1; a.ln = ln;
     a.alpha = alpha; a.beta1 = beta1; a.beta2 = beta2; a.ln_eps = ln_eps; a.f32 = f32;
+    a.out16 = (uint16_t*)out16; a.ldo16 = ldo16;
     const int tiles = (int)((M + BM - 1) / BM);
     const int grid = tiles < num_cu ? tiles : num_cu;
-    hipLaunchKernelGGL(ffn_kernel<F32E>, dim3((unsigned)grid), dim3(512), SMEM_LAUNCH, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((ffn_kernel<F32E, F32X>), dim3((unsigned)grid), dim3(512), SMEM_LAUNCH, (hipStream_t)stream, a);
     return wiw_check_launch("wiw_ffn_geglu_bf16");
 }
 }  // namespace
@@ -816,4 +894,19 @@ extern "C" int wiw_ffn_geglu_f32stream(void* stream, const void* X, int ldx, con
     WIW_REQUIRE(f32 >= 0 && f32 < 8, "ffn_geglu_f32stream: f32 is a 3-bit mask (out, res1, res2)");
     return ffn_launch<true>(stream, X, ldx, W1, b1, W2, b2, rowvec, rowvec_ld, rows_per_vec, res1, ldr1, beta1, res2, ldr2, beta2,
                             alpha, out, ldo, M, C_in, hidden, ln, ln_eps, f32);
+}
+
+// ABI 16: ... and with the fp32 stream on the INPUT side too — f32 bit 3: X is fp32 [M][ldx] (then ln != 0: the fused LayerNorm
+// reads it; ldx in elements, a multiple of 4) — and an optional second output `out16` [M][ldo16], the 16-bit rounding of `out`
+extern "C" int wiw_ffn_geglu_f32stream2(void* stream, const void* X, int ldx, const void* W1, const float* b1, const void* W2,
+                                        const float* b2, const float* rowvec, int rowvec_ld, int rows_per_vec, const void* res1,
+                                        int ldr1, float beta1, const void* res2, int ldr2, float beta2, float alpha, void* out,
+                                        int ldo, int64_t M, int C_in, int hidden, int ln, float ln_eps, int f32, void* out16,
+                                        int ldo16) {
+    WIW_REQUIRE(f32 >= 0 && f32 < 16, "ffn_geglu_f32stream2: f32 is a 4-bit mask (out, res1, res2, X)");
+    if (f32 & 8)
+        return ffn_launch<true, true>(stream, X, ldx, W1, b1, W2, b2, rowvec, rowvec_ld, rows_per_vec, res1, ldr1, beta1, res2, ldr2,
+                                      beta2, alpha, out, ldo, M, C_in, hidden, ln, ln_eps, f32 & 7, out16, ldo16);
+    return ffn_launch<true>(stream, X, ldx, W1, b1, W2, b2, rowvec, rowvec_ld, rows_per_vec, res1, ldr1, beta1, res2, ldr2, beta2,
+                            alpha, out, ldo, M, C_in, hidden, ln, ln_eps, f32, out16, ldo16);
 }

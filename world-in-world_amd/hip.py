@@ -122,6 +122,9 @@ EXPORTS = {
     "wiw_ffn_geglu_f32stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "wiw_ffn_geglu_f32stream2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]),
     "wiw_clip_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -222,7 +225,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 15:
+        if self.lib.wiw_abi_version() != 16:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -376,16 +379,27 @@ class Hip:
         return O
 
     def ffn_geglu(self, X, W1, b1, W2, b2, out, M, *, ldx=FFN_C, rowvec=None, rowvec_ld=0, rows_per_vec=1, res1=None, ldr1=0,
-                  beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0, ldo=FFN_C, ln=False, ln_eps=1e-5):
+                  beta1=0.0, res2=None, ldr2=0, beta2=0.0, alpha=1.0, ldo=FFN_C, ln=False, ln_eps=1e-5, out16=None):
         """Fused (LayerNorm +) GEGLU FeedForward of the 320-channel level (ffn.hip): the [M, 1280] hidden tensor never
-        exists.  W1 / b1 packed by `unet.pack_geglu(..., tile=FFN_CHUNK)` (+ TiledW), W2 a TiledW of [320, 1280]."""
+        exists.  W1 / b1 packed by `unet.pack_geglu(..., tile=FFN_CHUNK)` (+ TiledW), W2 a TiledW of [320, 1280].
+        ABI 16: an fp32 X (the residual stream itself; needs ln=True) and `out16`, a second 16-bit copy of the output."""
         flops = 2.0 * M * (2 * FFN_HIDDEN * FFN_C + FFN_C * FFN_HIDDEN)
-        nbytes = 2.0 * M * FFN_C * (2 + (res1 is not None) + (res2 is not None)) + 2.0 * 3 * FFN_HIDDEN * FFN_C
+        el = lambda t: 0 if t is None else t.element_size()   # noqa: E731
+        nbytes = 1.0 * M * FFN_C * (el(X) + el(out) + el(res1) + el(res2) + el(out16)) + 2.0 * 3 * FFN_HIDDEN * FFN_C
 
         f32 = ((out.dtype == torch.float32) * 1 + (res1 is not None and res1.dtype == torch.float32) * 2
-               + (res2 is not None and res2.dtype == torch.float32) * 4)
+               + (res2 is not None and res2.dtype == torch.float32) * 4 + (X.dtype == torch.float32) * 8)
+        assert not (f32 & 8) or ln, "ffn_geglu: an fp32 X is read by the fused LayerNorm only"
+        assert out16 is None or out16.dtype == self.dtype
 
         def launch():
+            if (f32 & 8) or out16 is not None:
+                self._ck(self.lib.wiw_ffn_geglu_f32stream2(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec),
+                                                           rowvec_ld, rows_per_vec, _p(res1), ldr1, beta1, _p(res2), ldr2, beta2,
+                                                           alpha, _p(out), ldo, M, FFN_C, FFN_HIDDEN, 1 if ln else 0, ln_eps, f32,
+                                                           _p(out16), FFN_C if out16 is not None else 0),
+                         "wiw_ffn_geglu_f32stream2")
+                return
             if f32:      # fp32 residual stream: the F32E instantiation (fragment-layout epilogue, one rounding)
                 self._ck(self.lib.wiw_ffn_geglu_f32stream(self._stream(), _p(X), ldx, _p(W1), _p(b1), _p(W2), _p(b2), _p(rowvec),
                                                           rowvec_ld, rows_per_vec, _p(res1), ldr1, beta1, _p(res2), ldr2, beta2,

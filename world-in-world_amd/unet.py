@@ -189,16 +189,20 @@ class UNetHIP:
         self.sdt = torch.float32 if self.res32 else self.dtype      # dtype of residual-stream tensors
         if self.res32:
             self.ln_fold = False          # the folds read the raw stream as a 16-bit MFMA operand
-            self.temporal_unfused = True  # LayerNorm (fp32 in) + QKV GEMM + attention core
+            # round 6: the fused temporal block runs in this mode too — on the 16-bit ROUNDING of the fp32 stream tensor, which
+            # its producer writes beside it (wiw_ffn_geglu_f32stream2's out16 at C = 320, a cast pass elsewhere).  A/B knob:
+            # WIW_TEMPORAL_UNFUSED_RES32=1 = LayerNorm (fp32 in) + QKV GEMM + attention core, as rounds 4-5
+            self.temporal_unfused = self.temporal_unfused or bool(os.environ.get("WIW_TEMPORAL_UNFUSED_RES32"))
         # convolution weights with K in channel-block-major order (round 4: the taps of a 64-channel block re-read the same
         # activation window while it is still in L2; A/B knob WIW_K_TAPMAJOR=1 keeps the tap-major order)
         self.kc = 0 if os.environ.get("WIW_K_TAPMAJOR") else K_CMAJOR
         self.halo = not os.environ.get("WIW_CONV_NO_HALO")      # A/B knob: 3x3 convolutions without the halo-staged kernel
         self.halo_sc = not os.environ.get("WIW_CONV_NO_HALO_SC")  # A/B knob: ... except those with the fused shortcut segment
-        # (fp32 stream: the fused kernel's F32E epilogue takes the fp32 residual / output; its in-kernel LayerNorm reads a
-        # 16-bit x, so there the norm stays the f32in LayerNorm pass)
+        # (fp32 stream: the fused kernel's F32E epilogue takes the fp32 residual / output; round 6, ABI 16: its in-kernel
+        # LayerNorm reads the fp32 x itself — A/B knob WIW_FFN_NO_LN_RES32=1 keeps the f32in LayerNorm pass in front)
         self.ffn_fused = not os.environ.get("WIW_FF_UNFUSED") and not (self.res32 and os.environ.get("WIW_FF_UNFUSED_RES32"))
-        self.ffn_ln = self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN") and not self.res32
+        self.ffn_ln = (self.ffn_fused and not os.environ.get("WIW_FFN_NO_LN")
+                       and not (self.res32 and os.environ.get("WIW_FFN_NO_LN_RES32")))
         # round 5: the 32x32x16-MFMA form of the fused FeedForward (csrc/ffn32.hip) — correct and bit-repeatable, but NOT faster
         # than ffn.hip at M = 258 048 (805 vs 804 us: both sit on the same serial sum of MFMA + GEGLU + weight DMA + LDS time,
         # profiles/r13b_*): opt-in A/B knob, ffn.hip stays the served kernel
@@ -460,11 +464,15 @@ class UNetHIP:
         h = self._linear(x_bf16, p + ".linear_1", M, silu=True)
         return self._linear(h, p + ".linear_2", M, out_f32=True)
 
-    def _geglu_ff(self, a, p, M, Cn, ln_input=None, stream=True, **epi_kw):
+    def _geglu_ff(self, a, p, M, Cn, ln_input=None, stream=True, want16=False, **epi_kw):
         """FeedForward with GEGLU (attention.py:1185-1243): returns GEMM2 output with the given epilogue.
         ln_input: the RAW input of the LayerNorm in front of this FeedForward — given instead of `a` (= None) where the
         norm is folded into the projection (`_fold_ln`).  stream: the output is a residual-stream tensor (fp32 when
-        `residual_fp32`); False for the AlphaBlender output that only feeds proj_out as an MFMA operand."""
+        `residual_fp32`); False for the AlphaBlender output that only feeds proj_out as an MFMA operand.
+        want16 (fp32 stream only): also return the output's 16-bit rounding -> (out, out16); written by the fused kernel's
+        epilogue at C = 320 (ABI 16), by a cast pass behind the second GEMM elsewhere."""
+        if want16:
+            assert self.res32 and stream
         if (p + ".ffn.w1") in self.w:     # C = 320: ONE kernel, the [M, 4C] hidden tensor never exists (ffn.hip)
             ln = ln_input is not None
             assert not ln or (p + ".ffn.w1ln") in self.w
@@ -472,13 +480,15 @@ class UNetHIP:
             kw = {k: v for k, v in epi_kw.items() if k in ("rowvec", "rowvec_ld", "rows_per_vec", "res1", "ldr1", "beta1",
                                                            "res2", "ldr2", "beta2", "alpha")}
             assert len(kw) == len(epi_kw), f"unsupported FeedForward epilogue arguments: {set(epi_kw) - set(kw)}"
-            if (p + ".ffn32") in self.w:      # opt-in (WIW_FFN32=1): the 32x32x16 form
+            if (p + ".ffn32") in self.w and not self.res32:      # opt-in (WIW_FFN32=1): the 32x32x16 form
                 W1s, b1s, W2s = self.w[p + (".ffn32ln" if ln else ".ffn32")]
                 return self.hip.ffn32_geglu(ln_input if ln else a, W1s, b1s, W2s, self.w[p + ".net.2.bias"], out, M, ln=ln,
                                             ln_eps=1e-5, **kw)
-            return self.hip.ffn_geglu(ln_input if ln else a, self.w[p + (".ffn.w1ln" if ln else ".ffn.w1")],
-                                      self.w[p + (".ffn.b1ln" if ln else ".ffn.b1")], self.w[p + ".net.2.weight"],
-                                      self.w[p + ".net.2.bias"], out, M, ln=ln, ln_eps=1e-5, **kw)
+            o16 = self._empty(M, Cn) if want16 else None
+            self.hip.ffn_geglu(ln_input if ln else a, self.w[p + (".ffn.w1ln" if ln else ".ffn.w1")],
+                               self.w[p + (".ffn.b1ln" if ln else ".ffn.b1")], self.w[p + ".net.2.weight"],
+                               self.w[p + ".net.2.bias"], out, M, ln=ln, ln_eps=1e-5, out16=o16, **kw)
+            return (out, o16) if want16 else out
         g = self._empty(M, 4 * Cn)
         if ln_input is not None:
             W1 = self.w[p + ".net.0.proj.lnfold.weight"]
@@ -491,8 +501,9 @@ class UNetHIP:
         W2 = self.w[p + ".net.2.weight"]
         f32 = stream and self.res32
         out = self._empty(M, Cn, dtype=torch.float32 if f32 else self.dtype)
-        return self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"],
-                             epilogue=EPI_OUT_F32 if f32 else 0, **epi_kw)
+        self.hip.gemm(g, W2, out, M=M, N=Cn, K=4 * Cn, C1=4 * Cn, bias=self.w[p + ".net.2.bias"],
+                      epilogue=EPI_OUT_F32 if f32 else 0, **epi_kw)
+        return (out, self.hip.cast16(out)) if want16 else out
 
     # ------------------------------------------------------------------------------------------
     # request-level (step-invariant) conditioning
@@ -618,7 +629,7 @@ class UNetHIP:
         fold_ff = ((b + ".ff.net.0.proj.lnfold.weight") in w or (b + ".ff.ffn.w1ln") in w) and not legacy
         a = xn
         if self.res32:
-            assert not (fold_qkv or fold_ff or legacy), "A/B knobs of the 16-bit stream"
+            assert not (fold_qkv or legacy), "A/B knobs of the 16-bit stream"
         if not fold_qkv:
             a = hip.layernorm(h, M, Cn, w[b + ".norm1.weight"], w[b + ".norm1.bias"], out=xn)
         vt = self._empty(Cn, M)
@@ -662,11 +673,15 @@ class UNetHIP:
             a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
                               addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
-        hm = self._geglu_ff(a, t + ".ff_in", M, Cn, ln_input=hm if (fold_ff and fold_emb) else None, res1=hm, ldr1=Cn, beta1=1.0)
-        if T <= 14 and not self.temporal_unfused and M * Cn * 2 < (1 << 32):
+        t_fused = T <= 14 and not self.temporal_unfused and M * Cn * 2 < (1 << 32)
+        hm = self._geglu_ff(a, t + ".ff_in", M, Cn, ln_input=hm if (fold_ff and fold_emb) else None, res1=hm, ldr1=Cn, beta1=1.0,
+                            want16=self.res32 and t_fused)
+        if t_fused:
             # norm1 + to_q/k/v + the 14x14 attention in ONE kernel (temporal.hip): LayerNorm folded into the projection,
-            # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor
-            hip.temporal_attn_block(hm, w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"], o, Cn, batch, T, S,
+            # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor.  (fp32 stream: the kernel reads the
+            # stream tensor's 16-bit rounding, written beside it by its producer.)
+            hm, hm16 = hm if self.res32 else (hm, hm)
+            hip.temporal_attn_block(hm16, w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"], o, Cn, batch, T, S,
                                     heads, 1e-5, scale)
         else:
             a = hip.layernorm(hm, M, Cn, w[t + ".norm1.weight"], w[t + ".norm1.bias"], out=a)
