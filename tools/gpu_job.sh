@@ -4,11 +4,12 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-# r19b: the fp32-stream mode on the fused kernels (ffn LayerNorm on fp32 X, out16 -> fused temporal block): parity, then A/B
-timeout 1500 python -m pytest tests/test_hip_ffn.py tests/test_hip_res32.py tests/test_hip_temporal_block.py -q -m gpu -rP -x > $O/${TAG}_tests.log 2>&1
-grep -n "passed\|failed\|rror" $O/${TAG}_tests.log | tail -5; grep "\[tolerance\]" $O/${TAG}_tests.log | cut -c1-330
+# r19c: the cooperative one-read GroupNorm (ABI 16): parity / bit-identity first, then the same-box A/B
+timeout 300 python -m pytest tests/test_hip_kernels.py -q -m gpu -rP -x -k "groupnorm" > $O/${TAG}_gn_tests.log 2>&1
+grep -n "passed\|failed\|rror" $O/${TAG}_gn_tests.log | tail -5
+timeout 300 python -m pytest tests/test_hip_res32.py -q -m gpu -x -k "cooperative or kernels_on_fp32 or groupnorm" 2>&1 | tail -3
 B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
-for cfg in "A:--dtype fp16:" "B:--dtype fp16 --residual-fp32:" "C:--dtype fp16 --residual-fp32:WIW_TEMPORAL_UNFUSED_RES32=1" "D:--dtype fp16 --residual-fp32:WIW_FFN_NO_LN_RES32=1" "E:--dtype fp16 --residual-fp32:WIW_TEMPORAL_UNFUSED_RES32=1 WIW_FFN_NO_LN_RES32=1"; do
+for cfg in "A::" "B::WIW_GN_COOP=0" "C:--dtype fp16 --residual-fp32:" "D:--dtype fp16 --residual-fp32:WIW_GN_COOP=0" "E:--dtype fp16:"; do
   IFS=: read name flags envs <<< "$cfg"
   env $envs timeout 400 $B $flags 2>/dev/null | tail -1 > $O/${TAG}_bench_$name.json
   python - "$O/${TAG}_bench_$name.json" "$name $flags $envs" <<'PY'

@@ -464,14 +464,18 @@ class Hip:
         # The last-block-done reduction (norm.hip) needs its counters at zero before a launch and leaves them at zero: two
         # statistics launches must never overlap on ONE counter buffer.  Launches of one stream are ordered, so the buffer is
         # keyed by stream (the VAE shares this Hip with the UNet; a capture's warm-up runs on a side stream) — ADVICE r4.
+        cnt = self._gn_counter_row()
+        assert int(self.lib.wiw_groupnorm_counters(rows, rows_per_unit, rpb)) <= cnt.numel(), "groupnorm: more parts than counters"
+        buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
+        return buf[: units * 64], buf[units * 64:], cnt
+
+    def _gn_counter_row(self):
         cnt = self._gn_cnt.get(self._stream())
         if cnt is None:
             if len(self._gn_cnt) >= self._gn_cnt_pool.shape[0]:
                 raise RuntimeError("groupnorm: more streams than counter rows (Hip._gn_cnt_pool)")
             cnt = self._gn_cnt[self._stream()] = self._gn_cnt_pool[len(self._gn_cnt)]
-        assert int(self.lib.wiw_groupnorm_counters(rows, rows_per_unit, rpb)) <= cnt.numel(), "groupnorm: more parts than counters"
-        buf = torch.empty(units * 64 + n, dtype=torch.float32, device=self.device)
-        return buf[: units * 64], buf[units * 64:], cnt
+        return cnt
 
     def gn_counters_clean(self) -> bool:
         """Debug check (tests): every statistics launch left its counters at zero."""
