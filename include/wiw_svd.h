@@ -51,7 +51,7 @@ extern "C" {
                              14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling)
                                 15: wiw_groupnorm_onepass / wiw_groupnorm_onepass_ok (one-pass GroupNorm of the inner levels);
                              16: wiw_ffn_geglu_f32stream2 (the fused FeedForward's LayerNorm reads the fp32 stream; a second,
-                                 16-bit output) */
+                                 16-bit output); wiw_cross_attn_fewkeys_bf16 (cross-attention over 2..8 conditioning tokens) */
 
 int wiw_abi_version(void);
 
@@ -337,6 +337,19 @@ int wiw_groupnorm_apply_stats_f32in(void* stream, const float* X1, int C1, const
 int wiw_groupnorm_onepass_ok(int C1, int C2, int64_t rows, int rows_per_unit);
 int wiw_groupnorm_onepass(void* stream, const void* X1, int C1, const void* X2, int C2, int64_t rows, int rows_per_unit,
                           const float* gamma, const float* beta, float eps, int silu, void* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABI 16: cross-attention over a FEW keys — BasicTransformerBlock.attn2 (dp/models/attention.py:545-551) and
+ * TemporalBasicTransformerBlock.attn2 (:740-743) through AttnProcessor2_0 (attention_processor.py:2358-2391) when the
+ * conditioning holds P > 1 tokens per candidate (--num_past_obs > 1: train_svd.py:359, 889-894; pipeline_stable_video_
+ * diffusion.py:500-508).  Replaces F.scaled_dot_product_attention(q, k, v) with Sk = P:
+ *   O[m][h*64+d] = sum_p softmax_p(Q[m][h*64:(h+1)*64] . K[m / rows_per_item][p][h*64:(h+1)*64] * scale) V[...][p][h*64+d]
+ * Q [rows][ldq], O [rows][ldo]: 16-bit token-major tensors (heads * 64 columns used); K, V: 16-bit [rows / rows_per_item][P]
+ * [heads*64] contiguous (the projections to_k / to_v of the item's P embeddings); 1 <= P <= 8, heads * 64 <= 2048; fp32
+ * softmax.  The rows of an item (T * S in this build's token order, for the spatial and the temporal block alike) share
+ * its keys.  With P = 1 the served path never calls this: the operator collapses to a vector per candidate (unet.py). */
+int wiw_cross_attn_fewkeys_bf16(void* stream, const void* Q, int ldq, const void* K, const void* V, void* O, int ldo,
+                                int64_t rows, int rows_per_item, int heads, int P, float scale);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm over the channel dim with an optional fused pre-add of a per-row-group vector:

@@ -34,6 +34,9 @@ Fixtures written (all fp32 unless noted):
   unet_northstar_72x128.npz  ONE fp32 forward of the served UNet at the BENCHMARKED size, sample (2,14,8,72,128) (`unet_northstar`, ~20 min):
                            fp32 output + the fp32-math outputs on fp16- / bf16-rounded weights as fp16 differences; inputs from a seed
   pipeline_config0_32x32.npz  BASELINE config 0 (256x256x8, 10 steps) through the same __call__, served-width UNet built for 8 frames
+  pipeline_northstar_72x128.npz  the same __call__ at the BENCHMARKED size (576x1024x14, 25 steps, fp32): the reference's latents after
+                           steps 5 / 10 / 15 / 20 / 25 (`pipeline_northstar`, ~2.5 h of 8 cores; not part of the default run)
+  unet_tiny_ctx3.npz       tiny UNet forward with THREE conditioning tokens per candidate (--num_past_obs > 1: Sk = 3 cross-attention)
 """
 import os
 import sys
@@ -226,6 +229,29 @@ def gen_unet(ns):
     save("unet_tiny_b2.npz", weight_seed=np.array(0), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
          added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out_reference_batched=out_b.numpy(),
          out_contract=contract.numpy())
+
+
+def gen_unet_ctx3(ns):
+    """--num_past_obs > 1 (train_svd.py:359, 889-894; pipeline_stable_video_diffusion.py:500-508): the reference UNet forward
+    with THREE conditioning tokens per candidate, encoder_hidden_states (2, 3, 1024) — the general Sk > 1 form of both
+    cross-attentions of every transformer layer (attention.py:545-551, 740-743).  Tiny UNet, weights seed 0, B = 1 with CFG;
+    the uncond half carries zero tokens (pipeline:221-227: zeros_like of the embeddings)."""
+    cfg = UNetConfig.tiny(4)
+    m = ref_unet(ns, cfg, seed=0)
+    h, w = 16, 32
+    t = 1.0640485
+    sample, _, tids, acts = unet_inputs(cfg, 1, h, w, seed=5)
+    rs = np.random.RandomState(6)
+    ehs = rs.standard_normal((2, 3, cfg.cross_attention_dim)).astype(np.float32) * 1.5   # un-normalised scale: the softmax is not flat
+    ehs[:1] = 0
+    aid = ns.get_action_ids(1, torch.from_numpy(acts), "micro_cond", torch.float32)
+    with torch.no_grad():
+        out = m(torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs), torch.from_numpy(tids),
+                return_dict=False, added_action_ids=aid)[0]
+        out1 = m(torch.from_numpy(sample), torch.tensor(t), torch.from_numpy(ehs[:, :1].copy()), torch.from_numpy(tids),
+                 return_dict=False, added_action_ids=aid)[0]
+    save("unet_tiny_ctx3.npz", weight_seed=np.array(0), timestep=np.array(t, dtype=np.float32), sample=sample, ehs=ehs,
+         added_time_ids=tids, actions=acts, action_ids=aid.numpy(), out=out.numpy(), out_first_token_only=out1.numpy())
 
 
 def gen_unet_full(ns):
@@ -687,7 +713,7 @@ def main():
     gens = dict(scheduler=gen_scheduler, action_ids=gen_action_ids, noise_rotation=gen_noise_rotation, unet=gen_unet,
                 pipeline=gen_pipeline, frontend=gen_frontend, unet_full=gen_unet_full, schema=gen_schema, ema=gen_ema,
                 pipeline_full=gen_pipeline_full, pipeline_config0=gen_pipeline_config0, manip=gen_manip,
-                unet_northstar=gen_unet_northstar, pipeline_northstar=gen_pipeline_northstar)
+                unet_northstar=gen_unet_northstar, pipeline_northstar=gen_pipeline_northstar, unet_ctx3=gen_unet_ctx3)
     only = [a for a in sys.argv[1:] if a in gens]   # e.g. `make_golden.py unet_full`; default: everything but the 2-hour one
     for name, fn in gens.items():
         if name in only or (not only and name != "pipeline_northstar"):

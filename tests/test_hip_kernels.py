@@ -294,6 +294,32 @@ def test_attn_temporal(hip, B, T, S, heads):
     check(o.reshape(B, T, S, C), ref, max_tol=2e-2, rms_tol=8e-3, what=f"attn_temporal T={T} S={S} h={heads}")
 
 
+@pytest.mark.parametrize("heads,P,items,rpi", [(5, 3, 3, 1000), (5, 1, 2, 257), (10, 8, 2, 2304), (20, 2, 4, 144), (5, 5, 2, 14 * 576)])
+def test_cross_attention_over_a_few_keys(hip, heads, P, items, rpi):
+    """`wiw_cross_attn_fewkeys_bf16` (ABI 16, csrc/cross_attn.hip): softmax(Q K^T / 8) V with Sk = P conditioning tokens per
+    item, the rows of an item sharing its keys — against torch's fp32 attention on the same 16-bit operands; strided Q / O;
+    bit-repeatable; P outside 1..8 refused."""
+    C = heads * 64
+    rows = items * rpi
+    q = bf(rnd(rows, C + 64, seed=1, scale=1.5))
+    k, v = bf(rnd(items, P, C, seed=2, scale=1.2)), bf(rnd(items, P, C, seed=3))
+    o = torch.full((rows, C + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qd = dev_bf(q)
+    hip.cross_attn_fewkeys(qd, C + 64, dev_bf(k), dev_bf(v), o, C + 8, rows, rpi, heads, P, 0.125)
+    qh = q[:, :C].reshape(items, rpi, heads, 64).permute(0, 2, 1, 3)
+    kh, vh = (t.reshape(items, P, heads, 64).permute(0, 2, 1, 3) for t in (k, v))
+    w = torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (w @ vh).permute(0, 2, 1, 3).reshape(rows, C)
+    check(o[:, :C], ref, max_tol=1.2e-2, rms_tol=3e-3, what=f"cross attention heads={heads} P={P} items={items} rows/item={rpi}")
+    assert torch.isnan(o[:, C:].float()).all(), "columns beyond heads * 64 must not be written"
+    o2 = torch.empty_like(o)
+    hip.cross_attn_fewkeys(qd, C + 64, dev_bf(k), dev_bf(v), o2, C + 8, rows, rpi, heads, P, 0.125)
+    assert torch.equal(o[:, :C], o2[:, :C])
+    s = torch.cuda.current_stream().cuda_stream
+    assert hip.lib.wiw_cross_attn_fewkeys_bf16(s, qd.data_ptr(), C + 64, qd.data_ptr(), qd.data_ptr(), o.data_ptr(), C + 8, rows, rpi,
+                                               heads, 9, 0.125) != 0 and b"P <= 8" in hip.lib.wiw_last_error()
+
+
 # ----------------------------------------------------------------------------------------------
 # normalisation
 # ----------------------------------------------------------------------------------------------

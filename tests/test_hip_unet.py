@@ -167,13 +167,50 @@ def test_unet_with_folded_layernorms(tiny, golden):
     assert np.isfinite(out).all() and rms <= rms_ref and mx <= 1.25 * mx_ref
 
 
-def test_more_than_one_conditioning_embedding_is_refused(tiny):
-    """The cross-attention is the closed form for ONE key; (B, P > 1, D) embeddings of a --num_past_obs > 1 checkpoint must
-    raise, not be flattened into a mis-shaped vector (pipeline_stable_video_diffusion.py:501-504)."""
+def test_more_conditioning_embeddings_than_the_replica_was_built_for_are_refused(tiny):
+    """The served cross-attention is the closed form for ONE key; (B, P > 1, D) embeddings of a --num_past_obs > 1 checkpoint
+    need a replica built with num_past_obs = P (the general attention, below) — a replica built for one token must raise, not
+    flatten P tokens into a mis-shaped vector (pipeline_stable_video_diffusion.py:501-504)."""
     cfg, sd, unet = tiny(0)
     ie = torch.zeros(1, 2, cfg.cross_attention_dim)
     with pytest.raises(NotImplementedError, match="num_past_obs"):
         unet.prepare_request(ie, np.zeros((1, cfg.num_frames, cfg.action_input_channel), np.float32))
     sample = torch.zeros(2, cfg.num_frames, 8, 16, 32)
-    with pytest.raises(NotImplementedError, match="single-key"):
+    with pytest.raises(NotImplementedError, match="num_past_obs"):
         unet(sample, 1.0, torch.zeros(2, 2, cfg.cross_attention_dim), torch.zeros(2, 3), torch.zeros(1, cfg.num_frames, cfg.action_input_channel))
+
+
+@pytest.mark.parametrize("name", ["bf16", "fp16", "fp16+res32"])
+def test_unet_with_three_conditioning_tokens_against_the_reference(name, golden):
+    """--num_past_obs > 1 (train_svd.py:359, 889-894): encoder_hidden_states (2, 3, 1024), i.e. Sk = 3 in both cross-attentions of
+    every transformer layer (attention.py:545-551, 740-743) — `UNetHIP(num_past_obs=3)` on `wiw_cross_attn_fewkeys_bf16` against
+    the REFERENCE's forward (tests/golden/unet_tiny_ctx3.npz).  A replica built for three tokens also serves one (same bytes
+    as the closed form of a one-token replica), and the three-token result is NOT what the first token alone gives."""
+    import wiw_amd  # noqa: F401
+    from wiw_amd.config import UNetConfig
+    from wiw_amd.hip import Hip
+    from wiw_amd.unet import UNetHIP
+    from wiw_amd.weights import random_state_dict
+
+    g = golden("unet_tiny_ctx3.npz")
+    g1 = golden("unet_tiny_b1.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = random_state_dict(cfg, int(g["weight_seed"]))
+    dt = torch.bfloat16 if name == "bf16" else torch.float16
+    hip = Hip(torch.device(DEV), dt)
+    unet3 = UNetHIP(cfg, sd, DEV, hip=hip, num_past_obs=3, residual_fp32=name.endswith("res32"))
+    out = _run_unet(unet3, g)
+    mx, rms = rel(out, g["out"])
+    mx_ref, rms_ref = rel(g1["out_ref_bf16"], g1["out"])          # the reference's own bf16 run of this tiny network: the yardstick
+    far = rel(g["out_first_token_only"], g["out"])[1]
+    print(f"[parity] unet tiny, 3 conditioning tokens ({name}): max_rel={mx:.3e} rms_rel={rms:.3e} | reference bf16 yardstick "
+          f"{mx_ref:.3e} {rms_ref:.3e} | first token alone is {far:.3e} away")
+    assert np.isfinite(out).all() and rms <= rms_ref and mx <= 1.25 * mx_ref
+    assert far > 4 * rms, "the fixture must tell one token from three"
+    if name == "bf16":
+        unet1 = UNetHIP(cfg, sd, DEV, hip=hip)
+        a, b = _run_unet(unet1, g1), _run_unet(unet3, g1)
+        assert np.array_equal(a, b), "one token on a replica built for three: the closed form, same bytes"
+        with pytest.raises(NotImplementedError, match="num_past_obs"):
+            unet3(torch.zeros(2, cfg.num_frames, 8, 16, 32), 1.0, torch.zeros(2, 4, cfg.cross_attention_dim), torch.zeros(2, 3),
+                  torch.zeros(1, cfg.num_frames, cfg.action_input_channel))

@@ -77,6 +77,21 @@ def test_unet_b1(golden):
     assert 1e-4 < _rel(g["out_ref_bf16"], g["out"]) < 0.2
 
 
+def test_unet_three_conditioning_tokens(golden):
+    """--num_past_obs > 1: the oracle's cross-attention is the general one; pinned to the reference's forward with
+    encoder_hidden_states (2, 3, 1024) (tests/golden/unet_tiny_ctx3.npz)."""
+    g = golden("unet_tiny_ctx3.npz")
+    cfg = UNetConfig.tiny(4)
+    sd = _sd(cfg, g["weight_seed"])
+    assert g["ehs"].shape[1] == 3
+    args = (torch.from_numpy(g["sample"]), torch.tensor(float(g["timestep"])))
+    tail = (torch.from_numpy(g["added_time_ids"]), torch.from_numpy(g["action_ids"]))
+    out = O.unet_forward(sd, cfg.as_dict(), *args, torch.from_numpy(g["ehs"]), *tail)
+    assert _rel(out.numpy(), g["out"]) < 5e-5
+    one = O.unet_forward(sd, cfg.as_dict(), *args, torch.from_numpy(g["ehs"][:, :1].copy()), *tail)
+    assert _rel(one.numpy(), g["out_first_token_only"]) < 5e-5 and _rel(g["out_first_token_only"], g["out"]) > 1e-3
+
+
 def test_unet_b2_contract_and_quirk(golden):
     g = golden("unet_tiny_b2.npz")
     cfg = UNetConfig.tiny(4)

@@ -210,7 +210,8 @@ def test_cli_accepts_the_reference_launcher_arguments():
 
 
 def test_unsupported_configurations_are_refused_at_startup():
-    """--num_past_obs > 1 (Sk > 1 cross-attention is not built) and action-embedder widths the task cannot produce fail when
+    """--num_past_obs > 1 (the wire protocol carries one conditioning image per candidate: the reference's served path asserts
+    there are no past observations) and action-embedder widths the task cannot produce fail when
     the worker is BUILT, not at the first client request."""
     from wiw_amd.server.worker import validate_args
 

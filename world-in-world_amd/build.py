@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwiwsvd.so")
 LIB_F16 = os.path.join(HERE, "libwiwsvd_f16.so")
 VARIANTS = [(LIB, "build", []), (LIB_F16, "build_f16", ["-DWIW_F16=1"])]
-SOURCES = ["gemm.hip", "gemm_huge.hip", "ffn.hip", "ffn32.hip", "attention.hip", "attention32.hip", "temporal.hip", "clip.hip", "norm.hip", "elementwise.hip", "vae.hip", "train.hip"]
+SOURCES = ["gemm.hip", "gemm_huge.hip", "ffn.hip", "ffn32.hip", "attention.hip", "attention32.hip", "cross_attn.hip", "temporal.hip", "clip.hip", "norm.hip", "elementwise.hip", "vae.hip", "train.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file extras: the attention softmax never sees NaNs (infinities are used and preserved); dropping NaN

@@ -125,6 +125,8 @@ EXPORTS = {
     "wiw_ffn_geglu_f32stream2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_float,
                                       C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int]),
+    "wiw_cross_attn_fewkeys_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                              C.c_int, C.c_int, C.c_int, C.c_float]),
     "wiw_clip_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
@@ -427,6 +429,16 @@ class Hip:
                                      _p(res1), ldr1, beta1, _p(res2), ldr2, beta2, alpha, _p(out), ldo, M, FFN_C, FFN_HIDDEN,
                                      1 if ln else 0, ln_eps, f32), "wiw_ffn32_geglu"))
         return out
+
+    def cross_attn_fewkeys(self, Q, ldq, K, V, O, ldo, rows, rows_per_item, heads, P, scale):
+        """Cross-attention over P <= 8 conditioning tokens per item (csrc/cross_attn.hip): Q / O [rows, heads*64] 16-bit,
+        K / V [rows / rows_per_item, P, heads*64] 16-bit contiguous."""
+        C_ = heads * 64
+        assert K.is_contiguous() and V.is_contiguous() and K.shape == V.shape == (rows // rows_per_item, P, C_)
+        self._timed("attn_cross", 4.0 * rows * P * C_, 4.0 * rows * C_, lambda: self._ck(
+            self.lib.wiw_cross_attn_fewkeys_bf16(self._stream(), _p(Q), ldq, _p(K), _p(V), _p(O), ldo, rows, rows_per_item, heads, P,
+                                                 scale), "wiw_cross_attn_fewkeys_bf16"))
+        return O
 
     def attn_small(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, seqs, S, Sp, heads, head_dim, scale):
         self._timed("attn_small", 4.0 * seqs * heads * S * S * head_dim, 8.0 * seqs * S * heads * head_dim, lambda: self._ck(

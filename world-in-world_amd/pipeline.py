@@ -297,7 +297,9 @@ class SVDDenoiser:
         img = image_latents.to(self.device, torch.float32).contiguous()
         cond = self.unet.prepare_request(image_embeddings, act_ids, noise_aug_strength)
         hw = h * w
-        gf = self._graph_for(B, h, w, cond) if self.use_graph else None
+        # (graphs are captured for the served conditioning of ONE token per candidate; a num_past_obs > 1 request — a different
+        # launch sequence — runs eagerly)
+        gf = self._graph_for(B, h, w, cond) if self.use_graph and cond.P == 1 else None
         if gf is not None:
             gf.load(cond)
             cond = gf.cond

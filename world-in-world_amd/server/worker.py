@@ -340,12 +340,16 @@ def build_arg_parser() -> argparse.ArgumentParser:
 
 def validate_args(args) -> None:
     """Configurations this build does not serve are refused at START-UP, not at the first client request (on every rank of
-    a sharded server): --num_past_obs > 1 (Sk > 1 cross-attention is not built, unet._require_single_key); an action
+    a sharded server): --num_past_obs > 1 — the WM-server request has no field for past observations and the reference's
+    own served path asserts there are none (eval_inference.py:236-242, 343-348: `base_img_path=pil_images` -> `past_obs_pixel is
+    None`); the general Sk > 1 cross-attention exists below the server (UNetHIP(num_past_obs=P), csrc/cross_attn.hip) for the
+    offline / training callers that build (B, P, 1024) embeddings themselves (train_svd.py:889-894); an action
     embedder width the task cannot produce (navigation: one channel per frame, get_action_ids micro_cond; manipulation: 10 =
     [norm_xyz | r6 | norm_grip] or num_frames + 9, its positional form — utils/svd_utils.py:418-457, 499-567)."""
     if args.num_past_obs != 1:
-        raise SystemExit(f"--num_past_obs {args.num_past_obs}: this build serves checkpoints conditioned on ONE past observation "
-                         f"(single-key cross-attention in closed form); Sk > 1 is not built")
+        raise SystemExit(f"--num_past_obs {args.num_past_obs}: the WM-server protocol carries ONE conditioning image per candidate "
+                         f"(the reference's served path asserts past_obs_pixel is None, eval_inference.py:236-242); P > 1 tokens are "
+                         f"served by UNetHIP(num_past_obs=P) below the server only")
     if args.task_type == "manipulation":
         ok = (10, args.num_frames + 9)
         if args.action_input_channel not in ok:

@@ -143,24 +143,27 @@ class RequestCond:
     cross: Dict[str, torch.Tensor]   # attn2 prefix -> fp32 [Bc, C]
     pos_emb: Dict[str, torch.Tensor]  # transformer prefix -> fp32 [Bc*T, C]
     pos_emb_blend: Dict[str, torch.Tensor]  # -am/(1-am) * pos_emb (AlphaBlender correction, see _transformer)
+    P: int = 1                                # conditioning tokens per candidate (--num_past_obs)
+    cross_kv: Optional[Dict[str, tuple]] = None   # P > 1: attn2 prefix -> (K, V) 16-bit [Bc, P, C] (to_k / to_v of the tokens)
 
 
-def _require_single_key(ehs: torch.Tensor) -> None:
-    """The cross-attention of this build is the CLOSED FORM for one key (softmax over a single key is 1: the output is
+def _require_single_key(ehs: torch.Tensor, max_tokens: int = 1) -> None:
+    """The served cross-attention is the CLOSED FORM for one key (softmax over a single key is 1: the output is
     to_out(to_v(embedding)), attention.py:545-551, 740-743 with the served conditioning of one CLIP embedding per
     candidate).  A checkpoint trained with --num_past_obs > 1 hands (B, P > 1, 1024) embeddings
-    (pipeline_stable_video_diffusion.py:501-504; train_svd.py:359, 889-894): that needs the general Sk > 1 attention, which is
-    not built — refuse instead of flattening P embeddings into one mis-shaped vector."""
-    if ehs.dim() != 3 or ehs.shape[1] != 1:
-        raise NotImplementedError(f"encoder_hidden_states {tuple(ehs.shape)}: this build serves ONE conditioning embedding per "
-                                  f"candidate (B, 1, D) — the single-key cross-attention in closed form; --num_past_obs > 1 "
-                                  f"checkpoints (Sk > 1) are not supported")
+    (pipeline_stable_video_diffusion.py:501-504; train_svd.py:359, 889-894): those need the general attention, which a
+    UNetHIP built with `num_past_obs = P` carries (round 6, csrc/cross_attn.hip, P <= 8) — anything else is refused instead
+    of flattening P embeddings into one mis-shaped vector."""
+    if ehs.dim() != 3 or ehs.shape[1] < 1 or ehs.shape[1] > max_tokens:
+        raise NotImplementedError(f"encoder_hidden_states {tuple(ehs.shape)}: this UNetHIP takes (B, P, D) conditioning with "
+                                  f"1 <= P <= {max_tokens} (built with num_past_obs = {max_tokens}; the general Sk > 1 "
+                                  f"cross-attention needs UNetHIP(..., num_past_obs = P), P <= 8)")
 
 
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
                  hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None,
-                 residual_fp32: Optional[bool] = None):
+                 residual_fp32: Optional[bool] = None, num_past_obs: int = 1):
         """dtype: 16-bit storage type of weights and activations (bf16, or fp16 = the reference's served default,
         eval_inference.py:294); with `hip` given, its dtype is used.
         residual_fp32: keep the RESIDUAL STREAM in fp32 (ABI 11) — the outputs x + f(x) of every ResnetBlock and transformer
@@ -170,10 +173,16 @@ class UNetHIP:
         configuration that meets north_star's 1e-3 relative error on the served architecture (DESIGN.md 5:
         oracle/precision_study.py `res32`, tests/test_hip_fp16.py).  Cost: the fused FeedForward / temporal-block kernels
         (16-bit streams) are replaced by their unfused chains and the stream's bytes double.  Default: env WIW_RES32.
+        num_past_obs: conditioning tokens per candidate the replica is built for (--num_past_obs, train_svd.py:359).  1 (every
+        launcher of the reference): the two cross-attentions of a layer in closed form.  2..8: also the weights of the general
+        form (attn2.to_q / to_k, norm2) and `wiw_cross_attn_fewkeys_bf16`; requests may then carry 1..num_past_obs tokens.
         fold_layernorm: fold norm1 / norm3 / norm_in into their consumer GEMMs at the widths the 256x160 tile serves
         (WIW_EPI_LNFOLD).  OFF by default: measured -0.7 % on the rollout (the in-kernel row statistics cost the K = 320
         GEMMs more than the four LayerNorm passes per block they replace); env WIW_LN_FOLD=1 turns it on."""
         self.cfg = cfg
+        if not 1 <= int(num_past_obs) <= 8:
+            raise ValueError(f"num_past_obs = {num_past_obs}: 1 .. 8 conditioning tokens per candidate")
+        self.max_ctx = int(num_past_obs)
         self.device = torch.device(device)
         self.hip = hip or Hip(self.device, dtype)
         self.dtype = self.hip.dtype
@@ -181,6 +190,7 @@ class UNetHIP:
         self.w: Dict[str, torch.Tensor] = {}
         self.alpha: Dict[str, float] = {}
         self.no_splitk = bool(os.environ.get("WIW_NO_SPLITK"))     # A/B knob
+        self.legacy_cross_guard = bool(os.environ.get("WIW_LN_ADDVEC"))
         self.ln_fold = bool(os.environ.get("WIW_LN_FOLD")) if fold_layernorm is None else bool(fold_layernorm)
         self.temporal_unfused = bool(os.environ.get("WIW_TEMPORAL_UNFUSED"))   # A/B knob: LayerNorm + QKV GEMM + attention
         # fused FeedForward kernel of the 320-channel level (ffn.hip); A/B knobs: WIW_FF_UNFUSED=1 -> two GEMMs again,
@@ -360,6 +370,8 @@ class UNetHIP:
                 dtype=bf)
             for q in (b, t):  # single-key cross-attention: only to_v and to_out matter (§9.3)
                 lin(q + ".attn2.to_v", bias=False); lin(q + ".attn2.to_out.0")
+                if self.max_ctx > 1:   # the general form: Q projection of the normalised stream, K projection of the tokens
+                    norm(q + ".norm2"); lin(q + ".attn2.to_q", bias=False); lin(q + ".attn2.to_k", bias=False)
             ff(b + ".ff", b + ".norm3"); ff(t + ".ff_in", t + ".norm_in"); ff(t + ".ff", t + ".norm3")
             lin(p + ".time_pos_embed.linear_1"); lin(p + ".time_pos_embed.linear_2")
             self.alpha[p] = float(torch.sigmoid(self._t(sd, p + ".time_mixer.mix_factor")).item())
@@ -517,9 +529,10 @@ class UNetHIP:
         Bc = 2 * B if cfg_batch else B
         T = cfg.num_frames
         bf = self.dtype
-        _require_single_key(image_embeddings)
-        ie = image_embeddings.reshape(B, -1).to(self.device, torch.float32)
-        ehs = torch.cat([torch.zeros_like(ie), ie]) if cfg_batch else ie
+        _require_single_key(image_embeddings, self.max_ctx)
+        P = image_embeddings.shape[1]
+        ie = image_embeddings.reshape(B * P, -1).to(self.device, torch.float32)
+        ehs = torch.cat([torch.zeros_like(ie), ie]) if cfg_batch else ie      # [Bc * P, D]: item-major, the P tokens of an item adjacent
         ehs = ehs.to(bf).contiguous()
         # actions: Fourier features -> proj -> MLP (unet:472, 274-280)
         feat = action_features(np.asarray(action_ids))
@@ -531,16 +544,20 @@ class UNetHIP:
         # noise-aug embedding (unet:484-486); same value for every CFG row
         nfeat = torch.from_numpy(sinusoid(np.full((Bc,), noise_aug_strength, np.float32), cfg.addition_time_embed_dim))
         noise = self._mlp("add_embedding_noise", nfeat.to(self.device, bf), Bc)
-        cross, pos, posb = {}, {}, {}
+        cross, pos, posb, cross_kv = {}, {}, {}, {}
         for p in self.tr_names:
             for q in (p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"):
-                v = self._linear(ehs, q + ".attn2.to_v", Bc)
-                cross[q] = self._linear(v, q + ".attn2.to_out.0", Bc, out_f32=True)
+                v = self._linear(ehs, q + ".attn2.to_v", Bc * P)
+                if P == 1:      # softmax over one key == 1: attn2(x) = to_out(to_v(token)), one vector per CFG item
+                    cross[q] = self._linear(v, q + ".attn2.to_out.0", Bc, out_f32=True)
+                else:           # K / V of the item's tokens, [Bc, P, C]: the per-step part is Q.K softmax V (csrc/cross_attn.hip)
+                    k = self._linear(ehs, q + ".attn2.to_k", Bc * P)
+                    cross_kv[q] = (k.reshape(Bc, P, -1), v.reshape(Bc, P, -1))
             pos[p] = self.pos_emb_T[p].repeat(Bc, 1).contiguous()
             am = self.alpha[p]
             posb[p] = (pos[p] * (-am / (1.0 - am))).contiguous() if abs(1.0 - am) > 1e-4 else pos[p]
         return RequestCond(B=B, Bc=Bc, act_emb=act, noise_emb=noise, ehs_bf16=ehs, cross=cross, pos_emb=pos,
-                           pos_emb_blend=posb)
+                           pos_emb_blend=posb, P=P, cross_kv=cross_kv if P > 1 else None)
 
     # ------------------------------------------------------------------------------------------
     # blocks
@@ -611,6 +628,20 @@ class UNetHIP:
             self.hip.gemm(x, w[key + ".weight"], out, M=M, N=N, K=9 * C + Ksc, C1=C, mode=mode, H=H, Wd=W,
                           bias=w[key + ".bias"], splitk=splitk, epilogue=epilogue | self.kc, **kw)
 
+    def _cross_attention(self, q, h, M, Cn, rows_per_item, heads, cond: RequestCond):
+        """x + attn2(norm2(x), tokens) with P > 1 conditioning tokens (attention.py:545-551 / 740-743): LayerNorm, Q projection,
+        the few-keys attention against the item's (K, V) of `prepare_request`, out-projection + residual.  The rows of a CFG
+        item are consecutive in this build's token order for the spatial AND the temporal block (its time_context is the
+        first frame's tokens = the item's, transformer_temporal.py:313-320), so both use rows_per_item = T * S."""
+        hip, w = self.hip, self.w
+        if self.legacy_cross_guard:
+            raise NotImplementedError("WIW_LN_ADDVEC (A/B knob of the single-key closed form) with num_past_obs > 1")
+        a2 = hip.layernorm(h, M, Cn, w[q + ".norm2.weight"], w[q + ".norm2.bias"])
+        q2 = self._linear(a2, q + ".attn2.to_q", M)
+        K, V = cond.cross_kv[q]
+        o2 = hip.cross_attn_fewkeys(q2, Cn, K, V, a2, Cn, M, rows_per_item, heads, cond.P, 1.0 / math.sqrt(64.0))
+        return self._linear(o2, q + ".attn2.to_out.0", M, res1=h, stream=True)
+
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
         """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer."""
         hip, w, T = self.hip, self.w, self.cfg.num_frames
@@ -650,6 +681,11 @@ class UNetHIP:
             h = self._linear(o, b + ".attn1.to_out.0", M, res1=h)
             a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=h, out=a)
+        elif cond.P > 1:
+            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, stream=True)
+            h = self._cross_attention(b, h, M, Cn, T * S, heads, cond)
+            if not fold_ff:
+                a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
         else:
             h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S,
                              stream=True)
@@ -692,6 +728,11 @@ class UNetHIP:
             hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm)
             a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=hm, out=a)
+        elif cond.P > 1:
+            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, stream=True)
+            hm = self._cross_attention(t, hm, M, Cn, T * S, heads, cond)
+            if not fold_ff:
+                a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
         else:
             hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S,
                               stream=True)
@@ -796,9 +837,10 @@ class UNetHIP:
         Bc, T, Cin, h, w_ = sample.shape
         B = added_action_ids.shape[0]
         assert Bc % B == 0 and T == self.cfg.num_frames
-        _require_single_key(encoder_hidden_states)
-        ehs = encoder_hidden_states.reshape(Bc, -1).to(self.device, torch.float32)
-        cond = self.prepare_request(ehs[Bc - B:].reshape(B, 1, -1), added_action_ids.cpu().numpy(),
+        _require_single_key(encoder_hidden_states, self.max_ctx)
+        P = encoder_hidden_states.shape[1]
+        ehs = encoder_hidden_states.reshape(Bc, P, -1).to(self.device, torch.float32)
+        cond = self.prepare_request(ehs[Bc - B:], added_action_ids.cpu().numpy(),
                                     float(added_time_ids[0, -1]), cfg_batch=(Bc == 2 * B))
         # the general (non-zero uncond embeds) case: overwrite the embeds prepared above
         if Bc == 2 * B and float(ehs[:B].abs().max()) != 0.0:
