@@ -4,6 +4,11 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-# r19d: the general (Sk = 2..8) cross-attention: kernel vs torch, UNetHIP(num_past_obs=3) vs the reference fixture
-timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_hip_unet.py tests/test_hip_graph.py -q -m gpu -rP -x -k "cross_attention or conditioning or unet_tiny or transformer_golden or graph" > $O/${TAG}_tests.log 2>&1
-grep -n "passed\|failed\|rror" $O/${TAG}_tests.log | tail -5; grep "\[parity\] cross\|3 conditioning" $O/${TAG}_tests.log | cut -c1-250
+# r19f: fused FeedForward DMA schedules (FFN_W1_BULK / FFN_W2_SPLIT / FFN_BULK_AFTER variants), same-box probe, two rounds
+for i in 1 2; do
+for v in shipped bulk b2 b3 b4 b5; do
+  if [ $v = shipped ]; then L=""; else L="WIW_LIB=tools/ablate/libwiw_$v.so"; fi
+  echo "== $v: $(env $L ONLY_FUSED=1 ROUNDS=3 timeout 200 python tools/ffn_probe.py 2>&1 | grep BEST | tr '\n' ' ')"
+done
+done 2>&1 | tee $O/${TAG}_ffn_schedules.txt
+for v in b2 b3 b4 b5; do echo "== tests $v: $(timeout 600 env WIW_LIB=tools/ablate/libwiw_$v.so python -m pytest tests/test_hip_ffn.py -q -m gpu -x -k 'not ffn32 and not fp16' 2>&1 | tail -1)"; done

@@ -40,6 +40,11 @@
 #ifndef FFN_GE_PRIO
 #define FFN_GE_PRIO 0   // s_setprio of the H-waves' GEGLU segment (A/B knob)
 #endif
+#ifndef FFN_W1_BULK
+#define FFN_W1_BULK 1   // 1 (round 6): the Y-waves issue ALL five W1 K tiles of the next chunk in slot 5 (in front of their phase-2
+                        // MFMAs, while the H-waves evaluate the GEGLU) instead of one tile per K-tile slot: 648-654 -> 628-634 us at
+                        // M = 258 048 (profiles/r19f_ffn_dma_schedules.txt); 0 = the schedule of rounds 3-5 (A/B knob)
+#endif
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0   // timing-only builds (tools/build_variant.py): 1 no GELU math, 2 no phase-2 MFMAs, 3 no LDS-DMA, 4 no phase-1 MFMAs
 #endif
@@ -579,11 +584,19 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             ld_st = ld_st + 1 == RING_STAGES ? 0 : ld_st + 1;
             --ld_left;
         };
+#if FFN_W1_BULK
+        // prologue: the five W1 K tiles of chunk 0; tile 0 has landed when <= 16 instructions are outstanding
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) issue_w1();
+        wait_vmcnt<4 * (NKT - 1)>();
+        int h1 = 0, h2 = 0;
+#else
         // prologue: K tiles 0 .. LEAD-1 (NC >= 20 chunks: they exist); tile 0 has landed when <= 4 * (LEAD - 1) are outstanding
 #pragma unroll
         for (int i = 0; i < LEAD; ++i) issue_w1();
         wait_vmcnt<4 * (LEAD - 1)>();
         int h1 = LEAD >= 3 ? 4 : 0, h2 = LEAD >= 4 ? 4 : 0;   // DMA instructions issued in the previous two DMA slots (prologue tiles)
+#endif
 
         const int sw0 = (fq ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;
         int c = 0;   // chunk (inside its tile) the H-waves work on in this iteration; this wave works on chunk c - 1
@@ -608,6 +621,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                     h0 += 1;
                 }
                 if (cc >= 1 && kt < 3) {
+                    // (spreading the W2 pieces 3|3|2|2 or 2 x 5 over the slots, or the bulk W1 issue BEHIND phase 2: measured, no
+                    // gain — profiles/r19f_ffn_dma_schedules.txt)
                     const int NB2 = kt == 0 ? 4 : 3;              // blocks per wave in this slot (kt is unrolled)
                     const int RB0 = kt == 0 ? 0 : 16 + (kt - 1) * 12;   // first block of this slot: 0 | 16 | 28
                     const int rb = RB0 + wq * NB2;
@@ -618,6 +633,17 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                         if (i < NB2) glds16(src + (int64_t)i * NCH * 1024, dst + i * 1024);
                     h0 += NB2;
                 }
+#if FFN_W1_BULK
+                // The chunk's W1 tiles were issued in the previous slot 5 (below), in K-tile order and BEFORE anything issued
+                // in this chunk's slots: tile kt + 1 (read by the H-waves in the next slot) has landed once at most the tiles
+                // behind it (kt + 2 .. 4) and this chunk's own W2 / bias pieces (h1 accumulates them) are outstanding; W2 and
+                // the bias are read in slot 5, so slot 4 waits for everything.
+                h1 += h0;
+                FTP(1, 3 * kt + 2);  // DMA issued
+                wait_vmcnt_rt(kt == 4 ? 0 : 4 * (3 - kt > 0 ? 3 - kt : 0) + h1);
+                if (kt == 4) h1 = 0;
+                (void)h2;
+#else
                 if (ld_left > 0) {   // W1 K tile LEAD slots ahead of the one the H-waves read now
                     issue_w1();
                     h0 += 4;
@@ -625,10 +651,23 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 FTP(1, 3 * kt + 2);  // DMA issued
                 wait_vmcnt_rt(h0 + (LEAD >= 3 ? h1 : 0) + (LEAD >= 4 && kt != 4 ? h2 : 0));
                 h2 = h1; h1 = h0;
+#endif
             }
             FTP(1, 15);
             slot_barrier();
             FTP(1, 16);
+#if FFN_W1_BULK
+            // slot 5: every H-wave is past its last read of the ring (slot 4) — the five stages are free.  The next chunk's W1 K
+            // tiles go out here, in front of this wave's phase-2 MFMAs: the issue time (the ~110 cycles a VMEM instruction costs
+            // its wave, x 20) falls under the H-waves' GEGLU, where this wave otherwise idles ~2 000 cycles, instead of pacing
+            // the five K-tile slots (profiles/r05j_ffn_slot_timeline.txt: DMA issue + vmcnt wait 1 100 - 1 500 cycles per slot
+            // against 550 - 760 of MFMA work on the H side).  Tile 0 is confirmed at the end of this slot (below).
+            const bool bulk = ld_left > 0;
+            if (bulk) {
+#pragma unroll
+                for (int i = 0; i < NKT; ++i) issue_w1();
+            }
+#endif
             if (cc >= 1) {
                 // ---- phase 2 of chunk c2: Y += H . W2c^T  (H of the previous iteration, parity (cc - 1) & 1)
                 const char* hb = smem + H_OFF + ((cc - 1) & 1) * H_BYTES + (wq * 32 + frow) * 128;
@@ -812,6 +851,9 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                     ++ti;
                 }
             }
+#if FFN_W1_BULK
+            if (bulk) wait_vmcnt<4 * (NKT - 1)>();   // W1 tile 0 of the next chunk has landed (younger: tiles 1 .. 4; an epilogue's stores make this stricter)
+#endif
             c = c + 1 == NCH ? 0 : c + 1;
         }
 #ifdef WIW_FFN_TRACE
