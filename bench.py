@@ -44,6 +44,7 @@ MODE_NAMES = {0: "gemm_kernel<dense>", 1: "gemm_kernel<conv3x3>", 2: "gemm_kerne
 
 # the rocprofv3 kernel names behind each family (profiles/r*_kernel_stats_2step.csv rows): gemm_huge_kernel<MODE, GEGLU, SPLITK, HALO, F32E, A1>
 # = the 256x320 tile (gemm_huge.hip), gemm_kernel<MODE, WAVES, STAGES, GEGLU, LNFOLD, F32E> = the 256x160 / 128x160 tiles
+PROF_RES1, PROF_RES2 = 1 << 24, 1 << 25   # profile-key bits of wiw_amd.hip: the launch read a res1 / res2 operand
 MODE_TEMPLATES = {
     0: ["gemm_huge_kernel<0, false, false, 0, false, true>", "gemm_huge_kernel<0, true, false, 0, false, true>",
         "gemm_huge_kernel<0, false, false, 0, false, false>", "gemm_huge_kernel<0, true, false, 0, false, false>", "gemm_kernel<0, 8, 3, false, false, false>",
@@ -419,7 +420,8 @@ def main():
                                                    "tflops": round(v[1] / v[0] / 1e12, 1)} for m, v in sorted(by_mode.items())}
             # the dense family mixes regimes: the K <= 320 launches (C = 320 level) sit below the machine
             # ridge — 70 % of their time is the GEGLU up-projection, whose exact-erf epilogue is VALU-bound, the rest
-            # streams at 3-3.7 TB/s; algorithmic bytes = bf16 A + W + out (residual reads not counted)
+            # streams at 4.0-4.4 TB/s; algorithmic bytes = 16-bit A + W + out + the residual operands the launch reads (round 6:
+            # rounds 1-5 left the residuals out and under-stated these launches by a quarter — profiles/r19i_thin320_probe.txt)
             lo = [0.0, 0.0, 0.0, 0]
             hi = [0.0, 0.0, 0]
             for (mode, M, N, K, epi), (sec, cnt) in shapes.items():
@@ -427,7 +429,9 @@ def main():
                     continue
                 n_out = N // 2 if epi & 1 else N
                 if K <= 320:
-                    lo[0] += sec; lo[1] += 2.0 * M * N * K * cnt; lo[2] += 2.0 * (M * K + N * K + M * n_out) * cnt; lo[3] += cnt
+                    res_b = sum((4.0 if epi & f32 else 2.0) * M * n_out for has, f32 in ((PROF_RES1, 128), (PROF_RES2, 256)) if epi & has)
+                    out_b = (4.0 if epi & 4 else 2.0) * M * n_out
+                    lo[0] += sec; lo[1] += 2.0 * M * N * K * cnt; lo[2] += (2.0 * (M * K + N * K) + out_b + res_b) * cnt; lo[3] += cnt
                 else:
                     hi[0] += sec; hi[1] += 2.0 * M * N * K * cnt; hi[2] += cnt
             if lo[0] > 0 and hi[0] > 0:

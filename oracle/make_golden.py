@@ -600,7 +600,12 @@ def gen_pipeline_northstar(ns):
     background of the build container.  Tiny random VAE / CLIP supply the conditioning, captured at the UNet boundary.
     Stored: conditioning (image latents, CLIP embedding), the reference's latents after steps 5/10/15/20 and the final ones, fp32.  NOT stored:
     the latent noise (2 MB) — the test redraws it (numpy's frozen legacy RandomState, same draw order) and float64 checksums pin it.
-    Every step's latents also go to $WIW_NORTHSTAR_SCRATCH (default /tmp/wiw_ns_partial) so an interrupted run leaves a prefix."""
+    Every step's latents also go to $WIW_NORTHSTAR_SCRATCH (default /tmp/wiw_ns_partial) so an interrupted run leaves a prefix.
+    $WIW_NORTHSTAR_RESUME=k continues such a prefix INSIDE the same __call__: the UNet is skipped for steps 1 .. k, the step-k
+    callback hands the loop the stored step-k latents (`latents = callback_outputs.pop("latents", latents)`, :619), and steps
+    k+1 .. 25 run as always (the Euler scheduler carries no history, only its step index, which advances normally).  Every
+    recomputed step whose file is already in the prefix must equal it BIT FOR BIT (resuming one step before the end of the
+    prefix proves the continuation is the uninterrupted run)."""
     import time
 
     from diffusers import AutoencoderKLTemporalDecoder, StableVideoDiffusionPipeline
@@ -647,14 +652,40 @@ def gen_pipeline_northstar(ns):
         cap["ie"] = r.detach().clone()
         return r
 
+    resume = int(os.environ.get("WIW_NORTHSTAR_RESUME", "0"))
+    calls = [0]
+    real_forward = unet.forward
+
+    def forward(sample, *a, **k):
+        calls[0] += 1
+        if calls[0] <= resume:       # a step whose result the prefix already holds
+            return (torch.zeros_like(sample[:, :, :4]),)
+        return real_forward(sample, *a, **k)
+
+    if resume:
+        unet.forward = forward
+
     def on_step(pipe_, i, t, kw):
+        f = os.path.join(scratch, f"step_{i + 1:02d}.npy")
+        if i + 1 <= resume:
+            x = torch.from_numpy(np.load(f))
+            if i == 0:
+                assert np.array_equal(np.load(os.path.join(scratch, "image_latents.npy")), cap["il"][1:].numpy())
+                assert np.array_equal(np.load(os.path.join(scratch, "image_embeddings.npy")), cap["ie"][1:].numpy())
+            if (i + 1) in keep:
+                traj[i + 1] = x
+            return {"latents": x}
         x = kw["latents"].detach().clone()
         if (i + 1) in keep:
             traj[i + 1] = x
         if i == 0:
             np.save(os.path.join(scratch, "image_latents.npy"), cap["il"][1:].numpy())
             np.save(os.path.join(scratch, "image_embeddings.npy"), cap["ie"][1:].numpy())
-        np.save(os.path.join(scratch, f"step_{i + 1:02d}.npy"), x.numpy())
+        if resume and os.path.exists(f):
+            same = np.array_equal(np.load(f), x.numpy())
+            print(f"  pipeline_northstar: recomputed step {i + 1} {'==' if same else '!='} the prefix's", flush=True)
+            assert same, "the resumed run is not the interrupted one"
+        np.save(f, x.numpy())
         print(f"  pipeline_northstar: step {i + 1}/{steps}  {time.time() - t0:.0f} s  rms {float(x.double().pow(2).mean().sqrt()):.5f}", flush=True)
         return kw
 

@@ -474,12 +474,14 @@ def northstar_pipeline_noise(p):
     return noise
 
 
-# (rms, max) gates of the relative latent error after 25 steps at 72x128.  fp16 + fp32 stream: north_star's 1e-3 on BOTH norms;
-# the others 1.2 x the round-6 measurement (profiles/r19*_northstar_trajectory.log)
+# (rms, max) gates of the relative latent error after 25 steps at 72x128.  fp16 + fp32 stream: north_star's 1e-3 on BOTH norms
+# (measured 5.12e-4 / 8.56e-4); fp16: 1e-3 on the rms (6.75e-4), 1.2 x measured on the max norm (1.09e-3: the one norm of the
+# three 16-bit configurations' six that sits above 1e-3 at this size — DESIGN 5); bf16: 1.2 x measured (5.21e-3 / 7.65e-3).
+# Measurements: profiles/r19i_northstar_trajectory.log
 NORTHSTAR_LOOP_GATES = {
     ("fp16", True): (1.0e-3, 1.0e-3),
-    ("fp16", False): (1.0e-3, 1.5e-3),
-    ("bf16", False): (8.0e-3, 1.2e-2),
+    ("fp16", False): (1.0e-3, 1.32e-3),
+    ("bf16", False): (6.3e-3, 9.2e-3),
 }
 
 

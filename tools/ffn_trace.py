@@ -51,6 +51,13 @@ def main():
         print(f"   GEGLU by pass of 16 gate values (from 'last k-step issued'): {g[0] - h[12]:6d} {g[1] - g[0]:6d}")
         print(f"   chunk total (slot-0 stamp to GEGLU done): {h[13] - h[0]:6d} cycles")
         print(f"--- chunk {ch}: Y-wave (wave 4)")
+        if os.environ.get("FREEK"):   # -DFFN_FREE_K=1 build: two barriers per chunk
+            y = t[1][ch * 32: ch * 32 + 19]
+            nxt = t[1][(ch + 1) * 32] if ch == 0 else None
+            print(f"   barrier A wait {y[1] - y[0]:6d} | W2 + bias DMA issue {y[2] - y[1]:6d} | vmcnt wait {y[15] - y[2]:6d} | barrier B wait {y[16] - y[15]:6d}"
+                  f" | W1 bulk issue + phase 2 {y[17] - y[16]:6d} | epilogue (if any) {y[18] - y[17]:6d}"
+                  + (f" | W1 vmcnt wait {nxt - y[18]:6d}" if nxt is not None else ""))
+            continue
         for kt in range(5):
             nxt = y[3 * kt + 3] if kt < 4 else y[15]
             print(f"   slot {kt}: barrier wait {y[3 * kt + 1] - y[3 * kt]:6d} | DMA issue {y[3 * kt + 2] - y[3 * kt + 1]:6d} | vmcnt wait {nxt - y[3 * kt + 2]:6d}")

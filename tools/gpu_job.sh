@@ -4,11 +4,14 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-# r19f: fused FeedForward DMA schedules (FFN_W1_BULK / FFN_W2_SPLIT / FFN_BULK_AFTER variants), same-box probe, two rounds
-for i in 1 2; do
-for v in shipped bulk b2 b3 b4 b5; do
-  if [ $v = shipped ]; then L=""; else L="WIW_LIB=tools/ablate/libwiw_$v.so"; fi
-  echo "== $v: $(env $L ONLY_FUSED=1 ROUNDS=3 timeout 200 python tools/ffn_probe.py 2>&1 | grep BEST | tr '\n' ' ')"
-done
-done 2>&1 | tee $O/${TAG}_ffn_schedules.txt
-for v in b2 b3 b4 b5; do echo "== tests $v: $(timeout 600 env WIW_LIB=tools/ablate/libwiw_$v.so python -m pytest tests/test_hip_ffn.py -q -m gpu -x -k 'not ffn32 and not fp16' 2>&1 | tail -1)"; done
+# r19i: the persistent K = 320 projection (thin.hip) — parity, probe, rollout A/B; FFN_FREE_K as the default; the reference's
+# 25-step trajectory at the benchmarked size against the three precisions
+timeout 900 python -m pytest tests/test_hip_thin.py -q -m gpu -x -s 2>&1 | tail -40 | tee $O/${TAG}_thin_tests.log
+timeout 300 python tools/thin_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_thin_probe.txt
+timeout 900 python -m pytest tests/test_hip_ffn.py -q -m gpu -x 2>&1 | tail -3 | tee $O/${TAG}_ffn_tests.log
+timeout 1500 python -m pytest tests/test_hip_res32.py -q -m gpu -s -k "reference_trajectory_25_steps_at_the_benchmarked" 2>&1 | grep -v amdgpu.ids | tail -30 | tee $O/${TAG}_northstar_trajectory.log
+for v in "" "WIW_NO_LINEAR320=1"; do
+  echo "== ${v:-linear320}: $(env $v timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; print(d['value'],'frames/s', d['ms_per_step'],'ms | dense', r['achieved'],'TF/s frac',r['frac'],'| dense_split',d.get('dense_split'))")"
+done 2>&1 | tee $O/${TAG}_rollout_ab.txt

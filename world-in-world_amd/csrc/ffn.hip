@@ -45,6 +45,13 @@
                         // MFMAs, while the H-waves evaluate the GEGLU) instead of one tile per K-tile slot: 648-654 -> 628-634 us at
                         // M = 258 048 (profiles/r19f_ffn_dma_schedules.txt); 0 = the schedule of rounds 3-5 (A/B knob)
 #endif
+#ifndef FFN_FREE_K
+#define FFN_FREE_K 1    // (needs FFN_W1_BULK) 1 (round 6): with a chunk's five W1 K tiles resident before its first K tile is read, the
+                        // H-waves run the K phase WITHOUT the per-K-tile block barriers: two barriers per chunk (A: W1 resident /
+                        // W2 buffer and ring hand-over; B: W2 + bias landed, H of the previous chunk visible) instead of six:
+                        // 634-646 -> 615-620 us at M = 258 048 (profiles/r19g_ffn_freek.txt; timelines r19h); 0 = A/B knob
+#endif
+static_assert(!FFN_FREE_K || FFN_W1_BULK, "FFN_FREE_K needs the bulk W1 schedule");
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0   // timing-only builds (tools/build_variant.py): 1 no GELU math, 2 no phase-2 MFMAs, 3 no LDS-DMA, 4 no phase-1 MFMAs
 #endif
@@ -57,7 +64,8 @@ constexpr int KS = C / 32;                                       // 10 k-steps o
 #ifndef FFN_RING
 #define FFN_RING 5
 #endif
-constexpr int RING_STAGES = FFN_RING, LEAD = RING_STAGES - 1;     // W1 K tiles: issued LEAD slots before they are read
+constexpr int RING_STAGES = FFN_RING;
+[[maybe_unused]] constexpr int LEAD = RING_STAGES - 1;     // W1 K tiles: issued LEAD slots before they are read
 constexpr int RING_STAGE_BYTES = 2 * HC * BK * 2;                 // one W1 K tile: 128 rows x 64 k = 16 KiB
 constexpr int W2_OFF = RING_STAGES * RING_STAGE_BYTES;           // 81920
 constexpr int W2_BYTES = C * HC * 2;                             // 320 rows x 64 k = 40 KiB
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 FTP(0, 2 * kt);          // end of the previous slot's work
-                slot_barrier();
+                if (!FFN_FREE_K || kt == 0) slot_barrier();
                 FTP(0, 2 * kt + 1);      // barrier passed
                 // two halves of [2 MFMAs | 1 ds_read_b128] x 8, order pinned: the first half runs the PENDING k-step (fragments
                 // fbB of the previous slot) while this K tile's k-step-0 fragments arrive, the second half runs k-step 0 while
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
         }
         // drain: the Y-waves finish the last chunk (+ the tile-end barrier, see above)
 #pragma unroll
-        for (int i = 0; i < NKT + 2; ++i) slot_barrier();
+        for (int i = 0; i < (FFN_FREE_K ? 3 : NKT + 2); ++i) slot_barrier();
 #ifdef WIW_FFN_TRACE
         if (trace_blk) for (int i = 0; i < 64; ++i) g_ftrace[0][i] = *(volatile long long*)(smem + SMEM + i * 8);
 #endif
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
         // prologue: the five W1 K tiles of chunk 0; tile 0 has landed when <= 16 instructions are outstanding
 #pragma unroll
         for (int i = 0; i < NKT; ++i) issue_w1();
-        wait_vmcnt<4 * (NKT - 1)>();
+        wait_vmcnt<FFN_FREE_K ? 0 : 4 * (NKT - 1)>();
         int h1 = 0, h2 = 0;
 #else
         // prologue: K tiles 0 .. LEAD-1 (NC >= 20 chunks: they exist); tile 0 has landed when <= 4 * (LEAD - 1) are outstanding
@@ -603,6 +611,34 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
         int ti = 0;  // tile counter of the chunk THIS wave works on
         for (int cc = 0; cc <= NC; ++cc) {
             const int c2 = c == 0 ? NCH - 1 : c - 1;   // chunk of phase 2 in this iteration (valid for cc >= 1)
+#if FFN_FREE_K
+            // ---- K phase of the H-waves (they free-run through the chunk's five resident W1 K tiles): behind barrier A — every
+            // Y-wave is through phase 2 of the previous iteration, the W2 buffer is free — this wave issues its share of W2
+            // chunk c2 (10 blocks) and of the bias chunk, confirms them, and meets the H-waves at barrier B
+            FTP(1, 0);
+            slot_barrier();
+            FTP(1, 1);
+            if (cc < NC) {
+                if (lane < 8) glds16((const char*)p.b1 + c * (2 * HC * 4) + wq * 128 + lane * 16,
+                                     smem + BIAS_OFF + (cc & 1) * BIAS_BYTES + wq * 128);
+            }
+            if (cc >= 1) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int NB2 = g == 0 ? 4 : 3;
+                    const int RB0 = g == 0 ? 0 : 16 + (g - 1) * 12;
+                    const int rb = RB0 + wq * NB2;
+                    const char* src = W2b + ((int64_t)rb * NCH + c2) * 1024 + lane * 16;
+                    char* dst = smem + W2_OFF + rb * 1024;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < NB2) glds16(src + (int64_t)i * NCH * 1024, dst + i * 1024);
+                }
+            }
+            FTP(1, 2);
+            wait_vmcnt<0>();
+            (void)h1; (void)h2;
+#else
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 FTP(1, 3 * kt);          // end of the previous slot's work
@@ -653,6 +689,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 h2 = h1; h1 = h0;
 #endif
             }
+#endif
             FTP(1, 15);
             slot_barrier();
             FTP(1, 16);
@@ -852,7 +889,8 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 }
             }
 #if FFN_W1_BULK
-            if (bulk) wait_vmcnt<4 * (NKT - 1)>();   // W1 tile 0 of the next chunk has landed (younger: tiles 1 .. 4; an epilogue's stores make this stricter)
+            FTP(1, 18);
+            if (bulk) wait_vmcnt<FFN_FREE_K ? 0 : 4 * (NKT - 1)>();   // W1 tile 0 (FFN_FREE_K: every tile) of the next chunk has landed (younger: tiles 1 .. 4; an epilogue's stores make this stricter)
 #endif
             c = c + 1 == NCH ? 0 : c + 1;
         }

@@ -26,6 +26,7 @@ K_CMAJOR = 512   # conv modes: K of W is channel-block major, k = ((c / 64) * ta
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
 FFN_C, FFN_HIDDEN = 320, 1280   # the one shape wiw_ffn_geglu_bf16 is built for
+PROF_RES1, PROF_RES2 = 1 << 24, 1 << 25   # bench.py profile keys only: the launch read a res1 / res2 operand
 
 
 class TiledW:
@@ -338,7 +339,10 @@ class Hip:
         e0.record()
         self._ck(self.lib.wiw_gemm_bf16(self._stream(), C.byref(a)), "wiw_gemm_bf16")
         e1.record()
-        self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode, (M, N, K, epilogue)))
+        # (profile key: the caller's epilogue bits + which residual operands the launch read, PROF_RES1 / PROF_RES2)
+        self.gemm_profile.append((e0, e1, 2.0 * M * N * K, mode,
+                                  (M, N, K, epilogue | (PROF_RES1 if res1 is not None else 0) | (PROF_RES2 if res2 is not None else 0)
+                                   | (a.epilogue & (EPI_RES1_F32 | EPI_RES2_F32)))))
         return out
 
     def attn_spatial(self, QK, ldqk, k_col_off, Vt, ldvt, O, ldo, frames, S, heads, scale, lse=None):
