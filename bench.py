@@ -186,6 +186,7 @@ def main():
     ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
                     help="16-bit storage / MFMA operand type: bf16 (BASELINE's, libwiwsvd.so) or fp16 (the reference's "
                          "served default, libwiwsvd_f16.so)")
+    ap.add_argument("--residual-fp32-full", action="store_true", help="UNetHIP(residual_fp32='full'): rounds 4-5's form of the mode")
     ap.add_argument("--residual-fp32", action="store_true",
                     help="UNetHIP(residual_fp32=True): the residual stream in fp32 (with --dtype fp16 the configuration within "
                          "1e-3 of the reference's fp32 evaluation, DESIGN.md 5)")
@@ -260,7 +261,7 @@ def main():
     h, w = args.height // 8, args.width // 8
     sd = random_state_dict_torch(cfg, 0, device, torch.float32)
     unet = UNetHIP(cfg, sd, device, dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16,
-                   residual_fp32=True if args.residual_fp32 else None)
+                   residual_fp32="full" if args.residual_fp32_full else (True if args.residual_fp32 else None))
     # what THIS box gives a pure-MFMA loop and a device copy (outside the timed region): the pool's boxes differ by +-5 %
     box = unet.hip.calibrate_box() if rank == 0 and not args.no_calibrate else None
     sd_cpu = None
@@ -348,7 +349,7 @@ def main():
             "metric": "denoised frames/sec (576x1024x14, 25 steps)", "value": round(value, 4), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            **({"residual_stream": "fp32"} if unet.res32 else {}),
+            **({"residual_stream": "fp32"} if unet.res32_any else {}),
             "config": {"workload": f"SVD denoise loop {args.height}x{args.width}x{T}, {args.num_inference_steps} Euler steps, "
                                    f"CFG on, " + (f"{Btot} candidates in total" if strong else f"{B} candidate(s)/GPU") + ", random-init weights" + (" [TINY MODEL - INVALID]" if args.tiny else ""),
                        "candidates_per_gpu": B, "parallelism": f"candidate-sharded x{world}",
@@ -464,7 +465,7 @@ def main():
         if args.end_to_end and world == 1 and not args.tiny:
             res["end_to_end"] = end_to_end(den, unet, device, B, args)
         if (world == 1 and not dist_on and not args.no_extras and not args.tiny and B == 1 and not strong and
-                (args.height, args.width, args.num_inference_steps) == (576, 1024, 25) and not args.residual_fp32):
+                (args.height, args.width, args.num_inference_steps) == (576, 1024, 25) and not (args.residual_fp32 or args.residual_fp32_full)):
             res["extra"] = extras(args, cfg, unet, device, req, time.perf_counter() - t_start)
         if sd_cpu is not None:
             try:
@@ -563,7 +564,9 @@ def extras(args, cfg, unet, device, req, elapsed):
     otherwise never sees.  Each leg is guarded; none touches `value`.
       batch8      one 25-step rollout of 8 candidates on this GPU = the per-GPU work of BASELINE configs 2 / 3
       fp16        one rollout with the fp16 library (the reference's served dtype, eval_inference.py:294)
-      fp16_res32  the same with the residual stream in fp32: the configuration gated at <= 1e-3 vs the reference's fp32 output
+      fp16_res32  the same with the BLOCK-LEVEL residual stream in fp32 (UNetHIP(residual_fp32=True), round 6): the configuration whose
+                  25-step latents at this size are gated at <= 1e-3 (rms AND max) against the reference pipeline's; `ratio_to_fp16`
+      fp16_res32_full   ... with the hidden stream inside the transformer blocks in fp32 too (residual_fp32="full", rounds 4-5)
       end_to_end  ONE whole request through the worker: CLIP + VAE encode, loop, temporal VAE decode (own
                   row with its TFLOP/s), PIL resize, uint8 response
       train       2 warm-up + 5 timed fine-tuning steps at 576x1024x14 (BASELINE config 4's per-GPU work), every step bracketed:
@@ -605,12 +608,14 @@ def extras(args, cfg, unet, device, req, elapsed):
     except Exception as e:   # noqa: BLE001
         out["batch8"] = {"error": f"{type(e).__name__}: {e}"}
     if args.dtype == "bf16":
-        for name, r32 in (("fp16", False), ("fp16_res32", True)):
+        for name, r32 in (("fp16", False), ("fp16_res32", True), ("fp16_res32_full", "full")):
             try:
                 if left() > 30:
                     u = UNetHIP(cfg, random_state_dict_torch(cfg, 0, device, torch.float32), device, dtype=torch.float16,
                                 residual_fp32=r32)
                     out[name] = timed_rollout(SVDDenoiser(u, use_graph=True), req, 1)
+                    if name != "fp16" and "frames_per_s" in out.get("fp16", {}):
+                        out[name]["ratio_to_fp16"] = round(out[name]["frames_per_s"] / out["fp16"]["frames_per_s"], 4)
                     del u
                     torch.cuda.empty_cache()
             except Exception as e:   # noqa: BLE001

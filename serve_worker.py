@@ -102,6 +102,8 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
     # the drop-in default (fp16) carries the fp32 residual stream unless told otherwise: the configuration inside north_star's
     # 1e-3 in both norms on the reference's 25-step trajectory at the benchmarked size (worker.build_argparser)
     res32 = (dtype == torch.float16) if args.residual_fp32 is None else bool(args.residual_fp32)
+    if res32 and args.residual_fp32_full:
+        res32 = "full"
     unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype, residual_fp32=res32)
     den = SVDDenoiser(unet, use_graph=bool(args.hip_graph))   # graph replay by default, as bench.py measures
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)

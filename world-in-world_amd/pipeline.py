@@ -202,7 +202,7 @@ class SVDDenoiser:
     def graph_pool_estimate(self, B: int, h: int, w: int) -> float:
         """Bytes a captured forward pins for (B candidates, h x w latent): ~6.2 GB per candidate at 72x128 with 16-bit
         activations (measured, serve_worker --help), x 1.6 with the fp32 residual stream; linear in B h w."""
-        per = 6.2e9 * (1.6 if getattr(self.unet, "res32", False) else 1.0)
+        per = 6.2e9 * (1.6 if getattr(self.unet, "res32_any", False) else 1.0)
         return per * B * (h * w) / (72.0 * 128.0)
 
     def graph_status(self) -> dict:

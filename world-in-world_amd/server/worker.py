@@ -331,11 +331,14 @@ def build_arg_parser() -> argparse.ArgumentParser:
                          "work per forward; a captured shape pins ~6 GB of HBM per candidate at 576x1024).  ON by default — the "
                          "mode bench.py measures; --no-hip_graph launches eagerly")
     ap.add_argument("--residual_fp32", action=argparse.BooleanOptionalAction, default=None,
-                    help="keep the UNet's residual stream in fp32 (UNetHIP(residual_fp32=True); the reference keeps latents and the "
-                         "Euler step in fp32, scheduling_euler_discrete.py:635,673).  Default: ON with --weight_dtype float16 — the "
-                         "configuration whose 25-step latents at 576x1024x14 are within 1e-3 of the reference pipeline's in BOTH norms "
-                         "(5.1e-4 rms / 8.6e-4 max; plain fp16: 6.7e-4 / 1.09e-3; tests/test_hip_res32.py, DESIGN.md 5) at 0.90x the "
-                         "speed of plain fp16 — and OFF with bfloat16 (whose own rounding floor is 5e-3).  --no-residual_fp32 forces it off")
+                    help="keep the UNet's block-level residual stream in fp32 (UNetHIP(residual_fp32=True); the reference keeps latents "
+                         "and the Euler step in fp32, scheduling_euler_discrete.py:635,673).  Default: ON with --weight_dtype float16 — "
+                         "the configuration whose 25-step latents at 576x1024x14 are within 1e-3 of the reference pipeline's in BOTH "
+                         "norms (5.5e-4 rms / 8.6e-4 max; plain fp16: 6.7e-4 / 1.09e-3; tests/test_hip_res32.py, DESIGN.md 5) at 0.96x "
+                         "the speed of plain fp16 — and OFF with bfloat16 (whose own rounding floor is 5e-3).  --no-residual_fp32: off")
+    ap.add_argument("--residual_fp32_full", action="store_true",
+                    help="with --residual_fp32: also the hidden stream inside the transformer blocks in fp32 (rounds 4-5's form of "
+                         "the mode: 5.1e-4 / 8.6e-4 on the same trajectory at 0.90x the speed of fp16)")
     ap.add_argument("--batch_size", type=int, default=0)
     ap.add_argument("--coalesce_candidates", type=int, default=0,
                     help="> 0: batch requests of different clients into one GPU call of up to this many candidates")

@@ -163,16 +163,19 @@ def _require_single_key(ehs: torch.Tensor, max_tokens: int = 1) -> None:
 class UNetHIP:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, "torch.Tensor | np.ndarray"], device="cuda:0",
                  hip: Optional[Hip] = None, dtype: torch.dtype = torch.bfloat16, fold_layernorm: Optional[bool] = None,
-                 residual_fp32: Optional[bool] = None, num_past_obs: int = 1):
+                 residual_fp32: "Optional[bool | str]" = None, num_past_obs: int = 1):
         """dtype: 16-bit storage type of weights and activations (bf16, or fp16 = the reference's served default,
         eval_inference.py:294); with `hip` given, its dtype is used.
-        residual_fp32: keep the RESIDUAL STREAM in fp32 (ABI 11) — the outputs x + f(x) of every ResnetBlock and transformer
-        sub-block, the AlphaBlender outputs, the skip tensors and the stream between blocks are fp32 tensors (never rounded to
-        the 16-bit type), every MFMA operand stays 16-bit.  The reference keeps latents and the Euler update in fp32
-        (scheduling_euler_discrete.py:635,673) and autocasts nothing inside the UNet; with fp16 storage this is the
-        configuration that meets north_star's 1e-3 relative error on the served architecture (DESIGN.md 5:
-        oracle/precision_study.py `res32`, tests/test_hip_fp16.py).  Cost: the fused FeedForward / temporal-block kernels
-        (16-bit streams) are replaced by their unfused chains and the stream's bytes double.  Default: env WIW_RES32.
+        residual_fp32: keep the RESIDUAL STREAM in fp32 (ABI 11), every MFMA operand stays 16-bit.  The reference keeps latents and
+        the Euler update in fp32 (scheduling_euler_discrete.py:635,673) and autocasts nothing inside the UNet.
+          True    (round 6) the BLOCK-LEVEL stream: the outputs x + f(x) of every ResnetBlock, the skip tensors, what enters and
+                  leaves a transformer block (proj_out + x), the down / upsampler outputs are fp32 tensors, never rounded to the
+                  16-bit type; a transformer block's hidden stream between proj_in and proj_out stays 16-bit and runs on the fused
+                  16-bit kernels.  With fp16 storage: the reference pipeline's 25-step latents at 576x1024x14 within 5.5e-4 rms /
+                  8.6e-4 max (north_star: 1e-3 relative latent error) at 0.96 x the speed of plain fp16 (profiles/r20b_*).
+          "full"  (rounds 4-5) also every sub-block output inside the transformer blocks: 5.1e-4 / 8.6e-4 on the same trajectory,
+                  9.1e-4 instead of 1.00e-3 on ONE forward at sigma = 15.6 — at 0.90 x the speed of fp16.
+        Default: env WIW_RES32 (A/B knobs: WIW_RES32_PARTS = rb | tr | both, WIW_RES32_TR_MASK).
         num_past_obs: conditioning tokens per candidate the replica is built for (--num_past_obs, train_svd.py:359).  1 (every
         launcher of the reference): the two cross-attentions of a layer in closed form.  2..8: also the weights of the general
         form (attn2.to_q / to_k, norm2) and `wiw_cross_attn_fewkeys_bf16`; requests may then carry 1..num_past_obs tokens.
@@ -196,7 +199,24 @@ class UNetHIP:
         # fused FeedForward kernel of the 320-channel level (ffn.hip); A/B knobs: WIW_FF_UNFUSED=1 -> two GEMMs again,
         # WIW_FFN_NO_LN=1 -> fused FeedForward behind a separate LayerNorm pass
         self.res32 = bool(os.environ.get("WIW_RES32")) if residual_fp32 is None else bool(residual_fp32)
-        self.sdt = torch.float32 if self.res32 else self.dtype      # dtype of residual-stream tensors
+        # WHICH part of the stream is fp32 (round 6, profiles/r20b_res32_parts.txt: the reference's 25-step trajectory at 576x1024x14,
+        # fp16 weights — relative latent error rms / max and frames/s on one box, plain fp16 = 6.75e-4 / 1.09e-3, 5.857):
+        #   "rb"   the BLOCK-LEVEL stream only — ResBlock outputs, skip tensors, what enters and leaves a transformer block:
+        #          5.47e-4 / 8.58e-4, 5.613 frames/s = 0.958 x fp16                                  <- the mode (default)
+        #   "tr"   only the hidden stream INSIDE a transformer block (proj_in .. proj_out): 1.02e-3 max, 5.424
+        #   "both" rounds 4-5: 5.12e-4 / 8.56e-4, 5.242 = 0.895 x fp16                               (A/B: WIW_RES32_PARTS=both)
+        # The error that accumulates is the rounding of the stream that runs through the WHOLE depth of the network; a transformer
+        # block's inner stream starts fresh at proj_in and is folded back into the fp32 block stream at proj_out after 7 adds.
+        # `self.res32` is the flag of the code that is running: block level, or a transformer's inside.
+        assert residual_fp32 in (None, False, True, "full"), residual_fp32
+        parts = os.environ.get("WIW_RES32_PARTS", "both" if residual_fp32 == "full" else "rb") if self.res32 else "none"
+        assert parts in ("both", "tr", "rb", "none"), parts
+        self.res32_tr, self.res32_rb = parts in ("both", "tr"), parts in ("both", "rb")
+        # finer A/B knob: WHICH hidden-stream tensors of a transformer block are fp32 — bit 0 proj_in's output, 1 attn1.to_out
+        # (spatial), 2 the spatial FeedForward's, 3 ff_in's, 4 attn1.to_out (temporal); "tr" / "both" = 31
+        self.tr_mask = int(os.environ.get("WIW_RES32_TR_MASK", "31" if self.res32_tr else "0")) if self.res32 else 0
+        self.res32_tr = self.tr_mask != 0
+        self.sdt = torch.float32 if self.res32_rb else self.dtype      # dtype of block-level residual-stream tensors
         if self.res32:
             self.ln_fold = False          # the folds read the raw stream as a 16-bit MFMA operand
             # round 6: the fused temporal block runs in this mode too — on the 16-bit ROUNDING of the fp32 stream tensor, which
@@ -218,6 +238,8 @@ class UNetHIP:
         # profiles/r13b_*): opt-in A/B knob, ffn.hip stays the served kernel
         self.ffn32 = self.ffn_fused and bool(os.environ.get("WIW_FFN32"))
         self._prepare(state_dict)
+        self.res32_any = self.res32
+        self.res32 = self.res32_rb        # from here on: the flag of the running code (see WIW_RES32_PARTS above)
 
     # ------------------------------------------------------------------------------------------
     # weight re-layout (once, at load)
@@ -640,10 +662,19 @@ class UNetHIP:
         q2 = self._linear(a2, q + ".attn2.to_q", M)
         K, V = cond.cross_kv[q]
         o2 = hip.cross_attn_fewkeys(q2, Cn, K, V, a2, Cn, M, rows_per_item, heads, cond.P, 1.0 / math.sqrt(64.0))
-        return self._linear(o2, q + ".attn2.to_out.0", M, res1=h, stream=True)
+        return self._linear(o2, q + ".attn2.to_out.0", M, res1=h, stream=h.dtype == torch.float32)   # stays on h's stream
 
     def _transformer(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
         """TransformerSpatioTemporalModel (transformer_temporal.py:279-382), one layer."""
+        rb = self.res32
+        self.res32 = self.res32_tr            # the hidden stream between proj_in and proj_out
+        try:
+            hb = self._transformer_inside(p, x, Cn, M, H, W, heads, cond)
+        finally:
+            self.res32 = rb
+        return self._linear(hb, p + ".proj_out", M, res1=x, stream=True)      # back on the block-level stream
+
+    def _transformer_inside(self, p, x, Cn, M, H, W, heads, cond: RequestCond):
         hip, w, T = self.hip, self.w, self.cfg.num_frames
         S = H * W
         frames = M // S
@@ -651,7 +682,8 @@ class UNetHIP:
         b, t = p + ".transformer_blocks.0", p + ".temporal_transformer_blocks.0"
         scale = 1.0 / math.sqrt(64.0)
         xn = hip.groupnorm(x, Cn, None, 0, M, S, w[p + ".norm.weight"], w[p + ".norm.bias"], 1e-6, False)
-        h = self._linear(xn, p + ".proj_in", M, stream=True)
+        tb = lambda k: bool((self.tr_mask >> k) & 1)      # noqa: E731  (is hidden-stream tensor k fp32?)
+        h = self._linear(xn, p + ".proj_in", M, stream=tb(0))
         # ---- spatial block (attention.py:462-582)
         legacy = bool(os.environ.get("WIW_LN_ADDVEC"))   # A/B knob: the adds inside the LayerNorm kernel (extra write pass)
         # LayerNorm folded into its consumer GEMM where that GEMM runs on the 256x160 tile (`_fold_ln`): the projection
@@ -682,13 +714,13 @@ class UNetHIP:
             a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], addvec=cond.cross[b], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=h, out=a)
         elif cond.P > 1:
-            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, stream=True)
+            h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, stream=tb(1))
             h = self._cross_attention(b, h, M, Cn, T * S, heads, cond)
             if not fold_ff:
                 a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
         else:
             h = self._linear(o, b + ".attn1.to_out.0", M, res1=h, rowvec=cond.cross[b], rowvec_ld=Cn, rows_per_vec=T * S,
-                             stream=True)
+                             stream=tb(1))
             if not fold_ff:
                 a = hip.layernorm(h, M, Cn, w[b + ".norm3.weight"], w[b + ".norm3.bias"], out=a)
         am = self.alpha[p]
@@ -699,24 +731,25 @@ class UNetHIP:
         lnin = h if fold_ff else None         # the FeedForwards below take the RAW stream where their norm is folded
         if fold_emb:
             hm = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0, rowvec=cond.pos_emb[p],
-                                rowvec_ld=Cn, rows_per_vec=S)
+                                rowvec_ld=Cn, rows_per_vec=S, stream=tb(2))
             hs = hm                           # = spatial output + emb
             if not fold_ff:
                 a = hip.layernorm(hm, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], out=a)
         else:
-            hs = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0)
+            hs = self._geglu_ff(a, b + ".ff", M, Cn, ln_input=lnin, res1=h, ldr1=Cn, beta1=1.0, stream=tb(2))
             hm = self._empty(M, Cn)
             a = hip.layernorm(hs, M, Cn, w[t + ".norm_in.weight"], w[t + ".norm_in.bias"], addvec=cond.pos_emb[p],
                               addvec_ld=Cn, rows_per_vec=S, sum_out=hm, out=a)
         # ---- temporal block (attention.py:707-762); rows stay in (b,t,s) order
         t_fused = T <= 14 and not self.temporal_unfused and M * Cn * 2 < (1 << 32)
+        w16 = tb(3) and t_fused               # ff_in's output is fp32 and the fused temporal block wants its 16-bit rounding
         hm = self._geglu_ff(a, t + ".ff_in", M, Cn, ln_input=hm if (fold_ff and fold_emb) else None, res1=hm, ldr1=Cn, beta1=1.0,
-                            want16=self.res32 and t_fused)
+                            stream=tb(3), want16=w16)
         if t_fused:
             # norm1 + to_q/k/v + the 14x14 attention in ONE kernel (temporal.hip): LayerNorm folded into the projection,
             # Q/K/V never leave the registers — no LayerNorm pass, no 3C-wide QKV tensor.  (fp32 stream: the kernel reads the
             # stream tensor's 16-bit rounding, written beside it by its producer.)
-            hm, hm16 = hm if self.res32 else (hm, hm)
+            hm, hm16 = hm if w16 else (hm, hm)
             hip.temporal_attn_block(hm16, w[t + ".attn1.fused.weight"], w[t + ".attn1.fused.fold"], o, Cn, batch, T, S,
                                     heads, 1e-5, scale)
         else:
@@ -729,13 +762,13 @@ class UNetHIP:
             a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], addvec=cond.cross[t], addvec_ld=Cn,
                               rows_per_vec=T * S, sum_out=hm, out=a)
         elif cond.P > 1:
-            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, stream=True)
+            hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, stream=tb(4))
             hm = self._cross_attention(t, hm, M, Cn, T * S, heads, cond)
             if not fold_ff:
                 a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
         else:
             hm = self._linear(o, t + ".attn1.to_out.0", M, res1=hm, rowvec=cond.cross[t], rowvec_ld=Cn, rows_per_vec=T * S,
-                              stream=True)
+                              stream=tb(4))
             if not fold_ff:
                 a = hip.layernorm(hm, M, Cn, w[t + ".norm3.weight"], w[t + ".norm3.bias"], out=a)
         # AlphaBlender: am*hs + (1-am)*(hm + ff(a)); with hs' = hs + emb stored: am*hs = am*hs' - am*emb, and the
@@ -748,7 +781,7 @@ class UNetHIP:
         else:
             hb = self._geglu_ff(a, t + ".ff", M, Cn, ln_input=lnin, alpha=1.0 - am, res1=hm, ldr1=Cn, beta1=1.0 - am, res2=hs,
                                 ldr2=Cn, beta2=am, stream=False)
-        return self._linear(hb, p + ".proj_out", M, res1=x, stream=True)
+        return hb
 
     # ------------------------------------------------------------------------------------------
     # forward
