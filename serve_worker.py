@@ -24,7 +24,7 @@ import wiw_amd  # noqa: F401  (registers the package under an importable name)
 from wiw_amd import frontend as FE
 from wiw_amd.config import UNetConfig
 from wiw_amd.pipeline import SVDDenoiser
-from wiw_amd.server.worker import SVDWorker, build_arg_parser, serve_tcp, validate_args, worker_main
+from wiw_amd.server.worker import SVDWorker, build_arg_parser, resolve_precision, serve_tcp, validate_args, worker_main
 from wiw_amd.unet import UNetHIP
 from wiw_amd.vae import HIPFrontend, VAEHIP
 from wiw_amd.weights import load_safetensors, random_state_dict
@@ -94,16 +94,8 @@ def build_worker(args, cfg: UNetConfig = None, vae_cfg: dict = None, clip=None) 
     # 16-bit storage / MFMA operand type of UNet, VAE and CLIP: fp16 (the reference's own default, eval_inference.py:294, and
     # the default here since round 6) or bf16 (BASELINE's dtype) — libwiwsvd_f16.so / libwiwsvd.so.  fp32 is not a serving dtype of
     # this path (the reference upcasts only the VAE encoder, pipeline:525-527).
-    names = {"bfloat16": torch.bfloat16, "bf16": torch.bfloat16, "torch.bfloat16": torch.bfloat16,
-             "float16": torch.float16, "fp16": torch.float16, "half": torch.float16, "torch.float16": torch.float16}
-    if args.weight_dtype not in names:
-        raise SystemExit(f"--weight_dtype {args.weight_dtype!r}: the HIP path serves bfloat16 or float16")
-    dtype = names[args.weight_dtype]
-    # the drop-in default (fp16) carries the fp32 residual stream unless told otherwise: the configuration inside north_star's
-    # 1e-3 in both norms on the reference's 25-step trajectory at the benchmarked size (worker.build_argparser)
-    res32 = (dtype == torch.float16) if args.residual_fp32 is None else bool(args.residual_fp32)
-    if res32 and args.residual_fp32_full:
-        res32 = "full"
+    dname, res32 = resolve_precision(args)     # float16 + the block-level fp32 residual stream unless told otherwise
+    dtype = getattr(torch, dname)
     unet = UNetHIP(cfg, unet_sd, args.device, dtype=dtype, residual_fp32=res32)
     den = SVDDenoiser(unet, use_graph=bool(args.hip_graph))   # graph replay by default, as bench.py measures
     clip = clip if clip is not None else _clip(args.svd_path, args.random_weights)

@@ -226,6 +226,24 @@ def test_unsupported_configurations_are_refused_at_startup():
             validate_args(ap.parse_args(bad.split()))
 
 
+def test_worker_precision_defaults_are_the_drop_in_ones():
+    """The launcher's defaults are the reference worker's dtype (float16, FTsvd/eval_inference.py:294) with the block-level fp32
+    residual stream — the configuration gated at <= 1e-3 on the reference's 25-step trajectory at the benchmarked size
+    (tests/test_hip_res32.py); bfloat16 (BASELINE's dtype) does not carry the stream unless asked to."""
+    from wiw_amd.server.worker import resolve_precision
+
+    ap = build_arg_parser()
+    assert resolve_precision(ap.parse_args([])) == ("float16", True)
+    assert resolve_precision(ap.parse_args(["--no-residual_fp32"])) == ("float16", False)
+    assert resolve_precision(ap.parse_args(["--residual_fp32_full"])) == ("float16", "full")
+    assert resolve_precision(ap.parse_args("--weight_dtype bfloat16".split())) == ("bfloat16", False)
+    assert resolve_precision(ap.parse_args("--weight_dtype bf16 --residual_fp32".split())) == ("bfloat16", True)
+    assert resolve_precision(ap.parse_args("--weight_dtype torch.float16".split())) == ("float16", True)
+    for bad in ("--weight_dtype float32", "--weight_dtype bfloat16 --residual_fp32_full", "--no-residual_fp32 --residual_fp32_full"):
+        with pytest.raises(SystemExit):
+            resolve_precision(ap.parse_args(bad.split()))
+
+
 def test_manipulation_requests_with_degenerate_quaternions_are_refused():
     """The reference raises inside scipy on a zero-norm / NaN quaternion (utils/svd_utils.py:357-375); the closed-form rotation
     here would decode NaN frames silently: `check_b_action` refuses before compute is committed."""

@@ -346,6 +346,24 @@ def build_arg_parser() -> argparse.ArgumentParser:
     return ap
 
 
+def resolve_precision(args):
+    """-> (dtype name, residual_fp32 of UNetHIP) from --weight_dtype / --residual_fp32 / --residual_fp32_full.  The drop-in
+    default (float16, the reference worker's dtype, eval_inference.py:294) carries the block-level fp32 residual stream unless
+    told otherwise: the configuration whose 25-step latents at 576x1024x14 are within 1e-3 of the reference pipeline's in both
+    norms; bfloat16 (BASELINE's dtype; rounding floor 5e-3) does not.  fp32 is not a serving dtype of this path."""
+    names = {"bfloat16": "bfloat16", "bf16": "bfloat16", "torch.bfloat16": "bfloat16",
+             "float16": "float16", "fp16": "float16", "half": "float16", "torch.float16": "float16"}
+    if args.weight_dtype not in names:
+        raise SystemExit(f"--weight_dtype {args.weight_dtype!r}: the HIP path serves bfloat16 or float16")
+    dtype = names[args.weight_dtype]
+    res32 = (dtype == "float16") if args.residual_fp32 is None else bool(args.residual_fp32)
+    if getattr(args, "residual_fp32_full", False):
+        if not res32:
+            raise SystemExit("--residual_fp32_full extends --residual_fp32 (on by default with float16 only)")
+        res32 = "full"
+    return dtype, res32
+
+
 def validate_args(args) -> None:
     """Configurations this build does not serve are refused at START-UP, not at the first client request (on every rank of
     a sharded server): --num_past_obs > 1 — the WM-server request has no field for past observations and the reference's
