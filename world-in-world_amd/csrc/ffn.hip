@@ -52,6 +52,12 @@
                         // 634-646 -> 615-620 us at M = 258 048 (profiles/r19g_ffn_freek.txt; timelines r19h); 0 = A/B knob
 #endif
 static_assert(!FFN_FREE_K || FFN_W1_BULK, "FFN_FREE_K needs the bulk W1 schedule");
+#ifndef FFN_BIAS_INIT
+#define FFN_BIAS_INIT FFN_FREE_K   // (needs FFN_FREE_K) 1 (round 6): the up-projection's accumulators START at the bias (b1's chunk is
+                                   // resident before the chunk's K phase: the Y-waves issue it with the bulk W1 tiles) instead of at
+                                   // zero — the GEGLU loses its 32 bias adds per lane and chunk (of ~300 VALU issues); 0 = A/B knob
+#endif
+static_assert(!FFN_BIAS_INIT || FFN_FREE_K, "FFN_BIAS_INIT needs the free-running K phase (bias resident at barrier A)");
 #ifndef FFN_ABLATE
 #define FFN_ABLATE 0   // timing-only builds (tools/build_variant.py): 1 no GELU math, 2 no phase-2 MFMAs, 3 no LDS-DMA, 4 no phase-1 MFMAs
 #endif
@@ -447,10 +453,12 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
         // one hidden chunk (H-wave side); LAST: compile-time "chunk NCH - 1 of its tile" (F32X only, see the loads below)
         auto chunk = [&](const int cc, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
+#if !FFN_BIAS_INIT
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
             // ---- slots 0..4: K tile kt.  The MFMAs of a K tile's second k-step run in the NEXT slot, under that slot's
             // first fragment reads, so the matrix pipe is not idle while a slot's first reads are in flight.
 #pragma unroll
@@ -458,6 +466,17 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                 FTP(0, 2 * kt);          // end of the previous slot's work
                 if (!FFN_FREE_K || kt == 0) slot_barrier();
                 FTP(0, 2 * kt + 1);      // barrier passed
+#if FFN_BIAS_INIT
+                if (kt == 0) {   // behind barrier A the chunk's bias is resident: both row blocks start at it (a lane's 4 columns)
+                    const char* bs0 = smem + BIAS_OFF + (cc & 1) * BIAS_BYTES + fq * 16;
+#pragma unroll
+                    for (int ni = 0; ni < 8; ++ni) {
+                        const float4 b = *(const float4*)(bs0 + (ni < 4 ? ni * 16 : HC + (ni - 4) * 16) * 4);
+                        acc[0][ni] = f32x4{b.x, b.y, b.z, b.w};
+                        acc[1][ni] = f32x4{b.x, b.y, b.z, b.w};
+                    }
+                }
+#endif
                 // two halves of [2 MFMAs | 1 ds_read_b128] x 8, order pinned: the first half runs the PENDING k-step (fragments
                 // fbB of the previous slot) while this K tile's k-step-0 fragments arrive, the second half runs k-step 0 while
                 // the k-step-1 fragments arrive — the reads' issue slots sit inside the MFMAs' pipe time (left alone the
@@ -511,6 +530,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int ni = 2 * np + h;
+#if FFN_BIAS_INIT
+                        (void)bs; bv[h] = bg[h] = float4{0.f, 0.f, 0.f, 0.f};      // the accumulators carry the bias already
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) g16[h * 8 + mi * 4 + r] = acc[mi][ni + 4][r];
+#else
                         bv[h] = *(const float4*)(bs + (ni * 16 + fq * 4) * 4);
                         bg[h] = *(const float4*)(bs + (HC + ni * 16 + fq * 4) * 4);
 #pragma unroll
@@ -518,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                             g16[h * 8 + mi * 4 + 0] = acc[mi][ni + 4][0] + bg[h].x; g16[h * 8 + mi * 4 + 1] = acc[mi][ni + 4][1] + bg[h].y;
                             g16[h * 8 + mi * 4 + 2] = acc[mi][ni + 4][2] + bg[h].z; g16[h * 8 + mi * 4 + 3] = acc[mi][ni + 4][3] + bg[h].w;
                         }
+#endif
                     }
 #if FFN_ABLATE != 1
                     gelu_erf16(g16);
@@ -530,8 +557,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
                             const f32x4 v = acc[mi][ni];
                             const float* g = g16 + h * 8 + mi * 4;
                             uint2 pk;
+#if FFN_BIAS_INIT
+                            pk.x = pack2bf(v[0] * g[0], v[1] * g[1]);
+                            pk.y = pack2bf(v[2] * g[2], v[3] * g[3]);
+#else
                             pk.x = pack2bf((v[0] + bv[h].x) * g[0], (v[1] + bv[h].y) * g[1]);
                             pk.y = pack2bf((v[2] + bv[h].z) * g[2], (v[3] + bv[h].w) * g[3]);
+#endif
                             // H[row][16*ni + 4*fq .. +3]: 16-byte chunk 2*ni + (fq >> 1) of the row, swizzled like every K tile
                             const int row = wq * 32 + mi * 16 + frow;
                             *(uint2*)(hb + row * 128 + (((2 * ni + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
@@ -596,6 +628,10 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
         // prologue: the five W1 K tiles of chunk 0; tile 0 has landed when <= 16 instructions are outstanding
 #pragma unroll
         for (int i = 0; i < NKT; ++i) issue_w1();
+#if FFN_BIAS_INIT
+        // ... and the bias of chunk 0: the H-waves' accumulators start at it (behind barrier A)
+        if (lane < 8) glds16((const char*)p.b1 + wq * 128 + lane * 16, smem + BIAS_OFF + wq * 128);
+#endif
         wait_vmcnt<FFN_FREE_K ? 0 : 4 * (NKT - 1)>();
         int h1 = 0, h2 = 0;
 #else
@@ -618,10 +654,12 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             FTP(1, 0);
             slot_barrier();
             FTP(1, 1);
+#if !FFN_BIAS_INIT
             if (cc < NC) {
                 if (lane < 8) glds16((const char*)p.b1 + c * (2 * HC * 4) + wq * 128 + lane * 16,
                                      smem + BIAS_OFF + (cc & 1) * BIAS_BYTES + wq * 128);
             }
+#endif
             if (cc >= 1) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -703,6 +741,13 @@ __global__ __launch_bounds__(512, 2) void ffn_kernel(const FfnArgs p) {
             if (bulk) {
 #pragma unroll
                 for (int i = 0; i < NKT; ++i) issue_w1();
+#if FFN_BIAS_INIT
+                // ... and the next chunk's bias (parity buffer last read at the start of chunk cc - 1's K phase): resident,
+                // like the W1 tiles, at the end of this iteration — the H-waves' accumulators start at it behind barrier A
+                const int cn = c + 1 == NCH ? 0 : c + 1;
+                if (lane < 8) glds16((const char*)p.b1 + cn * (2 * HC * 4) + wq * 128 + lane * 16,
+                                     smem + BIAS_OFF + ((cc + 1) & 1) * BIAS_BYTES + wq * 128);
+#endif
             }
 #endif
             if (cc >= 1) {
