@@ -457,9 +457,15 @@ def main():
                 rows = sorted(((k, v) for k, v in shapes.items()), key=lambda kv: -kv[1][0])
                 with open(args.dump_shapes, "w") as f:
                     for (mode, M, N, K, epi), (sec, cnt) in rows:
-                        f.write(f"mode={mode} M={M} N={N} K={K} epi={epi} launches={cnt} total_ms={1e3 * sec:.2f} "
-                                f"avg_us={1e6 * sec / cnt:.1f} tflops={2.0 * M * N * K * cnt / sec / 1e12:.1f} "
-                                f"algorithmic_MB={2.0 * (M * K / (9 if mode in (1, 2, 3, 5) else (3 if mode == 4 else 1)) + N * K + M * (N // 2 if epi & 1 else N) * (2 if epi & 4 else 1)) / 1e6:.1f}\n")
+                        n_out = N // 2 if epi & 1 else N
+                        nres = sum((2 if epi & f32 else 1) for has, f32 in ((PROF_RES1, 128), (PROF_RES2, 256)) if epi & has)
+                        # algorithmic bytes: the A operand once (not per tap), W, the output, the residual operands read (round 6)
+                        mb = 2.0 * (M * K / (9 if mode in (1, 2, 3, 5) else (3 if mode == 4 else 1)) + N * K
+                                    + M * n_out * ((2 if epi & 4 else 1) + nres)) / 1e6
+                        f.write(f"mode={mode} M={M} N={N} K={K} epi={epi & 0xFFFFFF} res={bool(epi & PROF_RES1) + bool(epi & PROF_RES2)} "
+                                f"launches={cnt} total_ms={1e3 * sec:.2f} avg_us={1e6 * sec / cnt:.1f} "
+                                f"tflops={2.0 * M * N * K * cnt / sec / 1e12:.1f} algorithmic_MB={mb:.1f} "
+                                f"algorithmic_GBps={mb * cnt / sec / 1e3:.0f}\n")
                     for k, v in (res.get("other_kernels") or {}).items():
                         f.write(f"family={k} " + " ".join(f"{a}={b}" for a, b in v.items()) + "\n")
         if args.end_to_end and world == 1 and not args.tiny:

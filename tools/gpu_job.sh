@@ -1,13 +1,11 @@
 #!/bin/bash
+# Per-call GPU job: `gpurun -- 'bash tools/gpu_job.sh TAG'`.  This file is edited for every experiment (its history is in
+# git); the committed form is the round-end check: full GPU suite (-rP: the measured parity values of every passing test),
+# smoke, default bench line -> gpurun_out/TAG/; `bash tools/profile_run.sh TAG` adds the rocprofv3 set.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-job}
 O=gpurun_out/$TAG; mkdir -p $O
-# r20g: fused FeedForward with the up-projection accumulators starting at the bias (FFN_BIAS_INIT): tests, same-box probe A/B
-timeout 900 python -m pytest tests/test_hip_ffn.py -q -m gpu -x 2>&1 | tail -3 | tee $O/${TAG}_ffn_tests.log
-for i in 1 2; do
-for v in shipped nobias; do
-  if [ $v = shipped ]; then L=""; else L="WIW_LIB=tools/ablate/libwiw_$v.so"; fi
-  echo "== $v: $(env $L ONLY_FUSED=1 ROUNDS=3 timeout 200 python tools/ffn_probe.py 2>&1 | grep BEST | tr '\n' ' ')"
-done
-done 2>&1 | tee $O/${TAG}_ffn_bias_init.txt
-timeout 1500 python -m pytest tests/test_hip_res32.py tests/test_hip_served_width.py tests/test_hip_unet.py -q -m gpu -x 2>&1 | tail -3 | tee -a $O/${TAG}_ffn_tests.log
+timeout 2400 python -m pytest tests -q -m gpu -rP > $O/${TAG}_gpu_suite_full.log 2>&1
+grep -n "passed\|failed\|rror" $O/${TAG}_gpu_suite_full.log | tail -6
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo "== bench"; T0=$SECONDS; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json; cut -c1-260 $O/${TAG}_bench.json; echo "bench.py wall: $((SECONDS - T0)) s"
