@@ -31,7 +31,7 @@ extern "C" {
 #define WIW_ELAUNCH -2 /* HIP launch error */
 #define WIW_ENODEV -3  /* no gfx950 device visible */
 
-#define WIW_ABI_VERSION 16  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
+#define WIW_ABI_VERSION 17  /* 2: WiwGemmArgs gained A3 / C3 (fused conv3x3 + shortcut segment);
                              3: wiw_temporal_attn_block_bf16; GroupNorm stats = (mean, variance);
                              4: WiwGemmArgs gained splitk / workspace; wiw_transpose_bf16;
                              5: wiw_dtype (the library exists in a bf16 and an fp16 build);
@@ -51,7 +51,8 @@ extern "C" {
                              14: wiw_ffn32_geglu (the fused FeedForward on 32x32x16 MFMAs, weights in the sw16 tiling)
                                 15: wiw_groupnorm_onepass / wiw_groupnorm_onepass_ok (one-pass GroupNorm of the inner levels);
                              16: wiw_ffn_geglu_f32stream2 (the fused FeedForward's LayerNorm reads the fp32 stream; a second,
-                                 16-bit output); wiw_cross_attn_fewkeys_bf16 (cross-attention over 2..8 conditioning tokens) */
+                                 16-bit output); wiw_cross_attn_fewkeys_bf16 (cross-attention over 2..8 conditioning tokens);
+                             17: wiw_calib_mfma_random (the box calibration loop on random operands: the SUSTAINED matrix-pipe rate) */
 
 int wiw_abi_version(void);
 
@@ -371,6 +372,10 @@ int wiw_cast_f32_to_16(void* stream, const float* X, int64_t n, void* out);
  * (v_mfma_f32_16x16x32, register operands, no memory traffic) per wave: blocks * 8 * iters * 8 * 16384 flop.  Timed by the
  * caller; what this box's clocks give the matrix pipe (the pool's boxes differ by +-5 %). */
 int wiw_calib_mfma(void* stream, int blocks, int iters, float* out);
+/* ABI 17: the same loop on random operands — src: 128 x 16 bytes of the library's 16-bit type (lane l: A = entry l, B = entry
+ * 64 + l), 16-byte aligned.  Held for about a second it measures what the board's power management lets the matrix pipe sustain
+ * (bench.py `box.mfma_sustained`); same flop count as wiw_calib_mfma. */
+int wiw_calib_mfma_random(void* stream, int blocks, int iters, const void* src, float* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Conditioning embedding rows (unet:464-487, micro_cond, no-grad path) with the SiLU of

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path, variant, code):
         assert hasattr(lib, name), f"{name} declared in wiw_svd.h but not exported by {os.path.basename(path)}"
     lib.wiw_abi_version.restype = ctypes.c_int
     lib.wiw_dtype.restype = ctypes.c_int
-    assert lib.wiw_abi_version() == 16 and lib.wiw_dtype() == code
+    assert lib.wiw_abi_version() == 17 and lib.wiw_dtype() == code
 
 
 def test_gemm_args_struct_layout():

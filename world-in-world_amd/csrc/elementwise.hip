@@ -221,6 +221,33 @@ __global__ __launch_bounds__(512, 2) void calib_mfma_kernel(int iters, float* ou
 }
 }  // namespace
 
+namespace {
+// ... and the same loop on RANDOM operands (src: 128 x 16 bytes of the library's 16-bit type, N(0, 0.5): lane l takes A from
+// entry l, B from entry 64 + l).  Power follows the data: held for a second this is what the board's power management lets
+// the matrix pipe SUSTAIN (bench.py `box.mfma_sustained`), where the near-constant operands of the burst above toggle little.
+__global__ __launch_bounds__(512, 2) void calib_mfma_random_kernel(const bf16x8* __restrict__ src, int iters, float* out) {
+    const int lane = threadIdx.x & 63;
+    const bf16x8 a = src[lane], b = src[64 + lane];
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = WIW_MFMA(a, b, acc[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (s == 12345.678f) out[0] = s;   // never true: keeps the loop alive
+}
+}  // namespace
+
+extern "C" int wiw_calib_mfma_random(void* stream, int blocks, int iters, const void* src, float* out) {
+    WIW_REQUIRE(blocks > 0 && iters > 0 && src != nullptr && out != nullptr && (((uintptr_t)src) & 15) == 0, "calib_mfma_random: bad arguments");
+    hipLaunchKernelGGL(calib_mfma_random_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, (const bf16x8*)src, iters, out);
+    return wiw_check_launch("wiw_calib_mfma_random");
+}
+
 /* Box calibration: `blocks` blocks of 8 waves run `iters` x 8 MFMAs (16x16x32, 16 384 flop each) per wave; the caller times
  * it with events: flops = blocks * 8 * iters * 8 * 16384. */
 extern "C" int wiw_calib_mfma(void* stream, int blocks, int iters, float* out) {

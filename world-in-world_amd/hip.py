@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import Optional
 
 import torch
@@ -156,6 +157,7 @@ EXPORTS = {
     "wiw_layernorm_f32in": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "wiw_cast_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "wiw_calib_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "wiw_calib_mfma_random": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wiw_emb_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]),
     "wiw_prep_unet_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -228,7 +230,7 @@ class Hip:
             raise ValueError("Hip: dtype must be torch.bfloat16 or torch.float16")
         self.dtype = dtype
         self.lib = load_library(LIB_PATH if dtype == torch.bfloat16 else LIB_PATH_F16)
-        if self.lib.wiw_abi_version() != 16:
+        if self.lib.wiw_abi_version() != 17:
             raise RuntimeError("libwiwsvd ABI version mismatch")
         if self.lib.wiw_dtype() != DTYPE_CODES[dtype]:
             raise RuntimeError("the loaded library was built for the other 16-bit type (wiw_dtype mismatch)")
@@ -583,9 +585,10 @@ class Hip:
             self.lib.wiw_cast_f32_to_16(self._stream(), _p(X), X.numel(), out.data_ptr()), "wiw_cast_f32_to_16"))
         return out
 
-    def calibrate_box(self, target_ms: float = 50.0):
-        """What THIS box gives (bench.py `box`): a pure-MFMA launch of ~target_ms (register operands, one 8-wave block per CU)
-        and a 1 GiB device copy, both timed with events.  -> dict(mfma_tflops, copy_GBps, cus)."""
+    def calibrate_box(self, target_ms: float = 50.0, sustain_s: float = 1.5):
+        """What THIS box gives (bench.py `box`): a pure-MFMA launch of ~target_ms (register operands, one 8-wave block per CU),
+        the same loop on random operands held for `sustain_s` seconds, and a 1 GiB device copy, all timed with events.
+        -> dict(mfma_tflops, mfma_sustained_tflops, copy_GBps, cus)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         out = torch.zeros(4, dtype=torch.float32, device=self.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -601,6 +604,24 @@ class Hip:
         iters = max(20000, int(20000 * target_ms / max(ms, 1e-3)))
         ms = min(run(iters), run(iters))
         tf = cus * 8.0 * iters * 8 * 16384 / (ms * 1e-3) / 1e12
+        # ... and what the power management lets the matrix pipe SUSTAIN: the same loop on random N(0, 0.5) operands, launches of
+        # ~target_ms back to back for `sustain_s` seconds, the rate of the second half (round 6: a 6-s hold of this loop settles at
+        # 1.98 PFLOP/s / 2 057 MHz / 1.31 kW where the burst above reads 2.36, profiles/r19a_mfma_energy.txt)
+        sustained = None
+        if sustain_s > 0:
+            g = torch.Generator(device="cpu").manual_seed(7)
+            src = (torch.randn(128 * 8, generator=g) * 0.5).to(self.dtype).to(self.device)
+            t_end = time.perf_counter() + sustain_s
+            evs = []
+            while time.perf_counter() < t_end:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self._ck(self.lib.wiw_calib_mfma_random(self._stream(), cus, iters, src.data_ptr(), out.data_ptr()), "wiw_calib_mfma_random")
+                b.record()
+                b.synchronize()
+                evs.append(a.elapsed_time(b))
+            half = evs[len(evs) // 2:]
+            sustained = cus * 8.0 * iters * 8 * 16384 / (sum(half) / len(half) * 1e-3) / 1e12
         src = torch.empty(1 << 28, dtype=torch.float32, device=self.device)
         dst = torch.empty_like(src)
         dst.copy_(src)
@@ -611,7 +632,8 @@ class Hip:
         e1.synchronize()
         gbps = 4 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-        return {"mfma_tflops": round(tf, 1), "copy_GBps": round(gbps, 1), "cus": cus}
+        return {"mfma_tflops": round(tf, 1), "mfma_sustained_tflops": None if sustained is None else round(sustained, 1),
+                "copy_GBps": round(gbps, 1), "cus": cus}
 
     def transpose(self, X, ldx, c0, rows, Cn, Y, ldy):
         """Y[c][r] = X[r][c0 + c] (bf16)."""
