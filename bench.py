@@ -361,7 +361,7 @@ def main():
             res["box"] = {"mfma_peak_measured": box["mfma_tflops"], "mfma_sustained": box.get("mfma_sustained_tflops"),
                           "mfma_peak_unit": "TFLOP/s", "hbm_copy_GBps": box["copy_GBps"],
                           "cus": box["cus"], "what": "a ~50 ms launch of back-to-back MFMAs on (near-constant) register operands, 8 "
-                          "waves per CU; mfma_sustained: the same loop on random N(0, 0.5) operands held for 1.5 s, rate of the second "
+                          "waves per CU; mfma_sustained: the same loop on random N(0, 0.5) operands held for 1 s, rate of the second "
                           "half = what the board's power management lets the matrix pipe sustain; a 1 GiB device copy (read + write "
                           "bytes); all measured on this box before the timed region"}
         if power is not None:

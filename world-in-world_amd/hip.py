@@ -585,7 +585,7 @@ class Hip:
             self.lib.wiw_cast_f32_to_16(self._stream(), _p(X), X.numel(), out.data_ptr()), "wiw_cast_f32_to_16"))
         return out
 
-    def calibrate_box(self, target_ms: float = 50.0, sustain_s: float = 1.5):
+    def calibrate_box(self, target_ms: float = 50.0, sustain_s: float = 1.0):
         """What THIS box gives (bench.py `box`): a pure-MFMA launch of ~target_ms (register operands, one 8-wave block per CU),
         the same loop on random operands held for `sustain_s` seconds, and a 1 GiB device copy, all timed with events.
         -> dict(mfma_tflops, mfma_sustained_tflops, copy_GBps, cus)."""
