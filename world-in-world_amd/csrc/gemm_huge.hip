@@ -44,8 +44,10 @@
 
 #include "common.h"
 #ifndef WIW_GE_PK
-#define WIW_GE_PK 0   // 1: GEGLU epilogue on packed pairs, breadth first (gelu_erf_pk) — measured 3 % SLOWER here (K = 640: 595 vs
-                      // 577 us, K = 1280: 420 vs 415 us, profiles/r06a_geglu_epilogue_ab.txt; +3 % in the 128x160 kernel of gemm.hip)
+#define WIW_GE_PK 1   // 1: GEGLU epilogue on packed pairs, breadth first (gelu_erf_pk).  Round 3 measured it 3 % SLOWER here with the
+                      // A&S 7.1.26 erf (14 VALU: K = 640 595 vs 577 us, profiles/r06a_geglu_epilogue_ab.txt); with round 5's fitted
+                      // sigmoid form (10 VALU, 13 issues per PAIR packed) it is FASTER: M = 64 512, K = 640: 470-476 -> 455-462 us,
+                      // M = 16 128, K = 1280: 348-351 -> 344 us (profiles/r20l_geglu_epilogue_pk_ab.txt), bit-identical results; 0 = A/B
 #endif
 
 namespace {
