@@ -1057,3 +1057,18 @@ def test_conv3x3_halo_staged_kernel(hip):
     with pytest.raises(RuntimeError, match="HALO32"):
         hip.gemm(dev_bf(nhwc(x)), H.TiledW(dev_bf(conv_k_halo32(wt.permute(0, 2, 3, 1).reshape(cout, -1)))), out, M=n * h * w,
                  N=cout, K=9 * c, C1=c, mode=H.A_CONV3X3, H=h, Wd=w, epilogue=H.K_HALO32)
+
+
+def test_box_calibration_burst_and_sustained(hip):
+    """`Hip.calibrate_box` (bench.py's `box` object): the burst figure of the matrix pipe (wiw_calib_mfma, near-constant register
+    operands), what it SUSTAINS on random operands under the board's power management (wiw_calib_mfma_random, ABI 17) and the
+    device copy rate are plausible for an MI355X: sustained <= burst <= the 2.5 PFLOP/s dense figure (+ a margin for fp16's
+    2.4 % higher burst), copy between 2 and 8 TB/s; bad arguments are refused."""
+    r = hip.calibrate_box(sustain_s=0.3)
+    assert r["cus"] >= 200
+    assert 1000.0 < r["mfma_sustained_tflops"] <= r["mfma_tflops"] * 1.02 and r["mfma_tflops"] < 2600.0
+    assert 2000.0 < r["copy_GBps"] < 8000.0
+    assert hip.calibrate_box(sustain_s=0.0)["mfma_sustained_tflops"] is None
+    out = torch.zeros(4, dtype=torch.float32, device=DEV)
+    assert hip.lib.wiw_calib_mfma_random(None, 256, 1000, None, out.data_ptr()) == -1
+    assert b"calib_mfma_random" in hip.lib.wiw_last_error()
