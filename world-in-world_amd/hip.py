@@ -27,6 +27,7 @@ K_CMAJOR = 512   # conv modes: K of W is channel-block major, k = ((c / 64) * ta
 GEGLU_TILE = 80  # value|gate half-tile width of the packed GEGLU weights (gemm.hip BN / 2)
 FFN_CHUNK = 64   # hidden units per chunk of the fused FeedForward kernel (ffn.hip): W1 rows in chunks of [64 value | 64 gate]
 FFN_C, FFN_HIDDEN = 320, 1280   # the one shape wiw_ffn_geglu_bf16 is built for
+_GN_RPB_R5 = bool(os.environ.get("WIW_GN_RPB_R5"))
 PROF_RES1, PROF_RES2 = 1 << 24, 1 << 25   # bench.py profile keys only: the launch read a res1 / res2 operand
 
 
@@ -464,10 +465,21 @@ class Hip:
         """Block size of the statistics pass — a function of the unit size and the KIND of norm only (never of the
         batch): per-frame norms (28+ units per request) use large blocks, per-clip norms (one unit per CFG item:
         TemporalResnetBlock) split a unit into ~500 blocks."""
+        # round 6 sweep on the final library (profiles/r20r_gn_stats_rpb_sweep.txt, 16-bit input, statistics pass alone): larger
+        # blocks win at the two outer levels — per-frame 72x128: 128 -> 256 rows 38.7 -> 32.7 us (C = 320), 65.6 -> 59.1 (C = 640);
+        # per-frame 36x64: 64 -> 128 rows 23.3 -> 21.0 us (C = 640), 34.7 -> 32.5 (C = 1280; 256 is slower there); per-clip 36x64
+        # (32 256 rows): 64 -> 128 rows 28.0 -> 25.9 us.  The inner levels run the one-pass kernel and do not come here.
+        if _GN_RPB_R5:      # A/B knob WIW_GN_RPB_R5=1: the block sizes of rounds 4-5
+            if not clip:
+                return 128 if rows_per_unit >= 8192 else (64 if rows_per_unit >= 2048 else (32 if rows_per_unit >= 512 else 16))
+            rpb = 16
+            while rpb < 256 and rpb * 2 * 448 <= rows_per_unit:
+                rpb *= 2
+            return rpb
         if not clip:
-            return 128 if rows_per_unit >= 8192 else (64 if rows_per_unit >= 2048 else (32 if rows_per_unit >= 512 else 16))
+            return 256 if rows_per_unit >= 8192 else (128 if rows_per_unit >= 2048 else (32 if rows_per_unit >= 512 else 16))
         rpb = 16
-        while rpb < 256 and rpb * 2 * 448 <= rows_per_unit:
+        while rpb < 256 and rpb * 448 <= rows_per_unit:
             rpb *= 2
         return rpb
 
