@@ -499,6 +499,12 @@ __global__ __launch_bounds__(GN1_THREADS) void gn_onepass_kernel(const uint16_t*
 // LayerNorm: one wave per row, row held in registers (C <= 2048 -> <= 4 chunks of 8 per lane),
 // exact two-pass mean / variance with 64-lane butterfly reductions.
 // ---------------------------------------------------------------------------------------------
+#ifndef LN_R_MID
+#define LN_R_MID 2     // rows in flight per wave at 512 < C <= 1024 (A/B knob)
+#endif
+#ifndef LN_R_WIDE
+#define LN_R_WIDE 1    // ... at C > 1024
+#endif
 constexpr int LN_MAXCH = 4;
 constexpr int LN_RUN = 8;      // consecutive rows per wave
 
@@ -781,8 +787,8 @@ extern "C" int wiw_layernorm_bf16(void* stream, const void* X, int64_t rows, int
     hipLaunchKernelGGL((layernorm_kernel<NCH, R, false>), grid, dim3(256), 0, (hipStream_t)stream, X, rows, C,        \
                        gamma, beta, eps, addvec, addvec_ld, rows_per_vec, (uint16_t*)sum_out, (uint16_t*)out)
     if (C <= 512) WIW_LN_LAUNCH(1, 8);
-    else if (C <= 1024) WIW_LN_LAUNCH(2, 2);
-    else WIW_LN_LAUNCH(4, 1);
+    else if (C <= 1024) WIW_LN_LAUNCH(2, LN_R_MID);
+    else WIW_LN_LAUNCH(4, LN_R_WIDE);
 #undef WIW_LN_LAUNCH
     return wiw_check_launch("wiw_layernorm_bf16");
 }
